@@ -1,0 +1,126 @@
+"""ctypes binding of oracle/fpc_oracle.c -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; the product package never does (tests/test_no_oracle_in_product.py).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libfpc_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force=False):
+    src = os.path.join(_DIR, "fpc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _DIR, "-B", "libfpc_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_forward.restype = ctypes.c_int
+        _lib.oracle_get_points.restype = ctypes.c_int
+        _lib.oracle_get_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def set_threads(n):
+    lib().oracle_set_threads(ctypes.c_int(n))
+
+
+def max_threads():
+    return lib().oracle_get_max_threads()
+
+
+TAP_NAMES = ["stem", "pool", "layer1.0", "layer1.1", "layer2.0", "layer2.1", "det.0", "det.1",
+             "desc_in.0", "desc_in.1", "up", "desc_out.0", "desc_out.1"]
+
+
+def tap_shapes(b, h, w):
+    h2, w2, h4, w4, h8, w8, h16, w16 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8, h // 16, w // 16
+    return [(b, 64, h2, w2), (b, 64, h4, w4), (b, 64, h4, w4), (b, 64, h4, w4), (b, 128, h8, w8),
+            (b, 128, h8, w8), (b, 65, h8, w8), (b, 65, h8, w8), (b, 256, h16, w16),
+            (b, 256, h16, w16), (b, 128, h8, w8), (b, 128, h8, w8), (b, 128, h8, w8)]
+
+
+def weight_ptrs(state_dict, spec):
+    """Array of 163 float* in state_dict order (NULL for the int64 counters)."""
+    keep = []
+    arr = (_f32p * len(spec))()
+    for i, name in enumerate(spec):
+        v = state_dict[name]
+        if v.dtype == np.float32:
+            v = np.ascontiguousarray(v)
+            keep.append(v)
+            arr[i] = _p(v)
+        else:
+            arr[i] = None
+    return arr, keep
+
+
+def forward(image, state_dict, spec, descriptor_enabled=True, with_taps=False):
+    """image float32 [B,3,H,W] -> (prob_map [B,H,W], desc [B,128,H/8,W/8], logits [B,65,H/8,W/8][, taps])."""
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    b, c, h, w = image.shape
+    assert c == 3
+    prob = np.empty((b, h, w), np.float32)
+    desc = np.empty((b, 128, h // 8, w // 8), np.float32)
+    logits = np.empty((b, 65, h // 8, w // 8), np.float32)
+    wp, keep = weight_ptrs(state_dict, spec)
+    taps = None
+    tap_arr = None
+    if with_taps:
+        taps = [np.empty(s, np.float32) for s in tap_shapes(b, h, w)]
+        tap_arr = (_f32p * len(taps))(*[_p(t) for t in taps])
+    rc = lib().oracle_forward(_p(image), wp, b, h, w, int(bool(descriptor_enabled)), _p(prob),
+                              _p(desc), _p(logits), tap_arr)
+    if rc != 0:
+        raise ValueError("oracle_forward: H and W must be multiples of 16")
+    del keep
+    if with_taps:
+        return prob, desc, logits, dict(zip(TAP_NAMES, taps))
+    return prob, desc, logits
+
+
+def get_points(prob, conf_thresh=0.015, nms_dist=4, border_remove=4):
+    """prob float32 [H,W] -> (xs int32[K], ys int32[K], conf float32[K], n_candidates)."""
+    prob = np.ascontiguousarray(prob, dtype=np.float32)
+    h, w = prob.shape
+    cap = h * w
+    xs = np.empty(cap, np.int32)
+    ys = np.empty(cap, np.int32)
+    conf = np.empty(cap, np.float32)
+    ncand = ctypes.c_int(0)
+    k = lib().oracle_get_points(_p(prob), h, w, ctypes.c_float(conf_thresh), nms_dist,
+                                border_remove, xs.ctypes.data_as(_i32p), ys.ctypes.data_as(_i32p),
+                                _p(conf), cap, ctypes.byref(ncand))
+    return xs[:k].copy(), ys[:k].copy(), conf[:k].copy(), ncand.value
+
+
+def get_descriptors(desc_map, xs, ys, h, w):
+    """desc_map float32 [D,Hc,Wc], points -> float32 [K,D] unit-norm rows."""
+    desc_map = np.ascontiguousarray(desc_map, dtype=np.float32)
+    d, hc, wc = desc_map.shape
+    xs = np.ascontiguousarray(xs, np.int32)
+    ys = np.ascontiguousarray(ys, np.int32)
+    k = len(xs)
+    out = np.empty((k, d), np.float32)
+    if k:
+        lib().oracle_get_descriptors(_p(desc_map), d, hc, wc, h, w, xs.ctypes.data_as(_i32p),
+                                     ys.ctypes.data_as(_i32p), k, _p(out))
+    return out

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ by running the REFERENCE's own
+hot-path modules (imported from /root/reference/python, read-only) on seeded
+inputs.  Run in the build container only; the reference does not travel:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is imported from the reference: src.settings.SuperPointSettings,
+src.superpoint.SuperPoint, src.netutils.{get_points, get_descriptors,
+restore_prob_map}, src.nms.corners_nms, src.saveutils.load_checkpoint_for_inference.
+`src/inferencewrapper.py` itself is not importable here (needs cv2 / torchvision /
+torchsummary), so its 5-line `run()` (inferencewrapper.py:38-46) is restated below
+by calling the three functions it calls.
+
+Inputs (weights, frames) come from feature-point-cnn_amd/synth.py and are NOT
+stored: the tests regenerate them from the seeds recorded in each fixture.
+The fixtures hold data only (inputs where they are hand-built, expected outputs).
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/python")
+sys.dont_write_bytecode = True
+
+import fpc_amd  # noqa: E402,F401
+from fpc_amd import arch, synth  # noqa: E402
+from src.netutils import get_descriptors, get_points, restore_prob_map  # noqa: E402
+from src.nms import corners_nms  # noqa: E402,F401
+from src.saveutils import load_checkpoint_for_inference  # noqa: E402
+from src.settings import SuperPointSettings  # noqa: E402
+from src.superpoint import SuperPoint  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def build_net(seed, dustbin_bias, via_checkpoint=False):
+    settings = SuperPointSettings()
+    net = SuperPoint(settings)
+    sd = synth.make_state_dict(seed, dustbin_bias)
+    tsd = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    if via_checkpoint:
+        # the reference's own file layout (saveutils.py:57-62) through its own loader
+        with tempfile.TemporaryDirectory() as d:
+            f = os.path.join(d, "super_point_0.pt")
+            torch.save({"epoch": 0, "model_state_dict": tsd, "optimizer_state_dict": {},
+                        "scaler_state_dict": {}}, f)
+            assert load_checkpoint_for_inference(f, net)
+    else:
+        net.load_state_dict(tsd, strict=True)
+    net.eval()
+    return net, settings, sd
+
+
+def min_tie_margin(points_in, h, w, r):
+    """Smallest relative confidence gap between two threshold candidates that lie
+    within infinity-distance r of each other (their greedy order decides the NMS
+    result).  0.0 means an exact tie: the reference result is then ambiguous."""
+    grid = np.zeros((h + 2 * r, w + 2 * r), np.float64)
+    xs, ys, c = points_in[0].astype(int), points_in[1].astype(int), points_in[2]
+    grid[ys + r, xs + r] = c
+    best = np.inf
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            if dy == 0 and dx == 0:
+                continue
+            nb = grid[ys + r + dy, xs + r + dx]
+            m = nb > 0
+            if m.any():
+                best = min(best, np.min(np.abs(nb[m] - c[m]) / c[m]))
+    return float(best)
+
+
+def run_frame(net, settings, frame_hwc):
+    """InferenceWrapper.run (inferencewrapper.py:29-46) restated."""
+    with torch.no_grad():
+        x = torch.from_numpy(frame_hwc.copy().transpose(2, 0, 1)).unsqueeze(0)  # prepare_input :70-81
+        h, w = x.shape[2], x.shape[3]
+        prob, desc_map, logits = net(x)
+        points = get_points(prob, h, w, settings)
+        desc = get_descriptors(points, desc_map, h, w, settings)
+    return prob, desc_map, logits, points, desc
+
+
+def golden_layers():
+    """F1: per-layer activations, 1x3x32x48, non-trivial BN statistics."""
+    net, settings, _ = build_net(seed=11, dustbin_bias=2.0)
+    frame = synth.make_frame(7, 32, 48)
+    acts = {}
+    mods = {
+        "stem": net.encoder.relu, "pool": net.encoder.max_pool,
+        "layer1.0": net.encoder.layer1[0], "layer1.1": net.encoder.layer1[1],
+        "layer2.0": net.encoder.layer2[0], "layer2.1": net.encoder.layer2[1],
+        "det.0": net.detector.layer[0], "det.1": net.detector.layer[1],
+        "desc_in.0": net.descriptor.layer_in[0], "desc_in.1": net.descriptor.layer_in[1],
+        "up": net.descriptor.relu,
+        "desc_out.0": net.descriptor.layer_out[0], "desc_out.1": net.descriptor.layer_out[1],
+    }
+    hooks = [m.register_forward_hook(lambda mod, i, o, n=n: acts.__setitem__(n, o.detach().numpy().copy()))
+             for n, m in mods.items()]
+    prob, desc_map, logits, points, desc = run_frame(net, settings, frame)
+    for hk in hooks:
+        hk.remove()
+    out = {"tap_" + k: v for k, v in acts.items()}
+    out.update(seed_weights=11, dustbin_bias=2.0, seed_frame=7, h=32, w=48,
+               prob=prob.numpy(), desc_map=desc_map.numpy(), logits=logits.numpy())
+    np.savez(os.path.join(HERE, "f1_layers_32x48.npz"), **out)
+    print("F1 layers: taps", {k: v.shape for k, v in acts.items()})
+
+
+def golden_restore():
+    """F2: restore_prob_map (netutils.py:64-75) on an arange tensor."""
+    t = torch.arange(2 * 65 * 2 * 3, dtype=torch.float32).reshape(2, 65, 2, 3)
+    out = restore_prob_map(t, 16, 24, 8).numpy()
+    np.savez(os.path.join(HERE, "f2_restore_prob_map.npz"), inp=t.numpy(), out=out)
+    print("F2 restore_prob_map", out.shape)
+
+
+def golden_get_points():
+    """F3: get_points (netutils.py:78-100 -> nms.py:4-53) on hand-built and random
+    tie-free probability maps.  Stored sparse: (flat index, value) of non-zeros."""
+    settings = SuperPointSettings()
+    cases = {}
+
+    def add(name, h, w, pts):
+        pm = np.zeros((1, h, w), np.float32)
+        for (x, y, c) in pts:
+            pm[0, y, x] = c
+        res = get_points(torch.from_numpy(pm), h, w, settings)
+        nz = np.flatnonzero(pm[0])
+        cases[name + "_hw"] = np.array([h, w], np.int32)
+        cases[name + "_idx"] = nz.astype(np.int32)
+        cases[name + "_val"] = pm[0].ravel()[nz]
+        cases[name + "_out"] = np.asarray(res, dtype=np.float64)
+        return res
+
+    add("empty", 32, 48, [])
+    add("below_thresh", 32, 48, [(10, 10, 0.0149)])
+    add("single", 32, 48, [(10, 12, 0.5)])
+    add("single_border", 32, 48, [(2, 12, 0.5)])                      # returned by nms, then cropped
+    add("pair_d4", 32, 48, [(10, 10, 0.9), (14, 10, 0.8)])            # inf-distance 4: suppressed
+    add("pair_d5", 32, 48, [(10, 10, 0.9), (15, 10, 0.8)])            # inf-distance 5: both kept
+    add("pair_diag4", 32, 48, [(10, 10, 0.9), (14, 14, 0.8)])
+    add("chain", 32, 48, [(8, 10, 0.9), (12, 10, 0.8), (16, 10, 0.7), (20, 10, 0.6)])   # a,c kept; b,d? d kept? greedy
+    add("border_suppresses", 32, 48, [(2, 10, 0.9), (5, 10, 0.8), (10, 3, 0.95), (10, 6, 0.5),
+                                      (46, 20, 0.7), (43, 20, 0.6), (20, 30, 0.9), (20, 27, 0.85)])
+    add("corners", 32, 48, [(0, 0, 0.9), (47, 31, 0.8), (47, 0, 0.7), (0, 31, 0.6), (4, 4, 0.5),
+                            (43, 27, 0.4), (44, 27, 0.45)])
+    rng = np.random.Generator(np.random.PCG64(5))
+    pts = [(int(x), int(y), float(c)) for x, y, c in zip(rng.integers(12, 20, 30), rng.integers(12, 20, 30),
+                                                         rng.permutation(30) * 0.01 + 0.02)]
+    add("dense_cluster", 32, 48, pts)
+    add("threshold_edge", 32, 48, [(10, 10, 0.015), (20, 10, float(np.nextafter(np.float32(0.015), np.float32(0)))),
+                                   (30, 10, float(np.nextafter(np.float32(0.015), np.float32(1))))])
+    for name, (h, w, n, seed) in {"rand_64x96": (64, 96, 700, 1), "rand_120x160": (120, 160, 3000, 2),
+                                  "rand_full_48x64": (48, 64, 48 * 64, 3)}.items():
+        rng = np.random.Generator(np.random.PCG64(seed))
+        idx = rng.choice(h * w, n, replace=False)
+        vals = (0.02 + 0.9 * rng.permutation(n) / n).astype(np.float32)   # distinct -> tie-free
+        assert len(np.unique(vals)) == n
+        res = add(name, h, w, [(int(i % w), int(i // w), float(v)) for i, v in zip(idx, vals)])
+        print("F3", name, "candidates", n, "kept", res.shape[1])
+    np.savez(os.path.join(HERE, "f3_get_points.npz"), **cases)
+    print("F3 get_points cases:", sorted({k.rsplit('_', 1)[0] for k in cases}))
+
+
+def golden_get_descriptors():
+    """F4: get_descriptors (netutils.py:103-121) on a small descriptor map."""
+    settings = SuperPointSettings()
+    rng = np.random.Generator(np.random.PCG64(9))
+    d, hc, wc = 16, 6, 8
+    h, w = hc * 8, wc * 8
+    dm = rng.uniform(0.0, 2.0, (1, d, hc, wc)).astype(np.float32)
+    xs = np.array([4, w - 5, 4, w - 5, 0, w - 1, 8, 16, 33, 17, 63, 32, 5], np.float64)
+    ys = np.array([4, h - 5, h - 5, 4, 0, h - 1, 8, 24, 17, 40, 47, 24, 44], np.float64)
+    pts = np.stack([xs, ys, np.linspace(0.9, 0.1, len(xs))])
+    out = get_descriptors(pts, torch.from_numpy(dm), h, w, settings)
+    empty = get_descriptors(np.zeros((3, 0)), torch.from_numpy(dm), h, w, settings)
+    assert empty.shape == (d, 0)
+    np.savez(os.path.join(HERE, "f4_get_descriptors.npz"), desc_map=dm, points=pts, out=out,
+             hw=np.array([h, w], np.int32))
+    print("F4 get_descriptors", out.shape)
+
+
+def golden_end_to_end():
+    """F5: full path on whole frames: keypoints, confidences, a descriptor subset and
+    strided probes of the dense maps."""
+    for tag, h, w, wseed, dust, fseed, descriptor in [
+            ("qvga", 240, 320, 21, 7.0, 300, True),
+            ("vga", 480, 640, 0, 7.0, 100, True),
+            ("magicpoint_qvga", 240, 320, 22, 7.0, 301, False)]:
+        net, settings, _ = build_net(wseed, dust, via_checkpoint=(tag == "vga"))
+        if not descriptor:
+            net.disable_descriptor()          # superpoint.py:74-78, 103-109
+        frame = synth.make_frame(fseed, h, w)
+        prob, desc_map, logits, points, desc = run_frame(net, settings, frame)
+        p = prob.numpy()
+        ys_, xs_ = np.where(p[0] >= settings.confidence_thresh)
+        cand = np.stack([xs_.astype(np.float64), ys_.astype(np.float64), p[0, ys_, xs_].astype(np.float64)])
+        margin = min_tie_margin(cand, h, w, settings.nms_dist)
+        thr_margin = float(np.min(np.abs(p - np.float32(settings.confidence_thresh))))
+        k = points.shape[1]
+        sub = np.arange(0, k, 16)
+        out = dict(h=h, w=w, seed_weights=wseed, dustbin_bias=dust, seed_frame=fseed,
+                   descriptor_enabled=int(descriptor), n_candidates=len(xs_),
+                   tie_margin=margin, thresh_margin=thr_margin,
+                   points_x=points[0].astype(np.int16), points_y=points[1].astype(np.int16),
+                   points_conf=points[2].astype(np.float32),
+                   desc_subset_idx=sub.astype(np.int32), desc_subset=desc[:, sub].T.astype(np.float32).copy(),
+                   logits_probe=logits.numpy().ravel()[::7].copy(),
+                   desc_map_probe=desc_map.numpy().ravel()[::11].copy(),
+                   prob_probe=p.ravel()[::13].copy(),
+                   logits_sum=float(logits.double().sum()), desc_map_sum=float(desc_map.double().sum()))
+        np.savez(os.path.join(HERE, "f5_e2e_%s.npz" % tag), **out)
+        print("F5", tag, "candidates", len(xs_), "kept", k, "tie margin %.3g" % margin,
+              "thresh margin %.3g" % thr_margin, "NaN desc:", int(np.isnan(desc).sum()))
+
+
+if __name__ == "__main__":
+    golden_layers()
+    golden_restore()
+    golden_get_points()
+    golden_get_descriptors()
+    golden_end_to_end()
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print("total fixture bytes", tot)

@@ -1,0 +1,124 @@
+"""Pins the CPU oracle (oracle/fpc_oracle.c) against the golden vectors produced by the
+reference's own python modules (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import fpc_amd  # noqa: F401
+from fpc_amd import arch, synth
+from oracle import oracle
+
+SPEC = arch.state_dict_spec()
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_spec_matches_survey_table_w():
+    assert len(SPEC) == 163
+    assert sum(int(np.prod(s)) for s in SPEC.values()) == 2352378
+    assert arch.conv_macs(480, 640) == 8304897600
+    assert abs(arch.conv_macs(240, 320, descriptor=False) * 2 / 1e9 - 2.127) < 1e-3
+
+
+def test_f1_per_layer_activations(golden_dir):
+    g = load(golden_dir, "f1_layers_32x48.npz")
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_frame(int(g["seed_frame"]), int(g["h"]), int(g["w"]))
+    prob, desc, logits, taps = oracle.forward(frame.transpose(2, 0, 1)[None], sd, SPEC, with_taps=True)
+    for name in oracle.TAP_NAMES:
+        ref = g["tap_" + name]
+        got = taps[name]
+        assert got.shape == ref.shape, name
+        # the reference is fp32 (oneDNN); the oracle accumulates in double: a few 1e-7 relative
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5, err_msg=name)
+    np.testing.assert_allclose(logits, g["logits"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(desc, g["desc_map"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(prob, g["prob"], rtol=2e-5, atol=1e-7)
+
+
+def test_f2_restore_prob_map(golden_dir):
+    g = load(golden_dir, "f2_restore_prob_map.npz")
+    inp = np.ascontiguousarray(g["inp"])
+    b, c, hc, wc = inp.shape
+    out = np.empty((b, hc * 8, wc * 8), np.float32)
+    oracle.lib().oracle_restore_prob_map(oracle._p(inp), oracle._p(out), b, hc, wc, 8)
+    np.testing.assert_array_equal(out, g["out"])
+
+
+F3_CASES = ["empty", "below_thresh", "single", "single_border", "pair_d4", "pair_d5", "pair_diag4",
+            "chain", "border_suppresses", "corners", "dense_cluster", "threshold_edge",
+            "rand_64x96", "rand_120x160", "rand_full_48x64"]
+
+
+def f3_case(g, name):
+    h, w = [int(v) for v in g[name + "_hw"]]
+    pm = np.zeros(h * w, np.float32)
+    pm[g[name + "_idx"]] = g[name + "_val"]
+    return pm.reshape(h, w), g[name + "_out"]
+
+
+@pytest.mark.parametrize("name", F3_CASES)
+def test_f3_get_points(golden_dir, name):
+    g = load(golden_dir, "f3_get_points.npz")
+    pm, ref = f3_case(g, name)
+    xs, ys, conf, _ = oracle.get_points(pm)
+    assert ref.shape[0] == 3
+    assert len(xs) == ref.shape[1]
+    # integer work: exact
+    np.testing.assert_array_equal(xs, ref[0].astype(np.int32))
+    np.testing.assert_array_equal(ys, ref[1].astype(np.int32))
+    np.testing.assert_array_equal(conf, ref[2].astype(np.float32))
+
+
+def test_f4_get_descriptors(golden_dir):
+    g = load(golden_dir, "f4_get_descriptors.npz")
+    h, w = [int(v) for v in g["hw"]]
+    pts = g["points"]
+    out = oracle.get_descriptors(g["desc_map"][0], pts[0].astype(np.int32), pts[1].astype(np.int32), h, w)
+    np.testing.assert_allclose(out.T, g["out"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, rtol=1e-6)
+    assert oracle.get_descriptors(g["desc_map"][0], [], [], h, w).shape == (0, 16)
+
+
+@pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
+def test_f5_end_to_end(golden_dir, tag):
+    g = load(golden_dir, "f5_e2e_%s.npz" % tag)
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_frame(int(g["seed_frame"]), h, w)
+    de = bool(int(g["descriptor_enabled"]))
+    prob, desc, logits = oracle.forward(frame.transpose(2, 0, 1)[None], sd, SPEC, descriptor_enabled=de)
+    np.testing.assert_allclose(logits.ravel()[::7], g["logits_probe"], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(desc.ravel()[::11], g["desc_map_probe"], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(prob.ravel()[::13], g["prob_probe"], rtol=5e-5, atol=1e-7)
+    xs, ys, conf, ncand = oracle.get_points(prob[0])
+    # fixtures were chosen tie-safe (make_golden.py prints the margins): indices must be identical
+    assert float(g["tie_margin"]) > 5e-6 and float(g["thresh_margin"]) > 1e-6
+    assert ncand == int(g["n_candidates"])
+    # The frames have flat regions, so distinct keypoints can carry bit-identical
+    # confidences; the reference leaves the order among exact ties unspecified
+    # (numpy's default argsort, nms.py:17,51), so the keypoint SET must be identical
+    # and the order must agree wherever confidences differ.
+    gx, gy, gc = g["points_x"].astype(np.int64), g["points_y"].astype(np.int64), g["points_conf"]
+    assert len(xs) == len(gx)
+    mine = np.sort(ys.astype(np.int64) * w + xs)
+    theirs = np.sort(gy * w + gx)
+    np.testing.assert_array_equal(mine, theirs)
+    assert np.all(np.diff(conf) <= 0)
+    lut = dict(zip((gy * w + gx).tolist(), gc.tolist()))
+    ref_conf = np.array([lut[int(i)] for i in ys.astype(np.int64) * w + xs], np.float32)
+    np.testing.assert_allclose(conf, ref_conf, rtol=2e-5)
+    np.testing.assert_allclose(conf, gc, rtol=2e-5)      # same rank -> same confidence
+    order = {int(i): k for k, i in enumerate((gy * w + gx).tolist())}
+    perm = np.array([order[int(i)] for i in ys.astype(np.int64) * w + xs])
+    if de:
+        d = oracle.get_descriptors(desc[0], xs, ys, h, w)
+        # row k of the reference's subset is its keypoint subset_idx[k]; find ours by pixel
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        np.testing.assert_allclose(d[inv[g["desc_subset_idx"]]], g["desc_subset"], rtol=0, atol=2e-5)
+    else:
+        assert not desc.any()
