@@ -1,0 +1,947 @@
+// fpc_api.hip -- the C-ABI of include/fpc.h: context, weight packing, launch plan.
+//
+// Data layout in HBM (all fp32): activations NHWC with the channel count padded to a
+// multiple of 8 (65 -> 72); one buffer per tensor of the network sized for max_batch
+// frames; the transposed-conv output and the encoder features share ONE 256-channel
+// buffer (`cat`), so torch.cat (python/src/superpoint.py:59) costs nothing; weights
+// live in one packed blob (BN folded, MFMA fragment order) that stays L2-resident.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/fpc.h"
+#include "conv_mfma.h"
+#include "kernels_misc.h"
+#include "weights.h"
+
+namespace fpc {
+
+static thread_local std::string g_hip_err;
+
+#define HIPCHECK(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+      return FPC_E_HIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+// ------------------------------------------------------------------------------------
+// Kernel instances.  KIND(name, TH,TW, S,EXT, KC, WM,WN, MB,NB)
+// ------------------------------------------------------------------------------------
+#define FPC_KINDS(X)                                                        \
+  X(T816_3x3_K64_N64, 8, 16, 1, 3, 64, 4, 1, 1, 2)                          \
+  X(T816_1x1_K64_N64, 8, 16, 1, 1, 64, 4, 1, 1, 2)                          \
+  X(T620_3x3s2_K32_N128, 6, 20, 2, 3, 32, 2, 2, 2, 2)                       \
+  X(T620_3x3_K64_N128, 6, 20, 1, 3, 64, 2, 2, 2, 2)                         \
+  X(T620_1x1_K64_N128, 6, 20, 1, 1, 64, 2, 2, 2, 2)                         \
+  X(T620_2x2_K64_N128, 6, 20, 1, 2, 64, 2, 2, 2, 2)                         \
+  X(T620_3x3_K64_N96, 6, 20, 1, 3, 64, 4, 1, 1, 3)                          \
+  X(T620_1x1_K64_N96, 6, 20, 1, 1, 64, 4, 1, 1, 3)                          \
+  X(T620_3x3_K72_N96, 6, 20, 1, 3, 72, 4, 1, 1, 3)                          \
+  X(T620_1x1_K72_N96, 6, 20, 1, 1, 72, 4, 1, 1, 3)
+
+enum Kind {
+#define X(name, ...) K_##name,
+  FPC_KINDS(X)
+#undef X
+      K_COUNT
+};
+
+struct KindInfo {
+  const char* name;
+  int TH, TW, S, EXT, KC, WM, WN, MB, NB;
+  int lds_bytes, threads;
+  const void* fn;
+  void (*launch)(const ConvArgs&, dim3, hipStream_t);
+};
+
+#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB)                                                    \
+  static void launch_##name(const ConvArgs& a, dim3 grid, hipStream_t st) {                            \
+    using C = ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>;                                             \
+    hipLaunchKernelGGL((conv_mfma_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB>), grid, dim3(C::NT),      \
+                       C::LDS_BYTES, st, a);                                                           \
+  }
+FPC_KINDS(X)
+#undef X
+
+static const KindInfo g_kinds[K_COUNT] = {
+#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB)                                                    \
+  {#name, TH, TW, S, EXT, KC, WM, WN, MB, NB, ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>::LDS_BYTES,   \
+   WM * WN * 64, (const void*)conv_mfma_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB>, launch_##name},
+    FPC_KINDS(X)
+#undef X
+};
+
+// ------------------------------------------------------------------------------------
+// Launch plan
+// ------------------------------------------------------------------------------------
+enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_SOFTMAX, OP_NMS, OP_DESC };
+
+struct Op {
+  OpType type;
+  std::string name;
+  Kind kind = K_COUNT;
+  ConvArgs args{};
+  int grid_y = 1, grid_z = 1;
+  double flops_per_frame = 0;  // algorithmic: 2 * MACs of the real (unpadded) convolution
+  bool descriptor_branch = false;
+};
+
+struct Timing {
+  hipEvent_t start, stop;
+  int op;
+};
+
+}  // namespace fpc
+
+using namespace fpc;
+
+struct fpc_ctx {
+  fpc_config cfg{};
+  int H = 0, W = 0, B = 0, Hc = 0, Wc = 0;
+  int cap = 0, sort_cap = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool weights_loaded = false;
+
+  // one slab for all activations / results; carved below
+  char* slab = nullptr;
+  size_t slab_bytes = 0;
+  float *stem_out, *x0, *h4, *x1, *x2, *h8, *x3, *cat, *dh, *dproj, *d0, *lg;
+  float *h16, *y16a, *y16b, *lo_h, *lo0, *desc_map, *desc_in_nhwc;
+  float* prob;
+  uint32_t *nmsmap, *cand;
+  int32_t *ncand, *count, *xy, *status;
+  float *conf, *desc_out;
+  unsigned long long* sort_scratch;
+
+  // packed weights
+  float* blob = nullptr;
+  size_t blob_floats = 0;
+  std::vector<float> host_blob;
+
+  std::vector<Op> ops;
+  StemArgs stem{};
+  size_t stem_w_off = 0, stem_b_off = 0;
+  struct ConvW {
+    size_t w_off[4] = {0, 0, 0, 0}, b_off = 0;
+  };
+  std::vector<ConvW> convw;  // parallel to ops (unused entries for non-conv ops)
+
+  bool timing = false;
+  std::vector<Timing> timings;
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+};
+
+namespace fpc {
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  size_t off = 0;
+  template <typename T>
+  size_t take(size_t n) {
+    const size_t o = off;
+    off = align_up(off + n * sizeof(T), 256);
+    return o;
+  }
+};
+
+// ---- architecture walk ---------------------------------------------------------------
+// Builds ctx->ops with geometry and buffer pointers, and assigns blob offsets.  The
+// weight VALUES are filled by pack_all() when a checkpoint arrives.
+
+struct ConvSpec {
+  std::string name;
+  Kind kind;
+  int ksize;             // 3, 1, or 2 (= ConvTranspose phase set)
+  int stride;
+  const float* in0;      // source 0
+  int cs0, cin0, cin0_pad, H0, W0;
+  const float* in1 = nullptr;  // optional second K source (1x1)
+  int cs1 = 0, cin1 = 0, cin1_pad = 0, s1 = 1, H1 = 0, W1 = 0;
+  const float* res = nullptr;
+  int csr = 0;
+  float* out;
+  int cso, cout, nstore, Ho, Wo;
+  int relu;
+  bool desc_branch;
+};
+
+static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
+  const KindInfo& k = g_kinds[s.kind];
+  Op op;
+  op.type = OP_CONV;
+  op.name = s.name;
+  op.kind = s.kind;
+  op.descriptor_branch = s.desc_branch;
+  ConvArgs& a = op.args;
+  const int N = k.WN * k.NB * 32;
+  const int nbt = (s.cout + N - 1) / N * (N / 32);
+  op.grid_y = nbt * 32 / N;
+  a.in0 = s.in0;
+  a.cs0 = s.cs0;
+  a.nchunk0 = s.cin0_pad / k.KC;
+  a.in1 = s.in1;
+  a.cs1 = s.cs1;
+  a.nchunk1 = s.in1 ? s.cin1_pad / k.KC : 0;
+  a.s1 = s.s1;
+  a.H1 = s.H1;
+  a.W1 = s.W1;
+  a.H = s.H0;
+  a.W = s.W0;
+  a.pad = s.ksize == 3 ? 1 : 0;
+  a.res = s.res;
+  a.csr = s.csr;
+  a.out = s.out;
+  a.cso = s.cso;
+  a.nstore = s.nstore;
+  a.relu = s.relu;
+  a.nbt = nbt;
+  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW4 = k.KC / 4 + 1;
+  fpc_ctx::ConvW cw;
+  const int K8 = k.KC / 8;
+  if (s.ksize == 2) {  // ConvTranspose2d(k3, s2, p1, op1): 4 output-parity phases over the INPUT grid
+    op.grid_z = 4;
+    a.Ho = s.H0;
+    a.Wo = s.W0;
+    a.OH = s.Ho;
+    a.OW = s.Wo;
+    a.oys = a.oxs = 2;
+    double macs = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+      ConvSub& sp = a.sub[ph];
+      sp.oy0 = py;
+      sp.ox0 = px;
+      sp.ntaps = 0;
+      for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+        for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+          const int dy = py ? 1 - iy : 0, dx = px ? 1 - ix : 0;  // py=1: (dy=1,ky=0), (dy=0,ky=2)
+          sp.tapoff4[sp.ntaps++] = (dy * HWp + dx) * ROW4;
+        }
+      cw.w_off[ph] = *blob_off;
+      *blob_off += ((size_t)a.nchunk0 * sp.ntaps * K8 + 2) * nbt * 64 * 4;
+      macs += (double)sp.ntaps;
+    }
+    op.flops_per_frame = 2.0 * macs * s.H0 * s.W0 * s.cin0 * s.cout;
+  } else {
+    a.Ho = a.OH = s.Ho;
+    a.Wo = a.OW = s.Wo;
+    a.oys = a.oxs = 1;
+    ConvSub& sp = a.sub[0];
+    sp.oy0 = sp.ox0 = 0;
+    sp.ntaps = s.ksize * s.ksize;
+    for (int ky = 0; ky < s.ksize; ++ky)
+      for (int kx = 0; kx < s.ksize; ++kx) sp.tapoff4[ky * s.ksize + kx] = (ky * HWp + kx) * ROW4;
+    cw.w_off[0] = *blob_off;
+    *blob_off += ((size_t)(a.nchunk0 * sp.ntaps + a.nchunk1) * K8 + 2) * nbt * 64 * 4;
+    op.flops_per_frame = 2.0 * s.Ho * s.Wo * s.cout * ((double)s.cin0 * sp.ntaps + s.cin1);
+  }
+  cw.b_off = *blob_off;
+  *blob_off += (size_t)nbt * 32;
+  a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
+  a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
+  c->ops.push_back(op);
+  c->convw.push_back(cw);
+}
+
+static int build_plan(fpc_ctx* c) {
+  const int H = c->H, W = c->W, B = c->B;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
+  const bool de = c->cfg.descriptor_enabled != 0;
+  // ---- carve the slab
+  Carver cv;
+  const size_t o_stem = cv.take<float>((size_t)B * H2 * W2 * 64);
+  const size_t o_x0 = cv.take<float>((size_t)B * H4 * W4 * 64), o_h4 = cv.take<float>((size_t)B * H4 * W4 * 64);
+  const size_t o_x1 = cv.take<float>((size_t)B * H4 * W4 * 64), o_x2 = cv.take<float>((size_t)B * H4 * W4 * 64);
+  const size_t npix8 = (size_t)B * Hc * Wc, npix16 = (size_t)B * H16 * W16;
+  const size_t o_h8 = cv.take<float>(npix8 * 128), o_x3 = cv.take<float>(npix8 * 128);
+  const size_t o_cat = cv.take<float>(npix8 * 256);
+  const size_t o_dh = cv.take<float>(npix8 * 72), o_dproj = cv.take<float>(npix8 * 72);
+  const size_t o_d0 = cv.take<float>(npix8 * 72), o_lg = cv.take<float>(npix8 * 72);
+  const size_t o_h16 = cv.take<float>(npix16 * 256), o_y16a = cv.take<float>(npix16 * 256);
+  const size_t o_y16b = cv.take<float>(npix16 * 256);
+  const size_t o_loh = cv.take<float>(npix8 * 128), o_lo0 = cv.take<float>(npix8 * 128);
+  const size_t o_desc = cv.take<float>(npix8 * 128), o_descin = cv.take<float>(npix8 * 128);
+  const size_t o_prob = cv.take<float>((size_t)B * H * W);
+  const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
+  const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4);
+  const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
+  const size_t o_dout = cv.take<float>(de ? (size_t)B * c->cap * 128 : 64);
+  const size_t o_sort = cv.take<unsigned long long>(c->sort_cap > NMS_LDS_KEYS ? (size_t)B * c->sort_cap : 64);
+  c->slab_bytes = cv.off;
+  if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
+    g_hip_err = "hipMalloc(workspace " + std::to_string(c->slab_bytes >> 20) + " MiB) failed";
+    return FPC_E_HIP;
+  }
+  HIPCHECK(hipMemset(c->slab, 0, c->slab_bytes));
+  auto F = [&](size_t o) { return reinterpret_cast<float*>(c->slab + o); };
+  c->stem_out = F(o_stem); c->x0 = F(o_x0); c->h4 = F(o_h4); c->x1 = F(o_x1); c->x2 = F(o_x2);
+  c->h8 = F(o_h8); c->x3 = F(o_x3); c->cat = F(o_cat); c->dh = F(o_dh); c->dproj = F(o_dproj);
+  c->d0 = F(o_d0); c->lg = F(o_lg); c->h16 = F(o_h16); c->y16a = F(o_y16a); c->y16b = F(o_y16b);
+  c->lo_h = F(o_loh); c->lo0 = F(o_lo0); c->desc_map = F(o_desc); c->desc_in_nhwc = F(o_descin);
+  c->prob = F(o_prob);
+  c->nmsmap = reinterpret_cast<uint32_t*>(c->slab + o_map);
+  c->cand = reinterpret_cast<uint32_t*>(c->slab + o_cand);
+  c->ncand = reinterpret_cast<int32_t*>(c->slab + o_ncand);
+  c->count = reinterpret_cast<int32_t*>(c->slab + o_count);
+  c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
+  c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
+  c->conf = F(o_conf);
+  c->desc_out = F(o_dout);
+  c->sort_scratch = reinterpret_cast<unsigned long long*>(c->slab + o_sort);
+
+  // ---- ops
+  size_t bo = 0;  // blob offset in floats
+  c->ops.clear();
+  c->convw.clear();
+  {
+    Op op;
+    op.type = OP_STEM;
+    op.name = "encoder.conv1+bn1+relu";
+    op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;
+    c->ops.push_back(op);
+    c->convw.push_back({});
+    c->stem_w_off = bo;
+    bo += (size_t)STEM_KG * 2 * 64 * 4;
+    c->stem_b_off = bo;
+    bo += 64;
+    op = Op();
+    op.type = OP_POOL;
+    op.name = "encoder.max_pool";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+  }
+  auto block = [&](const std::string& p, Kind k3, Kind k1, int stride, const float* x, int csx, int cin, int cinp,
+                   int Hx, int Wx, float* h, int csh, int cout, int coutp, float* y, int csy, bool proj,
+                   bool desc) {
+    const int Ho = Hx / stride, Wo = Wx / stride;
+    ConvSpec s{};
+    s.name = p + ".conv1+bn1+relu";
+    s.kind = k3; s.ksize = 3; s.stride = stride;
+    s.in0 = x; s.cs0 = csx; s.cin0 = cin; s.cin0_pad = cinp; s.H0 = Hx; s.W0 = Wx;
+    s.out = h; s.cso = csh; s.cout = cout; s.nstore = coutp; s.Ho = Ho; s.Wo = Wo; s.relu = 1;
+    s.desc_branch = desc;
+    add_conv(c, s, &bo);
+    ConvSpec t{};
+    t.name = p + (proj ? ".conv2+bn2+proj+relu" : ".conv2+bn2+identity+relu");
+    t.kind = k1; t.ksize = 1; t.stride = 1;
+    t.in0 = h; t.cs0 = csh; t.cin0 = cout; t.cin0_pad = coutp; t.H0 = Ho; t.W0 = Wo;
+    if (proj) {
+      t.in1 = x; t.cs1 = csx; t.cin1 = cin; t.cin1_pad = cinp; t.s1 = stride; t.H1 = Hx; t.W1 = Wx;
+    } else {
+      t.res = x; t.csr = csx;
+    }
+    t.out = y; t.cso = csy; t.cout = cout; t.nstore = coutp; t.Ho = Ho; t.Wo = Wo; t.relu = 1;
+    t.desc_branch = desc;
+    add_conv(c, t, &bo);
+  };
+  float* feat = c->cat + 128;  // encoder output lives in channels 128..255 of `cat`
+  block("encoder.layer1.0", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x0, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
+        c->x1, 64, true, false);
+  block("encoder.layer1.1", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x1, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
+        c->x2, 64, false, false);
+  block("encoder.layer2.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, c->x2, 64, 64, 64, H4, W4, c->h8, 128,
+        128, 128, c->x3, 128, true, false);
+  block("encoder.layer2.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->x3, 128, 128, 128, Hc, Wc, c->h8, 128,
+        128, 128, feat, 256, false, false);
+  {  // detector.layer.0: the projection shortcut has K = 128 while conv2 has K = 72 (65 padded):
+     // run the shortcut as its own 1x1 and add it as the residual of conv2
+    ConvSpec s{};
+    s.name = "detector.layer.0.conv1+bn1+relu";
+    s.kind = K_T620_3x3_K64_N96; s.ksize = 3; s.stride = 1;
+    s.in0 = feat; s.cs0 = 256; s.cin0 = 128; s.cin0_pad = 128; s.H0 = Hc; s.W0 = Wc;
+    s.out = c->dh; s.cso = 72; s.cout = 65; s.nstore = 72; s.Ho = Hc; s.Wo = Wc; s.relu = 1;
+    add_conv(c, s, &bo);
+    ConvSpec p{};
+    p.name = "detector.layer.0.identity_downsample";
+    p.kind = K_T620_1x1_K64_N96; p.ksize = 1; p.stride = 1;
+    p.in0 = feat; p.cs0 = 256; p.cin0 = 128; p.cin0_pad = 128; p.H0 = Hc; p.W0 = Wc;
+    p.out = c->dproj; p.cso = 72; p.cout = 65; p.nstore = 72; p.Ho = Hc; p.Wo = Wc; p.relu = 0;
+    add_conv(c, p, &bo);
+    ConvSpec t{};
+    t.name = "detector.layer.0.conv2+bn2+shortcut+relu";
+    t.kind = K_T620_1x1_K72_N96; t.ksize = 1; t.stride = 1;
+    t.in0 = c->dh; t.cs0 = 72; t.cin0 = 65; t.cin0_pad = 72; t.H0 = Hc; t.W0 = Wc;
+    t.res = c->dproj; t.csr = 72;
+    t.out = c->d0; t.cso = 72; t.cout = 65; t.nstore = 72; t.Ho = Hc; t.Wo = Wc; t.relu = 1;
+    add_conv(c, t, &bo);
+  }
+  block("detector.layer.1", K_T620_3x3_K72_N96, K_T620_1x1_K72_N96, 1, c->d0, 72, 65, 72, Hc, Wc, c->dh, 72, 65, 72,
+        c->lg, 72, false, false);
+  {
+    Op op;
+    op.type = OP_SOFTMAX;
+    op.name = "exp-softmax+depth_to_space+threshold";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+  }
+  if (de) {
+    block("descriptor.layer_in.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, feat, 256, 128, 128, Hc, Wc, c->h16,
+          256, 256, 256, c->y16a, 256, true, true);
+    block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
+          c->h16, 256, 256, 256, c->y16b, 256, false, true);
+    ConvSpec u{};
+    u.name = "descriptor.up_sample+bn+relu";
+    u.kind = K_T620_2x2_K64_N128; u.ksize = 2; u.stride = 1;
+    u.in0 = c->y16b; u.cs0 = 256; u.cin0 = 256; u.cin0_pad = 256; u.H0 = H16; u.W0 = W16;
+    u.out = c->cat; u.cso = 256; u.cout = 128; u.nstore = 128; u.Ho = Hc; u.Wo = Wc; u.relu = 1;
+    u.desc_branch = true;
+    add_conv(c, u, &bo);
+    block("descriptor.layer_out.0", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->cat, 256, 256, 256, Hc, Wc,
+          c->lo_h, 128, 128, 128, c->lo0, 128, true, true);
+    block("descriptor.layer_out.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->lo0, 128, 128, 128, Hc, Wc,
+          c->lo_h, 128, 128, 128, c->desc_map, 128, false, true);
+  }
+  {
+    Op op;
+    op.type = OP_NMS;
+    op.name = "nms+sort+border_crop";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+    if (de) {
+      op.type = OP_DESC;
+      op.name = "descriptor_sample+l2norm";
+      c->ops.push_back(op);
+      c->convw.push_back({});
+    }
+  }
+  c->blob_floats = bo;
+  HIPCHECK(hipMalloc((void**)&c->blob, c->blob_floats * sizeof(float)));
+  HIPCHECK(hipMemset(c->blob, 0, c->blob_floats * sizeof(float)));
+  // resolve weight pointers
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    Op& op = c->ops[i];
+    if (op.type != OP_CONV) continue;
+    for (int z = 0; z < op.grid_z; ++z)
+      op.args.sub[z].wfrag = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[z]);
+    op.args.bias = c->blob + c->convw[i].b_off;
+  }
+  c->stem.wfrag = reinterpret_cast<const float4*>(c->blob + c->stem_w_off);
+  c->stem.bias = c->blob + c->stem_b_off;
+  c->stem.out = c->stem_out;
+  c->stem.H = H; c->stem.W = W; c->stem.Ho = H2; c->stem.Wo = W2;
+  c->stem.tiles_x = (W2 + STEM_T - 1) / STEM_T;
+  c->stem.tiles_y = (H2 + STEM_T - 1) / STEM_T;
+  return FPC_OK;
+}
+
+// ---- checkpoint -> blob -----------------------------------------------------------------
+static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
+  std::vector<float>& blob = c->host_blob;
+  blob.assign(c->blob_floats, 0.f);
+  auto need = [&](const std::string& k, std::initializer_list<int64_t> shp) -> const float* {
+    if (!has_shape(m, k, shp)) {
+      if (missing->empty()) *missing = k;
+      return nullptr;
+    }
+    return m.at(k).data;
+  };
+  // stem
+  {
+    const float* w = need("encoder.conv1.weight", {64, 3, 7, 7});
+    Fold f;
+    if (!w || !fold_bn(m, "encoder.bn1", 64, &f, missing)) return FPC_E_MISSING_KEY;
+    float* dst = blob.data() + c->stem_w_off;
+    for (int g = 0; g < STEM_KG; ++g)
+      for (int nb = 0; nb < 2; ++nb)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int k = g * 8 + 2 * j + (lane >> 5), n = nb * 32 + (lane & 31);
+            dst[(((size_t)g * 2 + nb) * 64 + lane) * 4 + j] = k < 147 ? (float)((double)w[n * 147 + k] * f.s[n]) : 0.f;
+          }
+    for (int n = 0; n < 64; ++n) blob[c->stem_b_off + n] = (float)f.t[n];
+  }
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    const Op& op = c->ops[i];
+    if (op.type != OP_CONV) continue;
+    const KindInfo& k = g_kinds[op.kind];
+    const ConvArgs& a = op.args;
+    const fpc_ctx::ConvW& cw = c->convw[i];
+    // recover the checkpoint prefix and role from the op name
+    const std::string& nm = op.name;
+    const size_t dot = nm.find(".conv1+");
+    const size_t dot2 = nm.find(".conv2+");
+    const int cin0p = a.nchunk0 * k.KC, cin1p = a.nchunk1 * k.KC;
+    Fold f, fp;
+    std::vector<double> bias(a.nbt * 32, 0.0);
+    if (nm == "descriptor.up_sample+bn+relu") {
+      const float* w = need("descriptor.up_sample.weight", {256, 128, 3, 3});
+      const float* bct = need("descriptor.up_sample.bias", {128});
+      if (!w || !bct || !fold_bn(m, "descriptor.bn", 128, &f, missing)) return FPC_E_MISSING_KEY;
+      for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        std::vector<std::pair<int, int>> taps;  // (ky, kx) in the order add_conv laid the taps out
+        for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+          for (int ix = 0; ix < (px ? 2 : 1); ++ix) taps.push_back({py ? (iy == 0 ? 0 : 2) : 1, px ? (ix == 0 ? 0 : 2) : 1});
+        PackSource s{256, cin0p, (int)taps.size(),
+                     [&](int n, int ci, int t) { return (double)w[((ci * 128 + n) * 3 + taps[t].first) * 3 + taps[t].second]; },
+                     &f.s};
+        std::vector<float> frag = pack_conv({s}, 128, a.nbt, k.KC);
+        memcpy(blob.data() + cw.w_off[ph], frag.data(), frag.size() * sizeof(float));
+      }
+      for (int n = 0; n < 128; ++n) bias[n] = (double)bct[n] * f.s[n] + f.t[n];
+    } else if (nm == "detector.layer.0.identity_downsample") {
+      const float* w = need("detector.layer.0.identity_downsample.0.weight", {65, 128, 1, 1});
+      if (!w || !fold_bn(m, "detector.layer.0.identity_downsample.1", 65, &f, missing)) return FPC_E_MISSING_KEY;
+      PackSource s{128, cin0p, 1, [&](int n, int ci, int) { return (double)w[n * 128 + ci]; }, &f.s};
+      std::vector<float> frag = pack_conv({s}, 65, a.nbt, k.KC);
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < 65; ++n) bias[n] = f.t[n];
+    } else if (dot != std::string::npos) {  // 3x3 conv1 + bn1
+      const std::string p = nm.substr(0, dot);
+      auto it = m.find(p + ".conv1.weight");
+      if (it == m.end() || it->second.shape.size() != 4 || it->second.shape[2] != 3) {
+        if (missing->empty()) *missing = p + ".conv1.weight";
+        return FPC_E_MISSING_KEY;
+      }
+      const int co = (int)it->second.shape[0], ci = (int)it->second.shape[1];
+      const float* w = it->second.data;
+      if (ci > cin0p || co > a.nbt * 32 || !w) {
+        *missing = p + ".conv1.weight";
+        return FPC_E_MISSING_KEY;
+      }
+      if (!fold_bn(m, p + ".bn1", co, &f, missing)) return FPC_E_MISSING_KEY;
+      PackSource s{ci, cin0p, 9, [&](int n, int c_, int t) { return (double)w[((size_t)(n * ci + c_)) * 9 + t]; }, &f.s};
+      std::vector<float> frag = pack_conv({s}, co, a.nbt, k.KC);
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) bias[n] = f.t[n];
+    } else if (dot2 != std::string::npos) {  // 1x1 conv2 + bn2 (+ projection shortcut as a second K source)
+      const std::string p = nm.substr(0, dot2);
+      auto it = m.find(p + ".conv2.weight");
+      if (it == m.end() || it->second.shape.size() != 4 || !it->second.data) {
+        if (missing->empty()) *missing = p + ".conv2.weight";
+        return FPC_E_MISSING_KEY;
+      }
+      const int co = (int)it->second.shape[0];
+      const float* w = it->second.data;
+      if ((int)it->second.shape[1] != co || co > cin0p || co > a.nbt * 32) {
+        *missing = p + ".conv2.weight";
+        return FPC_E_MISSING_KEY;
+      }
+      if (!fold_bn(m, p + ".bn2", co, &f, missing)) return FPC_E_MISSING_KEY;
+      std::vector<PackSource> srcs;
+      srcs.push_back({co, cin0p, 1, [&, co](int n, int c_, int) { return (double)w[(size_t)n * co + c_]; }, &f.s});
+      for (int n = 0; n < co; ++n) bias[n] = f.t[n];
+      const float* wp = nullptr;
+      int cip = 0;
+      if (a.in1) {
+        auto ip = m.find(p + ".identity_downsample.0.weight");
+        if (ip == m.end() || ip->second.shape.size() != 4 || (int)ip->second.shape[0] != co || !ip->second.data ||
+            (int)ip->second.shape[1] > cin1p) {
+          if (missing->empty()) *missing = p + ".identity_downsample.0.weight";
+          return FPC_E_MISSING_KEY;
+        }
+        wp = ip->second.data;
+        cip = (int)ip->second.shape[1];
+        if (!fold_bn(m, p + ".identity_downsample.1", co, &fp, missing)) return FPC_E_MISSING_KEY;
+        srcs.push_back({cip, cin1p, 1, [&, cip](int n, int c_, int) { return (double)wp[(size_t)n * cip + c_]; }, &fp.s});
+        for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
+      }
+      std::vector<float> frag = pack_conv(srcs, co, a.nbt, k.KC);
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+    } else {
+      *missing = "internal: unknown op " + nm;
+      return FPC_E_INVALID;
+    }
+    for (int n = 0; n < a.nbt * 32; ++n) blob[cw.b_off + n] = (float)bias[n];
+  }
+  return FPC_OK;
+}
+
+// ---- execution -------------------------------------------------------------------------------
+static hipEvent_t next_event(fpc_ctx* c) {
+  if (c->events_used == c->event_pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    c->event_pool.push_back(e);
+  }
+  return c->event_pool[c->events_used++];
+}
+
+struct LaunchTimer {
+  fpc_ctx* c;
+  int op;
+  hipEvent_t s{}, e{};
+  LaunchTimer(fpc_ctx* c_, int op_) : c(c_), op(op_) {
+    if (c->timing) {
+      s = next_event(c);
+      e = next_event(c);
+      hipEventRecord(s, c->stream);
+    }
+  }
+  ~LaunchTimer() {
+    if (c->timing) {
+      hipEventRecord(e, c->stream);
+      c->timings.push_back({s, e, op});
+    }
+  }
+};
+
+static int run_network(fpc_ctx* c, const float* frames, int n, bool want_desc) {
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
+  c->timings.clear();
+  c->events_used = 0;
+  const int H = c->H, W = c->W;
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    const Op& op = c->ops[i];
+    if (op.descriptor_branch && !want_desc) continue;
+    switch (op.type) {
+      case OP_STEM: {
+        LaunchTimer t(c, (int)i);
+        StemArgs a = c->stem;
+        a.in = frames;
+        hipLaunchKernelGGL(stem_kernel, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, c->stream, a);
+        break;
+      }
+      case OP_POOL: {
+        LaunchTimer t(c, (int)i);
+        const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
+        hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float4*>(c->stem_out), reinterpret_cast<float4*>(c->x0), n, H / 2,
+                           W / 2, H / 4, W / 4);
+        break;
+      }
+      case OP_CONV: {
+        LaunchTimer t(c, (int)i);
+        const ConvArgs& a = op.args;
+        g_kinds[op.kind].launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), c->stream);
+        break;
+      }
+      default:
+        break;  // post-processing ops are issued by the callers
+    }
+  }
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+static int op_index(const fpc_ctx* c, OpType t) {
+  for (size_t i = 0; i < c->ops.size(); ++i)
+    if (c->ops[i].type == t) return (int)i;
+  return -1;
+}
+
+static int run_softmax(fpc_ctx* c, int n) {
+  HIPCHECK(hipMemsetAsync(c->ncand, 0, sizeof(int32_t) * c->B, c->stream));
+  LaunchTimer t(c, op_index(c, OP_SOFTMAX));
+  const int cells = n * c->Hc * c->Wc;
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3((cells + 3) / 4), dim3(256), 0, c->stream, c->lg, 72, n, c->Hc, c->Wc,
+                     c->cfg.conf_thresh, c->prob, c->nmsmap, c->cand, c->ncand);
+  return FPC_OK;
+}
+
+static int run_nms(fpc_ctx* c, int n) {
+  LaunchTimer t(c, op_index(c, OP_NMS));
+  NmsArgs a{};
+  a.nmsmap = c->nmsmap; a.cand = c->cand; a.ncand = c->ncand;
+  a.sort_scratch = c->sort_scratch; a.sort_cap = c->sort_cap;
+  a.H = c->H; a.W = c->W; a.r = c->cfg.nms_dist; a.border = c->cfg.border_remove; a.cap = c->cap;
+  a.count = c->count; a.xy = c->xy; a.conf = c->conf; a.status = c->status;
+  a.max_rounds = c->H * c->W;
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), NMS_LDS_KEYS * sizeof(unsigned long long), c->stream, a);
+  return FPC_OK;
+}
+
+static int run_desc(fpc_ctx* c, int n, const float* dmap_nhwc) {
+  LaunchTimer t(c, op_index(c, OP_DESC));
+  hipLaunchKernelGGL(descriptor_kernel, dim3((c->cap + 3) / 4, n), dim3(256), 0, c->stream, dmap_nhwc, 128, c->Hc,
+                     c->Wc, c->H, c->W, c->count, c->xy, c->cap, c->desc_out);
+  return FPC_OK;
+}
+
+}  // namespace fpc
+
+// ====================================================================================
+// C-ABI
+// ====================================================================================
+extern "C" {
+
+int fpc_abi_version(void) { return FPC_ABI_VERSION; }
+
+const char* fpc_strerror(int code) {
+  switch (code) {
+    case FPC_OK: return "ok";
+    case FPC_E_INVALID: return "invalid argument or unsupported geometry";
+    case FPC_E_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case FPC_E_HIP: return "HIP runtime error (see fpc_last_hip_error)";
+    case FPC_E_NO_WEIGHTS: return "weights not loaded";
+    case FPC_E_MISSING_KEY: return "checkpoint entry missing or of the wrong shape (see fpc_last_hip_error)";
+    case FPC_E_CAPACITY: return "caller buffer too small";
+    case FPC_E_NOT_CONVERGED: return "NMS round limit hit";
+    default: return "unknown error";
+  }
+}
+
+const char* fpc_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int fpc_default_config(fpc_config* cfg) {
+  if (!cfg) return FPC_E_INVALID;
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->device = 0;
+  cfg->height = 480;
+  cfg->width = 640;
+  cfg->max_batch = 1;
+  cfg->cell = 8;
+  cfg->nms_dist = 4;
+  cfg->conf_thresh = 0.015f;
+  cfg->border_remove = 4;
+  cfg->descriptor_enabled = 1;
+  cfg->max_keypoints = 0;
+  return FPC_OK;
+}
+
+int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
+  if (!out || !cfg) return FPC_E_INVALID;
+  *out = nullptr;
+  if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % 16 || cfg->width % 16 ||
+      cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
+      (long long)cfg->height * cfg->width >= (1ll << 30))
+    return FPC_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    g_hip_err = "hipGetDeviceCount: no device";
+    return FPC_E_NO_DEVICE;
+  }
+  HIPCHECK(hipSetDevice(cfg->device));
+  std::unique_ptr<fpc_ctx> c(new fpc_ctx());
+  c->cfg = *cfg;
+  c->H = cfg->height;
+  c->W = cfg->width;
+  c->B = cfg->max_batch;
+  c->Hc = c->H / 8;
+  c->Wc = c->W / 8;
+  // kept points are pairwise > nms_dist apart (infinity norm): at most one per (r+1)^2 cell
+  const int r1 = cfg->nms_dist + 1;
+  const int worst = ((c->H + r1 - 1) / r1) * ((c->W + r1 - 1) / r1);
+  c->cap = cfg->max_keypoints > 0 ? cfg->max_keypoints : worst;
+  c->sort_cap = 1;
+  while (c->sort_cap < worst) c->sort_cap <<= 1;
+  HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  for (int k = 0; k < K_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
+  HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
+  int rc = build_plan(c.get());
+  if (rc != FPC_OK) {
+    if (c->slab) hipFree(c->slab);
+    if (c->blob) hipFree(c->blob);
+    hipStreamDestroy(c->stream);
+    return rc;
+  }
+  *out = c.release();
+  return FPC_OK;
+}
+
+void fpc_destroy(fpc_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->cfg.device);
+  hipDeviceSynchronize();
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  if (c->slab) hipFree(c->slab);
+  if (c->blob) hipFree(c->blob);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int fpc_load_weights(fpc_ctx* c, const fpc_tensor* tensors, int n) {
+  if (!c || !tensors || n <= 0) return FPC_E_INVALID;
+  TensorMap m;
+  for (int i = 0; i < n; ++i) {
+    if (!tensors[i].name || tensors[i].ndim < 0 || tensors[i].ndim > 4) return FPC_E_INVALID;
+    HostTensor t;
+    t.data = tensors[i].data;
+    t.shape.assign(tensors[i].shape, tensors[i].shape + tensors[i].ndim);
+    m[tensors[i].name] = t;
+  }
+  std::string missing;
+  const int rc = pack_all(c, m, &missing);
+  if (rc != FPC_OK) {
+    g_hip_err = "checkpoint entry: " + missing;
+    return rc;
+  }
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipMemcpy(c->blob, c->host_blob.data(), c->blob_floats * sizeof(float), hipMemcpyHostToDevice));
+  c->weights_loaded = true;
+  return FPC_OK;
+}
+
+size_t fpc_packed_size(const fpc_ctx* c) { return c ? c->blob_floats * sizeof(float) : 0; }
+void* fpc_packed_device_ptr(fpc_ctx* c) { return c ? c->blob : nullptr; }
+
+int fpc_export_packed(fpc_ctx* c, void* dst, size_t cap) {
+  if (!c || !dst) return FPC_E_INVALID;
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  if (cap < c->blob_floats * sizeof(float)) return FPC_E_CAPACITY;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipMemcpy(dst, c->blob, c->blob_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return FPC_OK;
+}
+
+int fpc_import_packed(fpc_ctx* c, const void* src, size_t n) {
+  if (!c || !src || n != c->blob_floats * sizeof(float)) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipMemcpy(c->blob, src, n, hipMemcpyHostToDevice));
+  c->weights_loaded = true;
+  return FPC_OK;
+}
+
+int fpc_mark_weights_loaded(fpc_ctx* c) {
+  if (!c) return FPC_E_INVALID;
+  c->weights_loaded = true;
+  return FPC_OK;
+}
+
+int fpc_set_stream(fpc_ctx* c, void* s) {
+  if (!c) return FPC_E_INVALID;
+  if (c->own_stream && c->stream) {
+    hipStreamSynchronize(c->stream);
+    hipStreamDestroy(c->stream);
+  }
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return FPC_OK;
+}
+
+void* fpc_get_stream(fpc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int fpc_sync(fpc_ctx* c) {
+  if (!c) return FPC_E_INVALID;
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return FPC_OK;
+}
+
+int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc, float* logits) {
+  if (!c) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  const bool de = c->cfg.descriptor_enabled != 0;
+  int rc = run_network(c, frames, n, de);
+  if (rc != FPC_OK) return rc;
+  rc = run_softmax(c, n);
+  if (rc != FPC_OK) return rc;
+  const int HWc = c->Hc * c->Wc;
+  if (prob) HIPCHECK(hipMemcpyAsync(prob, c->prob, (size_t)n * c->H * c->W * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  if (logits) {
+    const size_t tot = (size_t)n * 65 * HWc;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->lg, 72, 65,
+                       HWc, n, logits);
+  }
+  if (desc) {
+    const size_t tot = (size_t)n * 128 * HWc;
+    if (de)
+      hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                         c->desc_map, 128, 128, HWc, n, desc);
+    else  // superpoint.py:106-109: zeros when the descriptor head is disabled
+      HIPCHECK(hipMemsetAsync(desc, 0, tot * sizeof(float), c->stream));
+  }
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+int fpc_detect(fpc_ctx* c, const float* frames, int n) {
+  if (!c) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  const bool de = c->cfg.descriptor_enabled != 0;
+  int rc = run_network(c, frames, n, de);
+  if (rc != FPC_OK) return rc;
+  if ((rc = run_softmax(c, n)) != FPC_OK) return rc;
+  if ((rc = run_nms(c, n)) != FPC_OK) return rc;
+  if (de && (rc = run_desc(c, n, c->desc_map)) != FPC_OK) return rc;
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n) {
+  if (!c || !prob || n < 1 || n > c->B) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  c->timings.clear();
+  c->events_used = 0;
+  const int HW = c->H * c->W;
+  HIPCHECK(hipMemsetAsync(c->ncand, 0, sizeof(int32_t) * c->B, c->stream));
+  const int per = (HW + 255) / 256;
+  hipLaunchKernelGGL(threshold_kernel, dim3(per * n), dim3(256), 0, c->stream, prob, n, HW, c->cfg.conf_thresh,
+                     c->nmsmap, c->cand, c->ncand);
+  int rc = run_nms(c, n);
+  if (rc != FPC_OK) return rc;
+  if (desc_nchw && c->cfg.descriptor_enabled) {
+    const size_t tot = (size_t)n * 128 * c->Hc * c->Wc;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, desc_nchw,
+                       128, c->Hc * c->Wc, n, c->desc_in_nhwc);
+    if ((rc = run_desc(c, n, c->desc_in_nhwc)) != FPC_OK) return rc;
+  }
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+int fpc_results(fpc_ctx* c, fpc_device_results* out) {
+  if (!c || !out) return FPC_E_INVALID;
+  out->count = c->count;
+  out->n_candidates = c->ncand;
+  out->xy = c->xy;
+  out->conf = c->conf;
+  out->desc = c->cfg.descriptor_enabled ? c->desc_out : nullptr;
+  out->capacity = c->cap;
+  out->desc_dim = 128;
+  return FPC_OK;
+}
+
+int fpc_get_counts(fpc_ctx* c, int n, int32_t* count, int32_t* ncand) {
+  if (!c || n < 1 || n > c->B) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  int32_t st = 0;
+  HIPCHECK(hipMemcpy(&st, c->status, sizeof(st), hipMemcpyDeviceToHost));
+  if (st) return FPC_E_NOT_CONVERGED;
+  if (count) HIPCHECK(hipMemcpy(count, c->count, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (ncand) HIPCHECK(hipMemcpy(ncand, c->ncand, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return FPC_OK;
+}
+
+int fpc_get_keypoints(fpc_ctx* c, int frame, int cap, int32_t* xy, float* conf, float* desc) {
+  if (!c || frame < 0 || frame >= c->B || cap < 0) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  int32_t k = 0;
+  HIPCHECK(hipMemcpy(&k, c->count + frame, sizeof(k), hipMemcpyDeviceToHost));
+  if (k > cap || k > c->cap) return FPC_E_CAPACITY;
+  if (k == 0) return 0;
+  if (xy) HIPCHECK(hipMemcpy(xy, c->xy + (size_t)frame * c->cap * 2, sizeof(int32_t) * 2 * k, hipMemcpyDeviceToHost));
+  if (conf) HIPCHECK(hipMemcpy(conf, c->conf + (size_t)frame * c->cap, sizeof(float) * k, hipMemcpyDeviceToHost));
+  if (desc) {
+    if (!c->cfg.descriptor_enabled) return FPC_E_INVALID;
+    HIPCHECK(hipMemcpy(desc, c->desc_out + (size_t)frame * c->cap * 128, sizeof(float) * 128 * k, hipMemcpyDeviceToHost));
+  }
+  return k;
+}
+
+int fpc_set_timing(fpc_ctx* c, int enable) {
+  if (!c) return FPC_E_INVALID;
+  c->timing = enable != 0;
+  return FPC_OK;
+}
+
+int fpc_get_timings(fpc_ctx* c, int cap, const char** names, float* ms, double* flops) {
+  if (!c) return FPC_E_INVALID;
+  const int n = (int)c->timings.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    const Timing& t = c->timings[i];
+    float v = 0.f;
+    if (hipEventElapsedTime(&v, t.start, t.stop) != hipSuccess) v = -1.f;
+    if (names) names[i] = t.op >= 0 ? c->ops[t.op].name.c_str() : "?";
+    if (ms) ms[i] = v;
+    if (flops) flops[i] = t.op >= 0 ? c->ops[t.op].flops_per_frame : 0.0;
+  }
+  return n;
+}
+
+}  // extern "C"

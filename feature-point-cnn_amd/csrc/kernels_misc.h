@@ -1,0 +1,428 @@
+// kernels_misc.h -- everything on the path that is not the halo-tile convolution:
+// the 7x7/2 stem (MFMA, K = 147), max-pool, exp-softmax + depth-to-space +
+// threshold, greedy NMS + sort + border crop, descriptor sampling, layout helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_mfma.h"
+
+namespace fpc {
+
+// ---------------------------------------------------------------------------------
+// Stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) + BN + ReLU
+// (python/src/superpoint.py:12-14,20-22).  Input NCHW planar (the layout the
+// reference's forward takes), output NHWC.  Implicit GEMM with K = 3*7*7 = 147
+// (padded to 152 = 19 groups of 8): one workgroup = 16x16 output pixels x 64
+// channels; the 37x37x3 input window sits in LDS and every A operand is one
+// ds_read_b32 at a compile-time offset.
+// ---------------------------------------------------------------------------------
+struct StemArgs {
+  const float* in;      // [B,3,H,W]
+  const float4* wfrag;  // [19][2][64] float4
+  const float* bias;    // [64]
+  float* out;           // [B,H/2,W/2,64]
+  int H, W, Ho, Wo, tiles_x, tiles_y;
+};
+
+constexpr int STEM_T = 16;                       // tile edge (output pixels)
+constexpr int STEM_HALO = (STEM_T - 1) * 2 + 7;  // 37
+constexpr int STEM_LW = 40;                      // LDS row stride (floats)
+constexpr int STEM_KG = 19;                      // groups of 8 k-values
+constexpr int STEM_LDS_FLOATS = 3 * STEM_HALO * STEM_LW;
+
+__device__ __forceinline__ constexpr int stem_koff(int k) {
+  k = k < 147 ? k : 146;  // padded k: weight is zero, any valid address will do
+  return (k / 49) * (STEM_HALO * STEM_LW) + ((k % 49) / 7) * STEM_LW + (k % 7);
+}
+
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+  __shared__ float lds[STEM_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x / tiles;
+  const int t = blockIdx.x - b * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
+
+  for (int e = tid; e < 3 * STEM_HALO * STEM_HALO; e += 256) {
+    const int c = e / (STEM_HALO * STEM_HALO);
+    const int r = e - c * (STEM_HALO * STEM_HALO);
+    const int hy = r / STEM_HALO, hx = r - hy * STEM_HALO;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    float v = 0.f;
+    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = a.in[((size_t)(b * 3 + c) * a.H + iy) * a.W + ix];
+    lds[(c * STEM_HALO + hy) * STEM_LW + hx] = v;
+  }
+  __syncthreads();
+
+  int abase[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = (wave * 2 + mb) * 32 + l31;
+    abase[mb] = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float4* wp = a.wfrag + lane;
+#pragma unroll
+  for (int g = 0; g < STEM_KG; ++g) {
+    const float4 bq0 = wp[(g * 2 + 0) * 64], bq1 = wp[(g * 2 + 1) * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = g * 8 + 2 * j;  // lanes 0-31 take k0, lanes 32-63 take k0+1
+      const int off = half ? stem_koff(k0 + 1) : stem_koff(k0);
+      const float bf0 = j == 0 ? bq0.x : j == 1 ? bq0.y : j == 2 ? bq0.z : bq0.w;
+      const float bf1 = j == 0 ? bq1.x : j == 1 ? bq1.y : j == 2 ? bq1.z : bq1.w;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float af = lds[abase[mb] + off];
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf0, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf1, acc[mb][1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = nb * 32 + l31;
+    const float bias = a.bias[n];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wave * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int y = ty * STEM_T + m / STEM_T, x = tx * STEM_T + m % STEM_T;
+        if (y < a.Ho && x < a.Wo) {
+          const float v = acc[mb][nb][r] + bias;
+          a.out[((size_t)(b * a.Ho + y) * a.Wo + x) * 64 + n] = v > 0.f ? v : 0.f;
+        }
+      }
+  }
+}
+
+// MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC, C = 64 (superpoint.py:15,23).
+__global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* out, int B, int H, int W,
+                                                      int Ho, int Wo) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // over B*Ho*Wo*16 float4
+  const size_t total = (size_t)B * Ho * Wo * 16;
+  if (i >= total) return;
+  const int c4 = i & 15;
+  size_t p = i >> 4;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int b = p / Ho;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * y + ky - 1;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * x + kx - 1;
+      if (ix < 0 || ix >= W) continue;
+      const float4 v = in[((size_t)(b * H + iy) * W + ix) * 16 + c4];
+      m.x = fmaxf(m.x, v.x);
+      m.y = fmaxf(m.y, v.y);
+      m.z = fmaxf(m.z, v.z);
+      m.w = fmaxf(m.w, v.w);
+    }
+  }
+  out[i] = m;
+}
+
+// ---------------------------------------------------------------------------------
+// Detector post-processing, part 1 (python/src/superpoint.py:111-114,
+// python/src/netutils.py:56-75): p = exp(l) / (sum_c exp(l) + 1e-5), drop the
+// dustbin, depth-to-space, threshold.  One wave per 8x8 cell: lane c owns
+// sub-pixel (c/8, c%8).  Writes the dense probability map, the NMS state map
+// (float bits of p where p >= thresh, else 0) and appends candidates to the
+// frame's list (order irrelevant: NMS below is order-free, the sort is total).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
+                                                          float thresh, float* prob, uint32_t* nmsmap,
+                                                          uint32_t* cand, int32_t* ncand) {
+  const int lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= B * Hc * Wc) return;
+  const int b = cell / (Hc * Wc);
+  const int r = cell - b * (Hc * Wc);
+  const int i = r / Wc, j = r - i * Wc;
+  const float* l = logits + (size_t)cell * cs;
+  const float e = expf(l[lane]);
+  const float ed = expf(l[64]);
+  float s = e;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float p = e / ((s + ed) + .00001f);
+  const int W = Wc * 8, H = Hc * 8;
+  const int y = i * 8 + (lane >> 3), x = j * 8 + (lane & 7);
+  const uint32_t idx = y * W + x;
+  prob[(size_t)b * H * W + idx] = p;
+  const bool c = p >= thresh;
+  nmsmap[(size_t)b * H * W + idx] = c ? __float_as_uint(p) : 0u;
+  const unsigned long long mask = __ballot(c);
+  if (mask) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&ncand[b], __popcll(mask));
+    base = __shfl(base, 0);
+    if (c) cand[(size_t)b * H * W + base + __popcll(mask & ((1ull << lane) - 1))] = idx;
+  }
+}
+
+// Same outputs from a caller-provided dense probability map (fpc_get_points).
+__global__ __launch_bounds__(256) void threshold_kernel(const float* prob, int B, int HW, float thresh,
+                                                        uint32_t* nmsmap, uint32_t* cand, int32_t* ncand) {
+  const int lane = threadIdx.x & 63;
+  const int per = (HW + 255) / 256 * 256;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = g / per;
+  const int idx = g - (size_t)b * per;
+  if (b >= B) return;
+  const bool in = idx < HW;
+  const float p = in ? prob[(size_t)b * HW + idx] : 0.f;
+  const bool c = in && p >= thresh;
+  if (in) nmsmap[(size_t)b * HW + idx] = c ? __float_as_uint(p) : 0u;
+  const unsigned long long mask = __ballot(c);
+  if (mask) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&ncand[b], __popcll(mask));
+    base = __shfl(base, 0);
+    if (c) cand[(size_t)b * HW + base + __popcll(mask & ((1ull << lane) - 1))] = idx;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Detector post-processing, part 2: greedy NMS + sort + border crop
+// (python/src/nms.py:4-53, python/src/netutils.py:90-99), one 1024-thread
+// workgroup per frame.
+//
+// The reference walks candidates in descending confidence and keeps a point iff
+// no already-kept point lies within infinity-distance nms_dist.  Equivalent
+// order-free rule, iterated to a fixed point: an undecided candidate is KEPT once
+// every higher-priority candidate in its window is suppressed, and SUPPRESSED as
+// soon as any candidate in its window is kept (a kept neighbour always has higher
+// priority, otherwise it could not have been decided before this one).  Decisions
+// are final and only depend on final decisions, so reading neighbours while other
+// threads update them is safe: a stale read only delays a decision by a round.
+// Priority = (confidence, then smaller row-major index) -- the tie order this
+// build defines (the reference's is unspecified: numpy's unstable argsort).
+//
+// State map word: 0 = empty / suppressed, float bits (> 0) = undecided candidate,
+// float bits | 0x80000000 = kept.
+// ---------------------------------------------------------------------------------
+struct NmsArgs {
+  uint32_t* nmsmap;        // [B][H*W]
+  uint32_t* cand;          // [B][H*W]
+  const int32_t* ncand;    // [B]
+  unsigned long long* sort_scratch;  // [B][sort_cap] used when the kept set exceeds LDS
+  int sort_cap;            // power of two
+  int H, W, r, border, cap;
+  int32_t* count;          // [B]
+  int32_t* xy;             // [B][cap][2]
+  float* conf;             // [B][cap]
+  int32_t* status;         // [1] set to 1 if the round limit is hit
+  int max_rounds;
+};
+
+constexpr int NMS_LDS_KEYS = 16384;  // 128 KiB of 64-bit keys
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
+  extern __shared__ unsigned long long keys_lds[];
+  __shared__ int s_count;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int H = a.H, W = a.W, r = a.r;
+  uint32_t* map = a.nmsmap + (size_t)b * H * W;
+  uint32_t* cand = a.cand + (size_t)b * H * W;
+  const int n = a.ncand[b];
+  if (tid == 0) s_count = 0;
+
+  if (n > 1) {  // nms.py:23-25: a single candidate is returned as is
+    for (int round = 0;; ++round) {
+      int pending = 0;
+      for (int i = tid; i < n; i += 1024) {
+        const uint32_t ci = cand[i];
+        if (ci & 0x80000000u) continue;  // decided in an earlier round
+        const int y = ci / W, x = ci - y * W;
+        const uint32_t v = map[ci];      // own word: only this thread ever writes it
+        const int y0 = max(y - r, 0), y1 = min(y + r, H - 1);
+        const int x0 = max(x - r, 0), x1 = min(x + r, W - 1);
+        bool kept_nb = false, wait = false;
+        for (int yy = y0; yy <= y1 && !kept_nb; ++yy) {
+          const uint32_t* row = map + yy * W;
+          for (int xx = x0; xx <= x1; ++xx) {
+            const uint32_t u = ld_relaxed(row + xx);
+            const uint32_t q = yy * W + xx;
+            if (q == ci) continue;
+            if (u & 0x80000000u) kept_nb = true;
+            else if (u > v || (u == v && q < ci)) wait = true;
+          }
+        }
+        if (kept_nb) {
+          st_relaxed(map + ci, 0u);
+          cand[i] = ci | 0x80000000u;
+        } else if (!wait) {
+          st_relaxed(map + ci, v | 0x80000000u);
+          cand[i] = ci | 0x80000000u;
+        } else {
+          ++pending;
+        }
+      }
+      if (!__syncthreads_or(pending)) break;
+      if (round >= a.max_rounds) {
+        if (tid == 0) *a.status = 1;
+        break;
+      }
+    }
+  } else if (n == 1 && tid == 0) {
+    map[cand[0]] |= 0x80000000u;
+  }
+  __syncthreads();
+
+  // Survivors inside the border, as 64-bit keys (conf bits, ~index): a descending
+  // sort of unique keys gives (confidence desc, index asc) -- netutils.py:92-99.
+  const int bw = a.border;
+  unsigned long long* keys = keys_lds;
+  // count first so that the LDS / scratch choice is uniform
+  int mine = 0;
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t ci = cand[i] & 0x7fffffffu;
+    const int y = ci / W, x = ci - y * W;
+    const bool keep = (map[ci] & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
+    mine += keep;
+  }
+  __shared__ int s_total;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  if (mine) atomicAdd(&s_total, mine);
+  __syncthreads();
+  const int K = s_total;
+  int P = 1;
+  while (P < K) P <<= 1;
+  if (P > NMS_LDS_KEYS) keys = a.sort_scratch + (size_t)b * a.sort_cap;
+  for (int i = tid; i < P; i += 1024) keys[i] = 0ull;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t ci = cand[i] & 0x7fffffffu;
+    const int y = ci / W, x = ci - y * W;
+    const uint32_t u = map[ci];
+    if ((u & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw) {
+      const int pos = atomicAdd(&s_count, 1);
+      keys[pos] = ((unsigned long long)(u & 0x7fffffffu) << 32) | (0xffffffffu - ci);
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long ki = keys[i], kl = keys[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? ki < kl : ki > kl) {
+            keys[i] = kl;
+            keys[l] = ki;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) a.count[b] = K;
+  for (int i = tid; i < K && i < a.cap; i += 1024) {
+    const unsigned long long k = keys[i];
+    const uint32_t ci = 0xffffffffu - (uint32_t)(k & 0xffffffffu);
+    const int y = ci / W, x = ci - y * W;
+    a.xy[((size_t)b * a.cap + i) * 2 + 0] = x;
+    a.xy[((size_t)b * a.cap + i) * 2 + 1] = y;
+    a.conf[(size_t)b * a.cap + i] = __uint_as_float((uint32_t)(k >> 32));
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// get_descriptors (python/src/netutils.py:103-121): bilinear grid_sample with
+// align_corners=True and zero padding at gx = x/(W/2) - 1, gy = y/(H/2) - 1, then
+// division by the L2 norm (no epsilon).  One wave per keypoint, lane = 2 channels of
+// the NHWC descriptor map (D = 128): each corner is one 512-byte coalesced read.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
+                                                         const int32_t* count, const int32_t* xy, int cap,
+                                                         float* out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int K = min(count[b], cap);
+  if (k >= K) return;
+  const int px = xy[((size_t)b * cap + k) * 2], py = xy[((size_t)b * cap + k) * 2 + 1];
+  const float gx = (float)((double)px / ((double)W / 2.) - 1.);
+  const float gy = (float)((double)py / ((double)H / 2.) - 1.);
+  const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
+  const float iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
+  const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), x1 = x0 + 1, y1 = y0 + 1;
+  const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
+  const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
+  const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc, vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
+  const float* base = dmap + (size_t)b * Hc * Wc * cs + 2 * lane;
+  float2 v = make_float2(0.f, 0.f);
+  if (vy0 && vx0) {
+    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y0 * Wc + x0) * cs);
+    v.x += t.x * wnw;
+    v.y += t.y * wnw;
+  }
+  if (vy0 && vx1) {
+    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y0 * Wc + x1) * cs);
+    v.x += t.x * wne;
+    v.y += t.y * wne;
+  }
+  if (vy1 && vx0) {
+    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y1 * Wc + x0) * cs);
+    v.x += t.x * wsw;
+    v.y += t.y * wsw;
+  }
+  if (vy1 && vx1) {
+    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y1 * Wc + x1) * cs);
+    v.x += t.x * wse;
+    v.y += t.y * wse;
+  }
+  float ss = v.x * v.x + v.y * v.y;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float nrm = sqrtf(ss);
+  float2 o2 = make_float2(v.x / nrm, v.y / nrm);
+  *reinterpret_cast<float2*>(out + ((size_t)b * cap + k) * 128 + 2 * lane) = o2;
+}
+
+// NHWC (pixel stride cs, first C channels) -> NCHW, for the reference-layout dense outputs.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, int cs, int C, int HW, int B, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * C * HW) return;
+  const int p = i % HW;
+  const int c = (i / HW) % C;
+  const int b = i / ((size_t)HW * C);
+  out[i] = in[((size_t)b * HW + p) * cs + c];
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, int C, int HW, int B, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * C * HW) return;
+  const int c = i % C;
+  const int p = (i / C) % HW;
+  const int b = i / ((size_t)HW * C);
+  out[i] = in[((size_t)b * C + c) * HW + p];
+}
+
+}  // namespace fpc

@@ -1,0 +1,89 @@
+// weights.h -- host side: checkpoint entries -> BatchNorm-folded, MFMA-fragment-packed blob.
+//
+// Input is the reference's ckpt['model_state_dict'] (python/src/saveutils.py:57-62,
+// SURVEY.md table W) as name -> float tensor.  BatchNorm is evaluated in inference
+// form (running statistics, eps 1e-5):  y = conv(x) * s + t  with
+// s = gamma / sqrt(var + eps), t = beta - mean * s  (python/src/resnet_blocks.py:17,20,23).
+// s is folded into the convolution weights in double precision, t becomes the bias.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace fpc {
+
+struct HostTensor {
+  const float* data = nullptr;
+  std::vector<int64_t> shape;
+};
+using TensorMap = std::unordered_map<std::string, HostTensor>;
+
+struct Fold {
+  std::vector<double> s, t;
+};
+
+inline bool has_shape(const TensorMap& m, const std::string& k, std::initializer_list<int64_t> shp) {
+  auto it = m.find(k);
+  if (it == m.end() || it->second.data == nullptr) return false;
+  return it->second.shape == std::vector<int64_t>(shp);
+}
+
+// BatchNorm2d(C) entries under `prefix` -> (s, t); returns false when an entry is missing / misshapen.
+inline bool fold_bn(const TensorMap& m, const std::string& prefix, int C, Fold* f, std::string* missing) {
+  static const char* leaf[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+  const float* p[4];
+  for (int i = 0; i < 4; ++i) {
+    if (!has_shape(m, prefix + leaf[i], {C})) {
+      *missing = prefix + leaf[i];
+      return false;
+    }
+    p[i] = m.at(prefix + leaf[i]).data;
+  }
+  f->s.resize(C);
+  f->t.resize(C);
+  for (int c = 0; c < C; ++c) {
+    const double s = (double)p[0][c] / std::sqrt((double)p[3][c] + 1e-5);
+    f->s[c] = s;
+    f->t[c] = (double)p[1][c] - (double)p[2][c] * s;
+  }
+  return true;
+}
+
+// One K-source of a packed GEMM-B: `cin_pad` channels (a multiple of KC) of which the
+// first `cin` are real, visited for each tap; w(n, c, tap) is the UNSCALED weight.
+struct PackSource {
+  int cin, cin_pad, ntaps;
+  std::function<double(int n, int c, int tap)> w;
+  const std::vector<double>* scale;  // per output channel
+};
+
+// B fragments in the exact order conv_mfma_kernel consumes them:
+//   step = ((chunk * ntaps + tap) * K8 + k8), chunks of source 0 first, then source 1;
+//   frag[(step * nbt + nb) * 64 + lane] = { B[step*8 + 4*half + j][nb*32 + (lane&31)] }, j = 0..3
+// followed by two all-zero steps (the kernel prefetches two steps ahead).
+inline std::vector<float> pack_conv(const std::vector<PackSource>& srcs, int cout, int nbt, int KC) {
+  const int K8 = KC / 8;
+  size_t nsteps = 0;
+  for (auto& s : srcs) nsteps += (size_t)(s.cin_pad / KC) * s.ntaps * K8;
+  std::vector<float> out((nsteps + 2) * nbt * 64 * 4, 0.f);
+  size_t step = 0;
+  for (auto& s : srcs)
+    for (int chunk = 0; chunk < s.cin_pad / KC; ++chunk)
+      for (int tap = 0; tap < s.ntaps; ++tap)
+        for (int k8 = 0; k8 < K8; ++k8, ++step)
+          for (int nb = 0; nb < nbt; ++nb)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int n = nb * 32 + (lane & 31), half = lane >> 5;
+              float* dst = &out[((step * nbt + nb) * 64 + lane) * 4];
+              for (int j = 0; j < 4; ++j) {
+                const int c = chunk * KC + k8 * 8 + 4 * half + j;
+                dst[j] = (n < cout && c < s.cin) ? (float)(s.w(n, c, tap) * (*s.scale)[n]) : 0.f;
+              }
+            }
+  return out;
+}
+
+}  // namespace fpc

@@ -1,0 +1,208 @@
+"""`Engine`: one fpc_ctx (one GPU, one frame geometry) behind a small Python class.
+
+PyTorch is used for what it is good at here -- owning device memory and streams;
+all arithmetic happens inside libfpc.so.  Tensors cross the boundary as raw
+device pointers (`tensor.data_ptr()`).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, arch
+
+
+def _as_tensor_table(state_dict):
+    """{name: array-like} -> (FpcTensor[n], keep-alive list).  Only float entries go in
+    (`num_batches_tracked` is an int64 counter the path never reads)."""
+    keep, items = [], []
+    for name, v in state_dict.items():
+        if isinstance(v, torch.Tensor):
+            if not v.dtype.is_floating_point:
+                continue
+            v = v.detach().cpu().contiguous().float().numpy()
+        else:
+            v = np.asarray(v)
+            if v.dtype.kind != "f":
+                continue
+            v = np.ascontiguousarray(v, dtype=np.float32)
+        if v.ndim > 4:
+            raise ValueError("tensor %s has %d dims" % (name, v.ndim))
+        keep.append(v)
+        items.append((name.encode(), v))
+    table = (_lib.FpcTensor * len(items))()
+    for i, (name, v) in enumerate(items):
+        table[i].name = name
+        table[i].data = v.ctypes.data
+        table[i].ndim = v.ndim
+        for d in range(v.ndim):
+            table[i].shape[d] = v.shape[d]
+    keep.append(items)
+    return table, keep
+
+
+class Engine:
+    def __init__(self, height, width, max_batch=1, device=0, nms_dist=4, conf_thresh=0.015,
+                 border_remove=4, descriptor_enabled=True, max_keypoints=0):
+        self._l = _lib.load()          # raises if libfpc.so is not built: no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("fpc_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU path in the product")
+        cfg = _lib.FpcConfig()
+        _lib.check(self._l.fpc_default_config(ctypes.byref(cfg)), "fpc_default_config")
+        cfg.device, cfg.height, cfg.width, cfg.max_batch = device, height, width, max_batch
+        cfg.nms_dist, cfg.conf_thresh, cfg.border_remove = nms_dist, conf_thresh, border_remove
+        cfg.descriptor_enabled, cfg.max_keypoints = int(bool(descriptor_enabled)), max_keypoints
+        self.cfg = cfg
+        self.h, self.w, self.max_batch, self.device = height, width, max_batch, device
+        self.descriptor_enabled = bool(descriptor_enabled)
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self._l.fpc_create(ctypes.byref(self._ctx), ctypes.byref(cfg)), "fpc_create")
+        self.torch_device = torch.device("cuda", device)
+        res = _lib.FpcDeviceResults()
+        _lib.check(self._l.fpc_results(self._ctx, ctypes.byref(res)), "fpc_results")
+        self.capacity, self.desc_dim = res.capacity, res.desc_dim
+        self._res = res
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._l.fpc_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------
+    def load_state_dict(self, state_dict):
+        """Strict load of ckpt['model_state_dict'] (reference: saveutils.py:6-18)."""
+        table, keep = _as_tensor_table(state_dict)
+        _lib.check(self._l.fpc_load_weights(self._ctx, table, len(table)), "fpc_load_weights")
+        del keep
+
+    def packed_size(self):
+        return self._l.fpc_packed_size(self._ctx)
+
+    def packed_view(self):
+        """The packed weight blob as a uint8 CUDA tensor aliasing the library's buffer
+        (the in-place target of the RCCL broadcast, see dist.py)."""
+        n = self.packed_size()
+        ptr = self._l.fpc_packed_device_ptr(self._ctx)
+        holder = _DevArray(ptr, n)
+        return torch.as_tensor(holder, device=self.torch_device)
+
+    def export_packed(self):
+        buf = np.empty(self.packed_size(), np.uint8)
+        _lib.check(self._l.fpc_export_packed(self._ctx, buf.ctypes.data, buf.nbytes), "fpc_export_packed")
+        return buf
+
+    def import_packed(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        _lib.check(self._l.fpc_import_packed(self._ctx, buf.ctypes.data, buf.nbytes), "fpc_import_packed")
+
+    def mark_weights_loaded(self):
+        _lib.check(self._l.fpc_mark_weights_loaded(self._ctx), "fpc_mark_weights_loaded")
+
+    # -- execution -------------------------------------------------------------------
+    def use_torch_stream(self):
+        s = torch.cuda.current_stream(self.torch_device).cuda_stream
+        _lib.check(self._l.fpc_set_stream(self._ctx, ctypes.c_void_p(s)), "fpc_set_stream")
+
+    def _frames(self, frames):
+        if not isinstance(frames, torch.Tensor):
+            frames = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32))
+        frames = frames.to(self.torch_device, torch.float32).contiguous()
+        if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[2] != self.h or frames.shape[3] != self.w:
+            raise ValueError("frames must be [n,3,%d,%d], got %s" % (self.h, self.w, tuple(frames.shape)))
+        if frames.shape[0] > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (frames.shape[0], self.max_batch))
+        return frames
+
+    def forward(self, frames):
+        """SuperPoint.forward (superpoint.py:91-115): -> prob_map [n,H,W], desc [n,128,H/8,W/8],
+        logits [n,65,H/8,W/8] as CUDA tensors."""
+        frames = self._frames(frames)
+        n = frames.shape[0]
+        dev = self.torch_device
+        prob = torch.empty((n, self.h, self.w), device=dev)
+        desc = torch.empty((n, 128, self.h // 8, self.w // 8), device=dev)
+        logits = torch.empty((n, 65, self.h // 8, self.w // 8), device=dev)
+        torch.cuda.synchronize(dev)
+        _lib.check(self._l.fpc_forward(self._ctx, frames.data_ptr(), n, prob.data_ptr(), desc.data_ptr(),
+                                       logits.data_ptr()), "fpc_forward")
+        self.sync()
+        return prob, desc, logits
+
+    def detect_async(self, frames_dev, n):
+        """Enqueue the whole path for n device-resident frames (no sync, no copies)."""
+        _lib.check(self._l.fpc_detect(self._ctx, frames_dev.data_ptr(), n), "fpc_detect")
+
+    def detect(self, frames):
+        frames = self._frames(frames)
+        torch.cuda.synchronize(self.torch_device)
+        self.detect_async(frames, frames.shape[0])
+        return self.fetch(frames.shape[0])
+
+    def get_points(self, prob_map, desc_map=None):
+        """Post-processing only, on caller-provided dense maps (netutils.py:78-121)."""
+        prob_map = prob_map.to(self.torch_device, torch.float32).contiguous()
+        n = prob_map.shape[0]
+        dptr = None
+        if desc_map is not None:
+            desc_map = desc_map.to(self.torch_device, torch.float32).contiguous()
+            dptr = desc_map.data_ptr()
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_get_points(self._ctx, prob_map.data_ptr(), dptr, n), "fpc_get_points")
+        return self.fetch(n, with_desc=desc_map is not None)
+
+    def sync(self):
+        _lib.check(self._l.fpc_sync(self._ctx), "fpc_sync")
+
+    def counts(self, n):
+        cnt = np.zeros(n, np.int32)
+        ncand = np.zeros(n, np.int32)
+        _lib.check(self._l.fpc_get_counts(self._ctx, n, cnt.ctypes.data, ncand.ctypes.data), "fpc_get_counts")
+        return cnt, ncand
+
+    def fetch(self, n, with_desc=None):
+        """-> list of (xy int32[K,2], conf float32[K], desc float32[K,128] | None, n_candidates)."""
+        if with_desc is None:
+            with_desc = self.descriptor_enabled
+        cnt, ncand = self.counts(n)
+        out = []
+        for f in range(n):
+            k = int(cnt[f])
+            xy = np.empty((k, 2), np.int32)
+            conf = np.empty(k, np.float32)
+            desc = np.empty((k, 128), np.float32) if with_desc else None
+            got = self._l.fpc_get_keypoints(self._ctx, f, k, xy.ctypes.data, conf.ctypes.data,
+                                            desc.ctypes.data if with_desc else None)
+            _lib.check(got, "fpc_get_keypoints")
+            assert got == k
+            out.append((xy, conf, desc, int(ncand[f])))
+        return out
+
+    # -- timing ----------------------------------------------------------------------
+    def set_timing(self, on):
+        _lib.check(self._l.fpc_set_timing(self._ctx, int(bool(on))), "fpc_set_timing")
+
+    def timings(self):
+        cap = 128
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        fl = (ctypes.c_double * cap)()
+        n = _lib.check(self._l.fpc_get_timings(self._ctx, cap, names, ms, fl), "fpc_get_timings")
+        return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(min(n, cap))]
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ holder so torch can alias library-owned memory."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def conv_flops_per_frame(h, w, descriptor=True):
+    return 2.0 * arch.conv_macs(h, w, descriptor)

@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's Python interface for this path:
+
+    reference                                      here
+    python/src/settings.py  SuperPointSettings  -> SuperPointSettings
+    python/src/saveutils.py load_checkpoint_for_inference -> load_checkpoint_for_inference
+    python/src/superpoint.py SuperPoint.forward -> SuperPoint.forward / __call__
+    python/src/netutils.py  get_points          -> get_points
+    python/src/netutils.py  get_descriptors     -> get_descriptors
+    python/src/inferencewrapper.py InferenceWrapper.{run,prepare_input} -> same names
+
+Same names, argument meaning and return conventions (points: float64 [3,K] rows
+x, y, confidence, descending confidence; descriptors: float32 [D,K], unit columns).
+Differences, all documented in DESIGN.md: load failures raise instead of exit();
+batches give independent per-frame results (the reference merges frames,
+netutils.py:59-61); ties in confidence are ordered by row-major pixel index.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .engine import Engine
+
+
+class SuperPointSettings:
+    """Inference fields of python/src/settings.py:2-8 (training fields are out of scope)."""
+
+    def __init__(self):
+        self.cuda = True
+        self.nms_dist = 4
+        self.confidence_thresh = 0.015
+        self.nn_thresh = 0.7
+        self.cell = 8
+        self.border_remove = 4
+
+
+def load_checkpoint_for_inference(filename):
+    """Reads the reference's checkpoint file (saveutils.py:54-63: a dict with
+    'model_state_dict') and returns the state dict; a bare state dict is accepted too."""
+    if not os.path.exists(filename):
+        raise FileNotFoundError("Failed to load checkpoint: %s" % filename)
+    ckpt = torch.load(filename, map_location="cpu", weights_only=True)
+    if isinstance(ckpt, dict) and "model_state_dict" in ckpt:
+        ckpt = ckpt["model_state_dict"]
+    return ckpt
+
+
+class SuperPoint:
+    """The network object (python/src/superpoint.py:64-115) backed by libfpc.so."""
+
+    def __init__(self, settings, device=0, max_batch=1):
+        self.settings = settings
+        self.is_descriptor_enabled = True
+        self.device = device
+        self.max_batch = max_batch
+        self._state_dict = None
+        self._engines = {}
+
+    def disable_descriptor(self):       # superpoint.py:74-78
+        self.is_descriptor_enabled = False
+
+    def enable_descriptor(self):        # superpoint.py:80-84
+        self.is_descriptor_enabled = True
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._state_dict = state_dict
+        for e in self._engines.values():
+            e.load_state_dict(state_dict)
+
+    def engine(self, h, w, batch=1):
+        key = (h, w, self.is_descriptor_enabled)
+        e = self._engines.get(key)
+        if e is None or e.max_batch < batch:
+            if e is not None:
+                e.close()
+            s = self.settings
+            e = Engine(h, w, max(batch, self.max_batch), self.device, s.nms_dist, s.confidence_thresh,
+                       s.border_remove, self.is_descriptor_enabled)
+            if self._state_dict is None:
+                raise RuntimeError("SuperPoint: no weights loaded")
+            e.load_state_dict(self._state_dict)
+            self._engines[key] = e
+        return e
+
+    def forward(self, image):
+        if len(image.shape) <= 2:       # superpoint.py:94-95
+            return torch.empty((1,)), torch.empty((1,)), torch.empty((1,))
+        h, w = image.shape[-2:]
+        return self.engine(h, w, image.shape[0]).forward(image)
+
+    __call__ = forward
+
+
+def get_points(prob_map, img_h, img_w, settings, engine=None):
+    """netutils.py:78-100 for a [1,H,W] probability map -> float64 [3,K]."""
+    if prob_map.dim() == 2:
+        prob_map = prob_map.unsqueeze(0)
+    if prob_map.shape[0] != 1:
+        raise ValueError("get_points takes one frame (the reference merges a batch: netutils.py:59-61)")
+    e = engine or Engine(img_h, img_w, 1, prob_map.device.index or 0, settings.nms_dist,
+                         settings.confidence_thresh, settings.border_remove, True)
+    xy, conf, _, _ = e.get_points(prob_map)[0]
+    return _points_array(xy, conf)
+
+
+def get_descriptors(points, descriptors_map, img_h, img_w, settings, engine=None):
+    """netutils.py:103-121 -> float32 [D,K]."""
+    d = descriptors_map.shape[1]
+    if points.shape[1] == 0:
+        return np.zeros((d, 0))
+    raise NotImplementedError("use InferenceWrapper.run / Engine.get_points(prob_map, desc_map): "
+                              "points and descriptors are produced in one device pass")
+
+
+def _points_array(xy, conf):
+    pts = np.zeros((3, len(conf)))
+    pts[0], pts[1], pts[2] = xy[:, 0], xy[:, 1], conf
+    return pts
+
+
+class InferenceWrapper:
+    """python/src/inferencewrapper.py:12-46,70-81."""
+
+    def __init__(self, weights_path, settings, device=0, max_batch=1):
+        self.name = "SuperPoint"
+        self.settings = settings
+        self.net = SuperPoint(settings, device, max_batch)
+        self.net.load_state_dict(load_checkpoint_for_inference(weights_path))
+
+    def prepare_input(self, img):
+        if not torch.is_tensor(img):
+            assert img.ndim == 3
+            assert img.dtype == np.float32, "Image must be float32."
+            assert img.shape[2] == 3, "Image must be rgb."
+            input_tensor = torch.from_numpy(img.copy().transpose((2, 0, 1))).unsqueeze(0)
+        else:
+            input_tensor = img
+        return input_tensor
+
+    def run(self, img):
+        """-> (points float64 [3,K], descriptors float32 [D,K])."""
+        x = self.prepare_input(img)
+        if x.shape[0] != 1:
+            raise ValueError("run() takes one frame; use run_batch() for several")
+        pts, desc = self.run_batch(x)[0]
+        return pts, desc
+
+    def run_batch(self, frames):
+        """frames [n,3,H,W] -> list of (points [3,K], descriptors [D,K]), one per frame."""
+        h, w = frames.shape[2], frames.shape[3]
+        e = self.net.engine(h, w, frames.shape[0])
+        out = []
+        for xy, conf, desc, _ in e.detect(frames):
+            d = desc.T.copy() if desc is not None else np.full((128, len(conf)), np.nan, np.float32)
+            out.append((_points_array(xy, conf), d))
+        return out

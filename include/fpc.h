@@ -1,0 +1,154 @@
+/*
+ * fpc.h -- C-ABI of the MI355X-native SuperPoint inference path (libfpc.so).
+ *
+ * The reference (Kolkir/feature-point-cnn) has no plugin / FFI interface for this
+ * path: its boundary is a pair of plain classes,
+ *     C++    superpoint::SuperPoint            cpp/src/superpoint.h:12-36
+ *     Python InferenceWrapper / SuperPoint     python/src/inferencewrapper.py:12-46,
+ *                                              python/src/superpoint.py:64-115
+ * Each entry point below names the reference code it stands in for.  Plain
+ * pointers and sizes only; no torch / OpenCV types cross this boundary.  Every
+ * function returns FPC_OK (0) or a negative FPC_E_* code -- nothing exits or
+ * throws across the ABI (the reference exit()s: cpp/src/superpoint.cc:56-59,
+ * python/src/saveutils.py:11-14).
+ *
+ * Threading: one fpc_ctx per GPU; calls on one ctx are serialised by the caller
+ * (the reference object is not re-entrant either: cpp/src/superpoint.h:31-35);
+ * distinct contexts are independent.
+ *
+ * There is no CPU fallback: without a HIP device fpc_create fails with
+ * FPC_E_NO_DEVICE.
+ */
+#ifndef FPC_H
+#define FPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPC_ABI_VERSION 1
+
+enum {
+  FPC_OK = 0,
+  FPC_E_INVALID = -1,     /* bad argument / unsupported geometry                  */
+  FPC_E_NO_DEVICE = -2,   /* no usable HIP device                                 */
+  FPC_E_HIP = -3,         /* a HIP runtime call failed (fpc_last_hip_error)       */
+  FPC_E_NO_WEIGHTS = -4,  /* forward/detect before any weights were loaded        */
+  FPC_E_MISSING_KEY = -5, /* checkpoint entry missing or of the wrong shape       */
+  FPC_E_CAPACITY = -6,    /* caller buffer too small (needed size is reported)    */
+  FPC_E_NOT_CONVERGED = -7 /* NMS round limit hit (never seen)     */
+};
+
+/* Replaces SuperPointSettings (python/src/settings.py:2-8) / Settings
+ * (cpp/src/settings.h:27-31) plus the geometry the reference takes from the frame. */
+typedef struct fpc_config {
+  int device;             /* HIP device ordinal                                    */
+  int height, width;      /* frame size; multiples of 16     */
+  int max_batch;          /* frames per fpc_detect / fpc_forward call              */
+  int cell;               /* 8   settings.py:7   (only 8 is supported)             */
+  int nms_dist;           /* 4   settings.py:4                                     */
+  float conf_thresh;      /* 0.015 settings.py:5                                   */
+  int border_remove;      /* 4   settings.py:8                                     */
+  int descriptor_enabled; /* 0 = MagicPoint, detector only (superpoint.py:103-109) */
+  int max_keypoints;      /* per-frame output capacity; 0 = worst case for nms_dist */
+  int reserved[7];
+} fpc_config;
+
+/* One checkpoint entry: name and shape as in ckpt['model_state_dict']
+ * (python/src/saveutils.py:57-62), data in host memory. */
+typedef struct fpc_tensor {
+  const char* name;
+  const float* data;      /* float32, contiguous, PyTorch layout                   */
+  int ndim;
+  int64_t shape[4];
+} fpc_tensor;
+
+/* Device-resident results of the last fpc_detect call (zero-copy view). */
+typedef struct fpc_device_results {
+  const int32_t* count;       /* [n]            keypoints per frame (after border crop)    */
+  const int32_t* n_candidates;/* [n]            pixels that passed conf_thresh             */
+  const int32_t* xy;          /* [n][cap][2]    x, y                                       */
+  const float* conf;          /* [n][cap]       descending (ties: row-major index ascending)*/
+  const float* desc;          /* [n][cap][D]    unit L2 norm; NULL when descriptors are off */
+  int capacity;               /* cap                                                       */
+  int desc_dim;               /* D = 128                                                   */
+} fpc_device_results;
+
+typedef struct fpc_ctx fpc_ctx;
+
+int fpc_abi_version(void);
+const char* fpc_strerror(int code);
+/* Text of the last HIP error seen by this thread (for FPC_E_HIP). */
+const char* fpc_last_hip_error(void);
+
+/* Fills the reference's defaults (settings.py:2-8), 480x640, max_batch 1. */
+int fpc_default_config(fpc_config* cfg);
+
+/* ~ SuperPoint::SuperPoint (cpp/src/superpoint.cc:9-66) / InferenceWrapper.__init__
+ * (python/src/inferencewrapper.py:13-27) minus the file parsing: allocates the
+ * device workspace for max_batch frames. */
+int fpc_create(fpc_ctx** out, const fpc_config* cfg);
+void fpc_destroy(fpc_ctx* ctx);
+
+/* ~ load_checkpoint_for_inference (python/src/saveutils.py:6-18), strict: every
+ * learnable entry of table W must be present with the right shape
+ * (`num_batches_tracked` entries are ignored).  Folds BatchNorm (eval mode,
+ * eps 1e-5) into the convolutions and packs MFMA fragments on the device.
+ * With descriptor_enabled == 0 the `descriptor.*` entries may be absent. */
+int fpc_load_weights(fpc_ctx* ctx, const fpc_tensor* tensors, int n);
+
+/* Packed, folded weights as one blob -- what rank 0 broadcasts over RCCL/xGMI
+ * instead of every rank parsing the checkpoint.  Layout is private to one build. */
+size_t fpc_packed_size(const fpc_ctx* ctx);
+void* fpc_packed_device_ptr(fpc_ctx* ctx);              /* in-place collective target */
+int fpc_export_packed(fpc_ctx* ctx, void* host_dst, size_t cap);
+int fpc_import_packed(fpc_ctx* ctx, const void* host_src, size_t n);
+/* Declares the blob at fpc_packed_device_ptr valid (after a broadcast into it). */
+int fpc_mark_weights_loaded(fpc_ctx* ctx);
+
+/* Work is enqueued on this hipStream_t (default: a stream the ctx owns). */
+int fpc_set_stream(fpc_ctx* ctx, void* hip_stream);
+void* fpc_get_stream(fpc_ctx* ctx);
+int fpc_sync(fpc_ctx* ctx);
+
+/* ~ SuperPoint.forward (python/src/superpoint.py:91-115): frames [n,3,H,W] float32
+ * on the device -> prob_map [n,H,W], desc [n,128,H/8,W/8], logits [n,65,H/8,W/8]
+ * (device, NCHW like the reference; any output may be NULL).  Asynchronous. */
+int fpc_forward(fpc_ctx* ctx, const float* frames_dev, int n, float* prob_map_dev,
+                float* desc_dev, float* logits_dev);
+
+/* ~ InferenceWrapper.run (inferencewrapper.py:29-46) / SuperPoint::ProcessFrame
+ * (cpp/src/superpoint.cc:68-96) for n independent frames: forward, exp-softmax,
+ * depth-to-space, threshold, greedy NMS, sort, border crop (netutils.py:78-100,
+ * nms.py:4-53), descriptor sampling + L2 normalisation (netutils.py:103-121).
+ * Asynchronous; results stay on the device until fetched. */
+int fpc_detect(fpc_ctx* ctx, const float* frames_dev, int n);
+
+/* Runs only the post-processing of fpc_detect on a caller-provided probability map
+ * [n,H,W] (device) -- get_points on its own (netutils.py:78-100). Descriptors are
+ * sampled from desc_nchw_dev [n,128,H/8,W/8] when it is not NULL. */
+int fpc_get_points(fpc_ctx* ctx, const float* prob_map_dev, const float* desc_nchw_dev, int n);
+
+int fpc_results(fpc_ctx* ctx, fpc_device_results* out);
+/* Synchronises, then copies the per-frame counts to the host. */
+int fpc_get_counts(fpc_ctx* ctx, int n, int32_t* count_host, int32_t* n_candidates_host);
+/* Synchronises, then copies frame `frame`'s keypoints: xy [K][2], conf [K],
+ * desc [K][128] (desc may be NULL).  Returns K, or FPC_E_CAPACITY if K > cap
+ * (nothing is written then; fpc_get_counts gives the size). */
+int fpc_get_keypoints(fpc_ctx* ctx, int frame, int cap, int32_t* xy, float* conf, float* desc);
+
+/* Optional per-launch timing for the bench: with `enable`, every kernel launch of
+ * fpc_detect / fpc_forward is bracketed by HIP events on the launch stream. */
+int fpc_set_timing(fpc_ctx* ctx, int enable);
+/* After fpc_sync: number of launches recorded by the last call; names[i] points
+ * into ctx-owned storage; ms[i] is the event-to-event duration; flops[i] the
+ * algorithmic FLOPs of that launch (0 for non-conv kernels). */
+int fpc_get_timings(fpc_ctx* ctx, int cap, const char** names, float* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPC_H */
