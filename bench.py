@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VGA SuperPoint forward + NMS + descriptors, frames/s.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the whole hot path (fpc_detect: network, exp-softmax,
+depth-to-space, threshold, greedy NMS, sort, border crop, descriptor sampling) over
+one batch of 32 synthetic 640x480 frames that is already resident in HBM
+(BASELINE.json configs[1]).  With N ranks every rank runs its own 32-frame batch
+(weak scaling; configs[2] = 256 frames over 8 GPUs); the only collective is the
+start-up broadcast of the packed weights.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import fpc_amd  # noqa: E402,F401
+from fpc_amd import arch, dist as fdist, synth  # noqa: E402
+from fpc_amd.engine import Engine  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (dense, f32 in / f32 acc)
+BATCH = 32
+H, W = 480, 640
+
+
+def cpu_baseline(state_dict, frames):
+    """The CPU oracle (oracle/fpc_oracle.c, kind "port") timed on this host's cores on a
+    bounded sample of the same workload.  Rank 0, N=1 only."""
+    from oracle import oracle
+    spec = arch.state_dict_spec()
+    n = frames.shape[0]
+    threads = oracle.max_threads()
+    oracle.forward(frames[:1], state_dict, spec)          # warm-up
+    t0 = time.perf_counter()
+    kept = 0
+    for i in range(n):
+        prob, desc, _ = oracle.forward(frames[i:i + 1], state_dict, spec)
+        xs, ys, _, _ = oracle.get_points(prob[0])
+        oracle.get_descriptors(desc[0], xs, ys, H, W)
+        kept += len(xs)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d of the bench's 640x480 frames, full path (forward + get_points + get_descriptors), "
+                      "oracle/fpc_oracle.c with %d OpenMP threads, %.1f s" % (n, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timing-events", action="store_true",
+                    help="do not bracket launches with HIP events (roofline then comes from a separate pass)")
+    args = ap.parse_args()
+
+    rank, world, local = fdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # synthetic checkpoint in the reference's layout; rank 0 packs and broadcasts it
+    sd = synth.make_state_dict(0, dustbin_bias=7.0) if rank == 0 else None
+    eng = Engine(H, W, max_batch=BATCH, device=local)
+    fdist.broadcast_packed_weights(eng, sd)
+    # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
+    frames_np = synth.make_batch(100 + BATCH * rank, BATCH, H, W)
+    frames = torch.from_numpy(frames_np).to(dev)
+    torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.detect_async(frames, BATCH)
+    eng.sync()
+    cnt, ncand = eng.counts(BATCH)
+
+    use_events = not args.no_timing_events
+    eng.set_timing(use_events)
+    per_kernel = {}
+    fdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.detect_async(frames, BATCH)
+        if use_events:
+            # events of a step are read back after the step has drained; the next step's
+            # launches are already queued behind it, so the GPU does not idle
+            pass
+    eng.sync()
+    torch.cuda.synchronize(dev)
+    fdist.barrier()
+    dt = time.perf_counter() - t0
+    if use_events:
+        for name, ms, fl in eng.timings():   # the LAST step's events (every step records the same launches)
+            per_kernel.setdefault(name, []).append((ms, fl * BATCH))
+    eng.set_timing(False)
+    dt = fdist.max_over_ranks(dt)
+    total_frames = BATCH * args.steps * world
+
+    if rank == 0:
+        value = total_frames / dt
+        flops_frame = 2.0 * arch.conv_macs(H, W)
+        out = {
+            "metric": "frames/sec (VGA 640x480) SuperPoint fwd+NMS+descriptors",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded frames + seeded checkpoint in the reference's layout)",
+            "config": {"workload": "batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
+                                   "(BASELINE.json configs[1]; configs[2] when n_gpus=8)",
+                       "frames_per_step_per_gpu": BATCH, "height": H, "width": W,
+                       "parallelism": "frame-sharded x%d, no data-path collective" % world},
+            "frames_per_sec_per_gpu": round(value / world, 2),
+            "whole_path_tflops": round(value * flops_frame / 1e12, 3),
+            "whole_path_frac_of_f32_mfma_peak": round(value / world * flops_frame / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "keypoints_per_frame": round(float(np.mean(cnt)), 1),
+            "candidates_per_frame": round(float(np.mean(ncand)), 1),
+        }
+        if per_kernel:
+            # dominant kernel = the launch with the largest share of the step
+            name, lst = max(per_kernel.items(), key=lambda kv: sum(m for m, _ in kv[1]))
+            ms = float(np.mean([m for m, _ in lst]))
+            fl = lst[0][1]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3),
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(ms, 4), "flops_per_launch": fl}
+            conv_ms = sum(np.mean([m for m, _ in v]) for k, v in per_kernel.items() if v[0][1] > 0)
+            all_ms = sum(np.mean([m for m, _ in v]) for v in per_kernel.values())
+            out["kernel_ms"] = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in per_kernel.items()}
+            out["conv_kernels_tflops"] = round(BATCH * flops_frame / (conv_ms * 1e-3) / 1e12, 3)
+            out["sum_kernel_ms"] = round(float(all_ms), 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, frames_np[:8])
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@
 // live in one packed blob (BN folded, MFMA fragment order) that stays L2-resident.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -634,9 +635,8 @@ static int op_index(const fpc_ctx* c, OpType t) {
 static int run_softmax(fpc_ctx* c, int n) {
   HIPCHECK(hipMemsetAsync(c->ncand, 0, sizeof(int32_t) * c->B, c->stream));
   LaunchTimer t(c, op_index(c, OP_SOFTMAX));
-  const int cells = n * c->Hc * c->Wc;
-  hipLaunchKernelGGL(softmax_d2s_kernel, dim3((cells + 3) / 4), dim3(256), 0, c->stream, c->lg, 72, n, c->Hc, c->Wc,
-                     c->cfg.conf_thresh, c->prob, c->nmsmap, c->cand, c->ncand);
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(n * c->Hc), dim3(256), (size_t)16 * c->W * sizeof(float), c->stream,
+                     c->lg, 72, n, c->Hc, c->Wc, c->cfg.conf_thresh, c->prob, c->nmsmap, c->cand, c->ncand);
   return FPC_OK;
 }
 
@@ -648,6 +648,13 @@ static int run_nms(fpc_ctx* c, int n) {
   a.H = c->H; a.W = c->W; a.r = c->cfg.nms_dist; a.border = c->cfg.border_remove; a.cap = c->cap;
   a.count = c->count; a.xy = c->xy; a.conf = c->conf; a.status = c->status;
   a.max_rounds = c->H * c->W;
+  // enough workgroups that a typical frame (a few thousand candidates) has about one
+  // candidate per thread, while the whole grid stays co-resident (2 x 1024 threads per CU)
+  const int G = std::max(1, std::min(16, 256 / n));
+  if (c->cfg.nms_dist == 4)
+    hipLaunchKernelGGL(nms_rounds_kernel<4>, dim3(G, n), dim3(1024), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(nms_rounds_kernel<0>, dim3(G, n), dim3(1024), 0, c->stream, a);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), NMS_LDS_KEYS * sizeof(unsigned long long), c->stream, a);
   return FPC_OK;
 }
@@ -703,7 +710,10 @@ int fpc_default_config(fpc_config* cfg) {
 int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   if (!out || !cfg) return FPC_E_INVALID;
   *out = nullptr;
-  if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % 16 || cfg->width % 16 ||
+  // the descriptor head halves the 1/8 map and doubles it again (superpoint.py:43-59): odd
+  // H/8 or W/8 breaks its concat, so frames must be multiples of 16 unless it is disabled
+  const int mult = cfg->descriptor_enabled ? 16 : 8;
+  if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30))
     return FPC_E_INVALID;
@@ -730,6 +740,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->own_stream = true;
   for (int k = 0; k < K_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
+  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
   int rc = build_plan(c.get());

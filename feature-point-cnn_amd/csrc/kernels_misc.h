@@ -149,32 +149,47 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* 
 __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
                                                           float thresh, float* prob, uint32_t* nmsmap,
                                                           uint32_t* cand, int32_t* ncand) {
-  const int lane = threadIdx.x & 63;
-  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (cell >= B * Hc * Wc) return;
-  const int b = cell / (Hc * Wc);
-  const int r = cell - b * (Hc * Wc);
-  const int i = r / Wc, j = r - i * Wc;
-  const float* l = logits + (size_t)cell * cs;
-  const float e = expf(l[lane]);
-  const float ed = expf(l[64]);
-  float s = e;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float p = e / ((s + ed) + .00001f);
+  // one workgroup per ROW of cells: the 8 x W strip of probabilities is assembled in LDS so
+  // that the dense maps are written as whole rows, and the strip's candidates are appended
+  // with ONE global atomic (per-wave atomics on one counter serialise at ~11 ns each).
+  extern __shared__ float strip[];                 // [8][W] floats, then [8*W] candidate slots
+  __shared__ int s_cnt, s_base;
   const int W = Wc * 8, H = Hc * 8;
-  const int y = i * 8 + (lane >> 3), x = j * 8 + (lane & 7);
-  const uint32_t idx = y * W + x;
-  prob[(size_t)b * H * W + idx] = p;
-  const bool c = p >= thresh;
-  nmsmap[(size_t)b * H * W + idx] = c ? __float_as_uint(p) : 0u;
-  const unsigned long long mask = __ballot(c);
-  if (mask) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&ncand[b], __popcll(mask));
-    base = __shfl(base, 0);
-    if (c) cand[(size_t)b * H * W + base + __popcll(mask & ((1ull << lane) - 1))] = idx;
+  uint32_t* s_list = reinterpret_cast<uint32_t*>(strip + 8 * W);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / Hc, i = blockIdx.x - b * Hc;
+  if (tid == 0) s_cnt = 0;
+  for (int j = wave; j < Wc; j += 4) {
+    const float* l = logits + ((size_t)(b * Hc + i) * Wc + j) * cs;
+    const float e = expf(l[lane]);
+    const float ed = expf(l[64]);
+    float s = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    strip[(lane >> 3) * W + j * 8 + (lane & 7)] = e / ((s + ed) + .00001f);
   }
+  __syncthreads();
+  const size_t fbase = (size_t)b * H * W + (size_t)i * 8 * W;
+  for (int k = tid; k < 8 * W; k += 256) {         // 8*W is a multiple of 64: whole waves
+    const float p = strip[k];
+    const bool c = p >= thresh;
+    prob[fbase + k] = p;
+    nmsmap[fbase + k] = c ? __float_as_uint(p) : 0u;
+    const unsigned long long mask = __ballot(c);
+    if (mask) {
+      int off = 0;
+      if (lane == 0) off = atomicAdd(&s_cnt, __popcll(mask));
+      off = __shfl(off, 0);
+      if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (uint32_t)(i * 8 * W + k);
+    }
+  }
+  __syncthreads();
+  const int n = s_cnt;
+  if (n == 0) return;
+  if (tid == 0) s_base = atomicAdd(&ncand[b], n);
+  __syncthreads();
+  uint32_t* dst = cand + (size_t)b * H * W + s_base;
+  for (int k = tid; k < n; k += 256) dst[k] = s_list[k];
 }
 
 // Same outputs from a caller-provided dense probability map (fpc_get_points).
@@ -241,78 +256,121 @@ __device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
-  extern __shared__ unsigned long long keys_lds[];
-  __shared__ int s_count;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int H = a.H, W = a.W, r = a.r;
+// Rounds.  grid = (G, B): the frame's candidates are dealt over G workgroups; a workgroup
+// leaves as soon as all of ITS candidates are decided.  Neighbour words are read and
+// written with relaxed agent-scope atomics only (they may belong to a workgroup on another
+// CU / XCD); a workgroup never blocks on another one, it just runs another round, so the
+// kernel needs no co-residency guarantee.
+template <int R>
+__device__ __forceinline__ void nms_scan(const uint32_t* map, int H, int W, int r, uint32_t ci, uint32_t v,
+                                         bool* kept_nb, bool* wait) {
+  const int y = ci / W, x = ci - y * W;
+  bool k = false, w = false;
+  if (R > 0) {  // compile-time radius: all (2R+1)^2 loads are issued before any is tested
+    uint32_t u[(2 * R + 1) * (2 * R + 1)];
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+      for (int dx = -R; dx <= R; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        u[(dy + R) * (2 * R + 1) + dx + R] = ld_relaxed(map + (ok ? yy * W + xx : (int)ci));
+      }
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+      for (int dx = -R; dx <= R; ++dx) {
+        if (dy == 0 && dx == 0) continue;
+        const int yy = y + dy, xx = x + dx;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const uint32_t q = yy * W + xx, uu = u[(dy + R) * (2 * R + 1) + dx + R];
+        k |= ok && (uu & 0x80000000u);
+        w |= ok && !(uu & 0x80000000u) && (uu > v || (uu == v && q < ci));
+      }
+  } else {
+    const int y0 = max(y - r, 0), y1 = min(y + r, H - 1), x0 = max(x - r, 0), x1 = min(x + r, W - 1);
+    for (int yy = y0; yy <= y1 && !k; ++yy)
+      for (int xx = x0; xx <= x1; ++xx) {
+        const uint32_t q = yy * W + xx;
+        if (q == ci) continue;
+        const uint32_t uu = ld_relaxed(map + q);
+        if (uu & 0x80000000u) k = true;
+        else if (uu > v || (uu == v && q < ci)) w = true;
+      }
+  }
+  *kept_nb = k;
+  *wait = w;
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void nms_rounds_kernel(const NmsArgs a) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int H = a.H, W = a.W;
   uint32_t* map = a.nmsmap + (size_t)b * H * W;
   uint32_t* cand = a.cand + (size_t)b * H * W;
   const int n = a.ncand[b];
-  if (tid == 0) s_count = 0;
-
-  if (n > 1) {  // nms.py:23-25: a single candidate is returned as is
-    for (int round = 0;; ++round) {
-      int pending = 0;
-      for (int i = tid; i < n; i += 1024) {
-        const uint32_t ci = cand[i];
-        if (ci & 0x80000000u) continue;  // decided in an earlier round
-        const int y = ci / W, x = ci - y * W;
-        const uint32_t v = map[ci];      // own word: only this thread ever writes it
-        const int y0 = max(y - r, 0), y1 = min(y + r, H - 1);
-        const int x0 = max(x - r, 0), x1 = min(x + r, W - 1);
-        bool kept_nb = false, wait = false;
-        for (int yy = y0; yy <= y1 && !kept_nb; ++yy) {
-          const uint32_t* row = map + yy * W;
-          for (int xx = x0; xx <= x1; ++xx) {
-            const uint32_t u = ld_relaxed(row + xx);
-            const uint32_t q = yy * W + xx;
-            if (q == ci) continue;
-            if (u & 0x80000000u) kept_nb = true;
-            else if (u > v || (u == v && q < ci)) wait = true;
-          }
-        }
-        if (kept_nb) {
-          st_relaxed(map + ci, 0u);
-          cand[i] = ci | 0x80000000u;
-        } else if (!wait) {
-          st_relaxed(map + ci, v | 0x80000000u);
-          cand[i] = ci | 0x80000000u;
-        } else {
-          ++pending;
-        }
-      }
-      if (!__syncthreads_or(pending)) break;
-      if (round >= a.max_rounds) {
-        if (tid == 0) *a.status = 1;
-        break;
+  if (n <= 1) {  // nms.py:23-25: a single candidate is returned as is
+    if (n == 1 && blockIdx.x == 0 && tid == 0) st_relaxed(map + cand[0], map[cand[0]] | 0x80000000u);
+    return;
+  }
+  const int first = blockIdx.x * 1024 + tid, stride = gridDim.x * 1024;
+  if (blockIdx.x * 1024 >= n) return;
+  for (int round = 0;; ++round) {
+    int pending = 0;
+    for (int i = first; i < n; i += stride) {
+      const uint32_t ci = cand[i];
+      if (ci & 0x80000000u) continue;  // decided in an earlier round (only this thread writes cand[i])
+      const uint32_t v = map[ci];      // own word: only this thread ever writes it
+      bool kept_nb, wait;
+      nms_scan<R>(map, H, W, a.r, ci, v, &kept_nb, &wait);
+      if (kept_nb) {
+        st_relaxed(map + ci, 0u);
+        cand[i] = ci | 0x80000000u;
+      } else if (!wait) {
+        st_relaxed(map + ci, v | 0x80000000u);
+        cand[i] = ci | 0x80000000u;
+      } else {
+        ++pending;
       }
     }
-  } else if (n == 1 && tid == 0) {
-    map[cand[0]] |= 0x80000000u;
+    if (!__syncthreads_or(pending)) break;
+    if (round >= a.max_rounds) {
+      if (tid == 0) *a.status = 1;
+      break;
+    }
+  }
+}
+
+// Survivors inside the border -> sort -> outputs.  One workgroup per frame.
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
+  extern __shared__ unsigned long long keys_lds[];
+  __shared__ int s_count, s_total;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int H = a.H, W = a.W;
+  const uint32_t* map = a.nmsmap + (size_t)b * H * W;
+  const uint32_t* cand = a.cand + (size_t)b * H * W;
+  const int n = a.ncand[b];
+  if (tid == 0) {
+    s_count = 0;
+    s_total = 0;
   }
   __syncthreads();
-
-  // Survivors inside the border, as 64-bit keys (conf bits, ~index): a descending
-  // sort of unique keys gives (confidence desc, index asc) -- netutils.py:92-99.
+  // 64-bit keys (conf bits, ~index): a descending sort of unique keys gives
+  // (confidence desc, index asc) -- netutils.py:92-99.  Count first so that the
+  // LDS / scratch choice is uniform over the workgroup.
   const int bw = a.border;
-  unsigned long long* keys = keys_lds;
-  // count first so that the LDS / scratch choice is uniform
   int mine = 0;
   for (int i = tid; i < n; i += 1024) {
     const uint32_t ci = cand[i] & 0x7fffffffu;
     const int y = ci / W, x = ci - y * W;
-    const bool keep = (map[ci] & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
-    mine += keep;
+    mine += (map[ci] & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
   }
-  __shared__ int s_total;
-  if (tid == 0) s_total = 0;
-  __syncthreads();
   if (mine) atomicAdd(&s_total, mine);
   __syncthreads();
   const int K = s_total;
   int P = 1;
   while (P < K) P <<= 1;
+  unsigned long long* keys = keys_lds;
   if (P > NMS_LDS_KEYS) keys = a.sort_scratch + (size_t)b * a.sort_cap;
   for (int i = tid; i < P; i += 1024) keys[i] = 0ull;
   __syncthreads();
@@ -326,8 +384,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
     }
   }
   __syncthreads();
-  // bitonic sort, descending
-  for (int k = 2; k <= P; k <<= 1)
+  for (int k = 2; k <= P; k <<= 1)  // bitonic sort, descending
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < P; i += 1024) {
         const int l = i ^ j;

@@ -46,7 +46,7 @@ enum {
  * (cpp/src/settings.h:27-31) plus the geometry the reference takes from the frame. */
 typedef struct fpc_config {
   int device;             /* HIP device ordinal                                    */
-  int height, width;      /* frame size; multiples of 16     */
+  int height, width;      /* frame size; multiples of 16 (8 if descriptor_enabled=0)*/
   int max_batch;          /* frames per fpc_detect / fpc_forward call              */
   int cell;               /* 8   settings.py:7   (only 8 is supported)             */
   int nms_dist;           /* 4   settings.py:4                                     */

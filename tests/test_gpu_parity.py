@@ -1,0 +1,310 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle
+and the committed golden fixtures.  Need a real MI355X:  pytest -m gpu
+
+Bars (BASELINE.json north_star): dense float outputs within 1e-4 of the reference;
+keypoint indices after NMS identical.  Integer / index work (threshold, NMS, sort,
+border crop) is compared bit-exact on identical inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import fpc_amd  # noqa: F401
+from fpc_amd import arch, synth
+
+pytestmark = pytest.mark.gpu
+
+SPEC = arch.state_dict_spec()
+ATOL = 1e-4     # the tolerance north_star states
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+def engine(h, w, b=1, **kw):
+    from fpc_amd.engine import Engine
+    return Engine(h, w, max_batch=b, **kw)
+
+
+def oracle_mod():
+    from oracle import oracle
+    return oracle
+
+
+def test_native_library_is_loaded(torch_gpu):
+    from fpc_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libfpc.so" in maps
+
+
+def test_f1_small_frame_dense_maps(torch_gpu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "f1_layers_32x48.npz"))
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_batch(int(g["seed_frame"]), 1, 32, 48)
+    e = engine(32, 48)
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(frame)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(desc.cpu().numpy(), g["desc_map"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(prob.cpu().numpy(), g["prob"], rtol=0, atol=ATOL)
+    # and much tighter against the oracle, relative to the activation scale
+    o_prob, o_desc, o_logits = oracle_mod().forward(frame, sd, SPEC)
+    assert np.max(np.abs(logits.cpu().numpy() - o_logits)) < 2e-5 * max(1.0, np.abs(o_logits).max())
+    assert np.max(np.abs(desc.cpu().numpy() - o_desc)) < 2e-5 * max(1.0, np.abs(o_desc).max())
+    e.close()
+
+
+def _check_frame_against_oracle_postproc(oracle, prob_b, desc_b, res, h, w):
+    """HIP post-processing vs the oracle's on the SAME probability / descriptor maps."""
+    xy, conf, d, ncand = res
+    oxs, oys, oconf, oncand = oracle.get_points(prob_b)
+    assert ncand == oncand
+    np.testing.assert_array_equal(xy[:, 0], oxs)
+    np.testing.assert_array_equal(xy[:, 1], oys)
+    np.testing.assert_array_equal(conf, oconf)          # bit-exact: the same floats, re-ordered
+    if d is not None and len(oxs):
+        od = oracle.get_descriptors(desc_b, oxs, oys, h, w)
+        np.testing.assert_allclose(d, od, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
+def test_f5_end_to_end(torch_gpu, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "f5_e2e_%s.npz" % tag))
+    h, w = int(g["h"]), int(g["w"])
+    de = bool(int(g["descriptor_enabled"]))
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_batch(int(g["seed_frame"]), 1, h, w)
+    e = engine(h, w, descriptor_enabled=de)
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(frame)
+    prob, desc, logits = prob.cpu().numpy(), desc.cpu().numpy(), logits.cpu().numpy()
+    # dense maps vs the reference's probes
+    np.testing.assert_allclose(logits.ravel()[::7], g["logits_probe"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(desc.ravel()[::11], g["desc_map_probe"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(prob.ravel()[::13], g["prob_probe"], rtol=0, atol=ATOL)
+    res = e.detect(frame)[0]
+    oracle = oracle_mod()
+    _check_frame_against_oracle_postproc(oracle, prob[0], desc[0], res, h, w)
+    # keypoint SET identical to the reference's (fixtures are tie-safe: make_golden.py)
+    xy, conf, d, ncand = res
+    gx, gy, gc = g["points_x"].astype(np.int64), g["points_y"].astype(np.int64), g["points_conf"]
+    assert ncand == int(g["n_candidates"])
+    assert len(conf) == len(gc)
+    np.testing.assert_array_equal(np.sort(xy[:, 1].astype(np.int64) * w + xy[:, 0]), np.sort(gy * w + gx))
+    np.testing.assert_allclose(conf, gc, rtol=0, atol=ATOL)
+    if de:
+        order = {int(i): k for k, i in enumerate((gy * w + gx).tolist())}
+        perm = np.array([order[int(i)] for i in xy[:, 1].astype(np.int64) * w + xy[:, 0]])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        np.testing.assert_allclose(d[inv[g["desc_subset_idx"]]], g["desc_subset"], rtol=0, atol=ATOL)
+    else:
+        assert d is None and not desc.any()
+    e.close()
+
+
+F3_CASES = ["empty", "below_thresh", "single", "single_border", "pair_d4", "pair_d5", "pair_diag4",
+            "chain", "border_suppresses", "corners", "dense_cluster", "threshold_edge",
+            "rand_64x96", "rand_120x160", "rand_full_48x64"]
+
+
+def test_f3_get_points_fixtures(torch_gpu, golden_dir):
+    """get_points alone (netutils.py:78-100) on the reference's hand-built maps: exact."""
+    torch = torch_gpu
+    g = np.load(os.path.join(golden_dir, "f3_get_points.npz"))
+    engines = {}
+    for name in F3_CASES:
+        h, w = [int(v) for v in g[name + "_hw"]]
+        pm = np.zeros(h * w, np.float32)
+        pm[g[name + "_idx"]] = g[name + "_val"]
+        ref = g[name + "_out"]
+        if (h, w) not in engines:
+            engines[(h, w)] = engine(h, w, descriptor_enabled=False)
+        xy, conf, _, _ = engines[(h, w)].get_points(torch.from_numpy(pm.reshape(1, h, w)))[0]
+        assert len(conf) == ref.shape[1], name
+        np.testing.assert_array_equal(xy[:, 0], ref[0].astype(np.int32), err_msg=name)
+        np.testing.assert_array_equal(xy[:, 1], ref[1].astype(np.int32), err_msg=name)
+        np.testing.assert_array_equal(conf, ref[2].astype(np.float32), err_msg=name)
+    for e in engines.values():
+        e.close()
+
+
+def test_get_points_ties_and_degenerate_maps(torch_gpu):
+    """Cases the reference leaves unspecified or that stress the kernels: exact ties inside
+    the NMS window, an all-pass map, a constant map -- against the oracle (same defined order)."""
+    torch = torch_gpu
+    oracle = oracle_mod()
+    h, w = 64, 96
+    e = engine(h, w, descriptor_enabled=False)
+    rng = np.random.Generator(np.random.PCG64(4))
+    maps = []
+    m = np.zeros((h, w), np.float32)
+    m[10, 10:40] = 0.5            # a run of exact ties: greedy keeps every 5th by index order
+    m[20:50, 60] = 0.25
+    maps.append(m)
+    maps.append(np.full((h, w), 0.3, np.float32))                      # constant: all ties
+    maps.append(rng.uniform(0.02, 1.0, (h, w)).astype(np.float32))     # all pass
+    q = (rng.integers(0, 8, (h, w)) / 8.0).astype(np.float32)          # heavy ties, some below threshold
+    maps.append(q)
+    maps.append(np.zeros((h, w), np.float32))                          # nothing
+    d = np.linspace(1.0, 0.02, w, dtype=np.float32)                    # monotone chains along rows (many rounds)
+    maps.append(np.tile(d, (h, 1)))
+    for i, m in enumerate(maps):
+        xy, conf, _, ncand = e.get_points(torch.from_numpy(m[None]))[0]
+        oxs, oys, oconf, oncand = oracle.get_points(m)
+        assert ncand == oncand, i
+        np.testing.assert_array_equal(xy[:, 0], oxs, err_msg=str(i))
+        np.testing.assert_array_equal(xy[:, 1], oys, err_msg=str(i))
+        np.testing.assert_array_equal(conf, oconf, err_msg=str(i))
+    e.close()
+
+
+def test_nms_radius_and_border_options(torch_gpu):
+    """nms_dist / border_remove / conf_thresh are runtime settings (settings.py:3-8)."""
+    torch = torch_gpu
+    oracle = oracle_mod()
+    h, w = 48, 64
+    rng = np.random.Generator(np.random.PCG64(8))
+    m = np.where(rng.uniform(0, 1, (h, w)) < 0.2, rng.uniform(0.0, 1.0, (h, w)), 0.0).astype(np.float32)
+    for r, bw, thr in [(0, 0, 0.015), (1, 2, 0.3), (2, 0, 0.015), (7, 6, 0.1), (4, 4, 0.5)]:
+        e = engine(h, w, descriptor_enabled=False, nms_dist=r, border_remove=bw, conf_thresh=thr)
+        xy, conf, _, ncand = e.get_points(torch.from_numpy(m[None]))[0]
+        oxs, oys, oconf, oncand = oracle.get_points(m, thr, r, bw)
+        assert ncand == oncand
+        np.testing.assert_array_equal(xy[:, 0], oxs)
+        np.testing.assert_array_equal(xy[:, 1], oys)
+        np.testing.assert_array_equal(conf, oconf)
+        e.close()
+
+
+def test_descriptor_sampling_against_oracle(torch_gpu):
+    """get_descriptors (netutils.py:103-121) incl. the frame corners (zero-padding taps)."""
+    torch = torch_gpu
+    oracle = oracle_mod()
+    h, w = 64, 96
+    rng = np.random.Generator(np.random.PCG64(12))
+    dm = rng.uniform(0.0, 2.0, (1, 128, h // 8, w // 8)).astype(np.float32)
+    pm = np.zeros((1, h, w), np.float32)
+    pts = [(0, 0), (w - 1, h - 1), (w - 1, 0), (0, h - 1), (8, 8), (16, 24), (33, 17), (95, 32), (48, 63), (5, 44)]
+    for k, (x, y) in enumerate(pts):
+        pm[0, y, x] = 0.9 - 0.01 * k
+    e = engine(h, w, border_remove=0, nms_dist=2)
+    xy, conf, d, _ = e.get_points(torch.from_numpy(pm), torch.from_numpy(dm))[0]
+    assert len(conf) == len(pts)
+    od = oracle.get_descriptors(dm[0], xy[:, 0], xy[:, 1], h, w)
+    np.testing.assert_allclose(d, od, rtol=0, atol=2e-6)
+    e.close()
+
+
+def test_batch_equals_single_frames(torch_gpu):
+    """Frames of a batch are independent (the reference façade is batch-1: netutils.py:59-61)."""
+    h, w, n = 96, 128, 5
+    sd = synth.make_state_dict(31, dustbin_bias=5.0)
+    frames = synth.make_batch(40, n, h, w)
+    eb = engine(h, w, n)
+    eb.load_state_dict(sd)
+    batch = eb.detect(frames)
+    pb, db, lb = eb.forward(frames)
+    e1 = engine(h, w, 1)
+    e1.load_state_dict(sd)
+    for i in range(n):
+        xy, conf, d, nc = e1.detect(frames[i:i + 1])[0]
+        bxy, bconf, bd, bnc = batch[i]
+        assert nc == bnc
+        np.testing.assert_array_equal(xy, bxy)
+        np.testing.assert_array_equal(conf, bconf)
+        np.testing.assert_array_equal(d, bd)
+        p1, d1, l1 = e1.forward(frames[i:i + 1])
+        np.testing.assert_array_equal(l1[0].cpu().numpy(), lb[i].cpu().numpy())
+    # repeated calls are deterministic
+    again = eb.detect(frames)
+    for a, b in zip(batch, again):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[2], b[2])
+    eb.close()
+    e1.close()
+
+
+def test_full_size_batch_properties(torch_gpu):
+    """BASELINE.json configs[1] at full size (32 x 640x480) through size-independent properties:
+    every frame's post-processing is exact against the oracle run on the HIP dense maps, keypoints
+    respect the NMS radius and the border, confidences descend, descriptors have unit norm."""
+    h, w, n = 480, 640, 32
+    sd = synth.make_state_dict(0, dustbin_bias=7.0)
+    frames = synth.make_batch(100, n, h, w)
+    e = engine(h, w, n)
+    e.load_state_dict(sd)
+    prob, desc, _ = e.forward(frames)
+    res = e.detect(frames)
+    oracle = oracle_mod()
+    for i in (0, 13, 31):
+        _check_frame_against_oracle_postproc(oracle, prob[i].cpu().numpy(), desc[i].cpu().numpy(), res[i], h, w)
+    o_prob, o_desc, o_logits = oracle.forward(frames[7:8], sd, SPEC)
+    assert np.max(np.abs(prob[7].cpu().numpy() - o_prob[0])) < ATOL
+    assert np.max(np.abs(desc[7].cpu().numpy() - o_desc[0])) < ATOL
+    for xy, conf, d, ncand in res:
+        assert len(conf) > 100 and ncand >= len(conf)
+        assert np.all(np.diff(conf) <= 0)
+        assert xy[:, 0].min() >= 4 and xy[:, 0].max() < w - 4 and xy[:, 1].min() >= 4 and xy[:, 1].max() < h - 4
+        grid = np.zeros((h, w), bool)
+        grid[xy[:, 1], xy[:, 0]] = True
+        # no two keypoints within infinity-distance 4: every 5x5-aligned window sum of a dilated grid
+        ys, xs = xy[:, 1], xy[:, 0]
+        for dy in range(-4, 5):
+            for dx in range(-4, 5):
+                if dy == 0 and dx == 0:
+                    continue
+                yy, xx = ys + dy, xs + dx
+                ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+                assert not grid[yy[ok], xx[ok]].any()
+        np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
+    e.close()
+
+
+def test_reference_style_wrapper(torch_gpu, tmp_path):
+    """InferenceWrapper(weights_path, settings).run(img) with a checkpoint FILE in the
+    reference's layout (saveutils.py:57-62) -> (points [3,K] float64, descriptors [D,K])."""
+    torch = torch_gpu
+    from fpc_amd.inference import InferenceWrapper, SuperPointSettings
+    sd = synth.make_state_dict(21, dustbin_bias=7.0)
+    f = str(tmp_path / "super_point_0.pt")
+    torch.save({"epoch": 0, "model_state_dict": {k: torch.from_numpy(v.copy()) for k, v in sd.items()},
+                "optimizer_state_dict": {}, "scaler_state_dict": {}}, f)
+    wrap = InferenceWrapper(f, SuperPointSettings())
+    img = synth.make_frame(300, 240, 320)
+    points, desc = wrap.run(img)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f5_e2e_qvga.npz"))
+    assert points.dtype == np.float64 and points.shape == (3, len(g["points_x"]))
+    assert desc.shape == (128, points.shape[1]) and desc.dtype == np.float32
+    np.testing.assert_array_equal(np.sort(points[1].astype(np.int64) * 320 + points[0].astype(np.int64)),
+                                  np.sort(g["points_y"].astype(np.int64) * 320 + g["points_x"]))
+    with pytest.raises(FileNotFoundError):
+        InferenceWrapper(str(tmp_path / "missing.pt"), SuperPointSettings())
+
+
+def test_error_codes(torch_gpu):
+    from fpc_amd import _lib
+    from fpc_amd.engine import Engine
+    with pytest.raises(_lib.FpcError) as ei:
+        Engine(100, 128)                      # not a multiple of 16
+    assert ei.value.code == -1
+    e = Engine(32, 48)
+    with pytest.raises(_lib.FpcError) as ei:  # forward before weights
+        e.forward(np.zeros((1, 3, 32, 48), np.float32))
+    assert ei.value.code == -4
+    sd = synth.make_state_dict(1)
+    del sd["encoder.layer1.0.bn1.running_var"]
+    with pytest.raises(_lib.FpcError) as ei:  # strict load (saveutils.py:10-14)
+        e.load_state_dict(sd)
+    assert ei.value.code == -5 and "encoder.layer1.0.bn1.running_var" in str(ei.value)
+    sd = synth.make_state_dict(1)
+    sd["detector.layer.0.conv1.weight"] = sd["detector.layer.0.conv1.weight"][:64]
+    with pytest.raises(_lib.FpcError):
+        e.load_state_dict(sd)
+    e.close()
