@@ -29,6 +29,9 @@ from fpc_amd.engine import Engine  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (dense, f32 in / f32 acc)
 BATCH = 32
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/): filled in
+# once measured; null until then.
+TRAFFIC_BYTES_PER_LAUNCH = 222623728   # profiles/r01_pmc_summary.csv, (2*FETCH_SIZE + WRITE_SIZE) KiB, mean of its 4 launches/step
 H, W = 480, 640
 
 
@@ -85,7 +88,7 @@ def main():
 
     use_events = not args.no_timing_events
     eng.set_timing(use_events)
-    per_kernel = {}
+    per_kernel, per_symbol = {}, {}
     fdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -100,8 +103,10 @@ def main():
     fdist.barrier()
     dt = time.perf_counter() - t0
     if use_events:
-        for name, ms, fl in eng.timings():   # the LAST step's events (every step records the same launches)
+        # every launch of the timed region: layer name -> [(ms, flops)], kernel symbol -> [(ms, flops)]
+        for name, kern, ms, fl in eng.timings():
             per_kernel.setdefault(name, []).append((ms, fl * BATCH))
+            per_symbol.setdefault(kern, []).append((ms, fl * BATCH))
     eng.set_timing(False)
     dt = fdist.max_over_ranks(dt)
     total_frames = BATCH * args.steps * world
@@ -126,20 +131,23 @@ def main():
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
         }
         if per_kernel:
-            # dominant kernel = the launch with the largest share of the step
-            name, lst = max(per_kernel.items(), key=lambda kv: sum(m for m, _ in kv[1]))
+            # dominant kernel = the kernel SYMBOL (as rocprofv3 aggregates) with the largest share
+            # of the step; achieved = its algorithmic FLOPs per launch / its average launch duration
+            sym, lst = max(per_symbol.items(), key=lambda kv: sum(m for m, _ in kv[1]))
             ms = float(np.mean([m for m, _ in lst]))
-            fl = lst[0][1]
+            fl = float(np.mean([f for _, f in lst]))
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3),
+            out["roofline"] = {"bound": "mfma", "kernel": sym, "achieved": round(ach, 3),
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                               "avg_launch_ms": round(ms, 4), "flops_per_launch": fl}
-            conv_ms = sum(np.mean([m for m, _ in v]) for k, v in per_kernel.items() if v[0][1] > 0)
-            all_ms = sum(np.mean([m for m, _ in v]) for v in per_kernel.values())
-            out["kernel_ms"] = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in per_kernel.items()}
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                               "avg_launch_ms": round(ms, 4), "flops_per_launch": fl,
+                               "launches_per_step": len(lst) // args.steps,
+                               "share_of_step": round(sum(m for m, _ in lst) / args.steps / (dt / args.steps * 1e3), 3)}
+            mean_ms = {k: float(np.mean([m for m, _ in v])) for k, v in per_kernel.items()}
+            conv_ms = sum(mean_ms[k] for k, v in per_kernel.items() if v[0][1] > 0)
+            out["layer_ms"] = {k: round(v, 4) for k, v in mean_ms.items()}
             out["conv_kernels_tflops"] = round(BATCH * flops_frame / (conv_ms * 1e-3) / 1e12, 3)
-            out["sum_kernel_ms"] = round(float(all_ms), 4)
+            out["sum_kernel_ms"] = round(float(sum(mean_ms.values())), 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, frames_np[:8])
         print(json.dumps(out))

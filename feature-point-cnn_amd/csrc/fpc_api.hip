@@ -56,6 +56,7 @@ enum Kind {
 
 struct KindInfo {
   const char* name;
+  const char* symbol;   // as rocprofv3 prints it
   int TH, TW, S, EXT, KC, WM, WN, MB, NB;
   int lds_bytes, threads;
   const void* fn;
@@ -73,7 +74,7 @@ FPC_KINDS(X)
 
 static const KindInfo g_kinds[K_COUNT] = {
 #define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB)                                                    \
-  {#name, TH, TW, S, EXT, KC, WM, WN, MB, NB, ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>::LDS_BYTES,   \
+  {#name, "conv_mfma_kernel<" #TH ", " #TW ", " #S ", " #EXT ", " #KC ", " #WM ", " #WN ", " #MB ", " #NB ">", TH, TW, S, EXT, KC, WM, WN, MB, NB, ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>::LDS_BYTES,   \
    WM * WN * 64, (const void*)conv_mfma_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB>, launch_##name},
     FPC_KINDS(X)
 #undef X
@@ -590,8 +591,6 @@ struct LaunchTimer {
 static int run_network(fpc_ctx* c, const float* frames, int n, bool want_desc) {
   if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
-  c->timings.clear();
-  c->events_used = 0;
   const int H = c->H, W = c->W;
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
@@ -876,8 +875,6 @@ int fpc_detect(fpc_ctx* c, const float* frames, int n) {
 int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n) {
   if (!c || !prob || n < 1 || n > c->B) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
-  c->timings.clear();
-  c->events_used = 0;
   const int HW = c->H * c->W;
   HIPCHECK(hipMemsetAsync(c->ncand, 0, sizeof(int32_t) * c->B, c->stream));
   const int per = (HW + 255) / 256;
@@ -939,19 +936,34 @@ int fpc_get_keypoints(fpc_ctx* c, int frame, int cap, int32_t* xy, float* conf, 
 int fpc_set_timing(fpc_ctx* c, int enable) {
   if (!c) return FPC_E_INVALID;
   c->timing = enable != 0;
+  c->timings.clear();   // records accumulate over calls from here on
+  c->events_used = 0;
   return FPC_OK;
 }
 
-int fpc_get_timings(fpc_ctx* c, int cap, const char** names, float* ms, double* flops) {
+int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernels, float* ms, double* flops) {
   if (!c) return FPC_E_INVALID;
   const int n = (int)c->timings.size();
   for (int i = 0; i < n && i < cap; ++i) {
     const Timing& t = c->timings[i];
     float v = 0.f;
     if (hipEventElapsedTime(&v, t.start, t.stop) != hipSuccess) v = -1.f;
-    if (names) names[i] = t.op >= 0 ? c->ops[t.op].name.c_str() : "?";
+    const Op* op = t.op >= 0 ? &c->ops[t.op] : nullptr;
+    if (names) names[i] = op ? op->name.c_str() : "?";
+    if (kernels) {
+      const char* k = "?";
+      if (op) switch (op->type) {
+          case OP_STEM: k = "stem_kernel"; break;
+          case OP_POOL: k = "maxpool_kernel"; break;
+          case OP_CONV: k = g_kinds[op->kind].symbol; break;
+          case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
+          case OP_NMS: k = "nms_rounds_kernel+nms_sort_kernel"; break;
+          case OP_DESC: k = "descriptor_kernel"; break;
+        }
+      kernels[i] = k;
+    }
     if (ms) ms[i] = v;
-    if (flops) flops[i] = t.op >= 0 ? c->ops[t.op].flops_per_frame : 0.0;
+    if (flops) flops[i] = op ? op->flops_per_frame : 0.0;
   }
   return n;
 }

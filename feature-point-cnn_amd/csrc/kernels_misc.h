@@ -342,36 +342,13 @@ __global__ __launch_bounds__(1024) void nms_rounds_kernel(const NmsArgs a) {
 }
 
 // Survivors inside the border -> sort -> outputs.  One workgroup per frame.
-__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
-  extern __shared__ unsigned long long keys_lds[];
-  __shared__ int s_count, s_total;
+// 64-bit keys (conf bits, ~index): a descending sort of unique keys gives
+// (confidence desc, index asc) -- netutils.py:92-99.
+template <typename KeyPtr>
+__device__ __forceinline__ void nms_sort_body(const NmsArgs& a, KeyPtr keys, int P, int K, int n, const uint32_t* map,
+                                              const uint32_t* cand, int* s_count) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int H = a.H, W = a.W;
-  const uint32_t* map = a.nmsmap + (size_t)b * H * W;
-  const uint32_t* cand = a.cand + (size_t)b * H * W;
-  const int n = a.ncand[b];
-  if (tid == 0) {
-    s_count = 0;
-    s_total = 0;
-  }
-  __syncthreads();
-  // 64-bit keys (conf bits, ~index): a descending sort of unique keys gives
-  // (confidence desc, index asc) -- netutils.py:92-99.  Count first so that the
-  // LDS / scratch choice is uniform over the workgroup.
-  const int bw = a.border;
-  int mine = 0;
-  for (int i = tid; i < n; i += 1024) {
-    const uint32_t ci = cand[i] & 0x7fffffffu;
-    const int y = ci / W, x = ci - y * W;
-    mine += (map[ci] & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
-  }
-  if (mine) atomicAdd(&s_total, mine);
-  __syncthreads();
-  const int K = s_total;
-  int P = 1;
-  while (P < K) P <<= 1;
-  unsigned long long* keys = keys_lds;
-  if (P > NMS_LDS_KEYS) keys = a.sort_scratch + (size_t)b * a.sort_cap;
+  const int H = a.H, W = a.W, bw = a.border;
   for (int i = tid; i < P; i += 1024) keys[i] = 0ull;
   __syncthreads();
   for (int i = tid; i < n; i += 1024) {
@@ -379,22 +356,20 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
     const int y = ci / W, x = ci - y * W;
     const uint32_t u = map[ci];
     if ((u & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw) {
-      const int pos = atomicAdd(&s_count, 1);
+      const int pos = atomicAdd(s_count, 1);
       keys[pos] = ((unsigned long long)(u & 0x7fffffffu) << 32) | (0xffffffffu - ci);
     }
   }
   __syncthreads();
-  for (int k = 2; k <= P; k <<= 1)  // bitonic sort, descending
+  for (int k = 2; k <= P; k <<= 1)  // bitonic sort, descending; one thread per compare-exchange
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < P; i += 1024) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned long long ki = keys[i], kl = keys[l];
-          const bool desc = (i & k) == 0;
-          if (desc ? ki < kl : ki > kl) {
-            keys[i] = kl;
-            keys[l] = ki;
-          }
+      for (int t = tid; t < (P >> 1); t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const unsigned long long ki = keys[i], kl = keys[l];
+        const bool desc = (i & k) == 0;
+        if (desc ? ki < kl : ki > kl) {
+          keys[i] = kl;
+          keys[l] = ki;
         }
       }
       __syncthreads();
@@ -408,6 +383,38 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
     a.xy[((size_t)b * a.cap + i) * 2 + 1] = y;
     a.conf[(size_t)b * a.cap + i] = __uint_as_float((uint32_t)(k >> 32));
   }
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
+  extern __shared__ unsigned long long keys_lds[];
+  __shared__ int s_count, s_total;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int H = a.H, W = a.W;
+  const uint32_t* map = a.nmsmap + (size_t)b * H * W;
+  const uint32_t* cand = a.cand + (size_t)b * H * W;
+  const int n = a.ncand[b];
+  if (tid == 0) {
+    s_count = 0;
+    s_total = 0;
+  }
+  __syncthreads();
+  // count first so that the LDS / scratch choice is uniform over the workgroup
+  const int bw = a.border;
+  int mine = 0;
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t ci = cand[i] & 0x7fffffffu;
+    const int y = ci / W, x = ci - y * W;
+    mine += (map[ci] & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
+  }
+  if (mine) atomicAdd(&s_total, mine);
+  __syncthreads();
+  const int K = s_total;
+  int P = 1;
+  while (P < K) P <<= 1;
+  if (P <= NMS_LDS_KEYS)
+    nms_sort_body(a, keys_lds, P, K, n, map, cand, &s_count);
+  else  // more survivors than LDS holds (large frames): same code on a global scratch buffer
+    nms_sort_body(a, a.sort_scratch + (size_t)b * a.sort_cap, P, K, n, map, cand, &s_count);
 }
 
 // ---------------------------------------------------------------------------------

@@ -189,12 +189,14 @@ class Engine:
         _lib.check(self._l.fpc_set_timing(self._ctx, int(bool(on))), "fpc_set_timing")
 
     def timings(self):
-        cap = 128
+        """[(layer name, kernel symbol, ms, algorithmic FLOPs per frame)] of the last call's launches."""
+        cap = max(128, _lib.check(self._l.fpc_get_timings(self._ctx, 0, None, None, None, None), "fpc_get_timings"))
         names = (ctypes.c_char_p * cap)()
+        kernels = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_float * cap)()
         fl = (ctypes.c_double * cap)()
-        n = _lib.check(self._l.fpc_get_timings(self._ctx, cap, names, ms, fl), "fpc_get_timings")
-        return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(min(n, cap))]
+        n = _lib.check(self._l.fpc_get_timings(self._ctx, cap, names, kernels, ms, fl), "fpc_get_timings")
+        return [(names[i].decode(), kernels[i].decode(), float(ms[i]), float(fl[i])) for i in range(min(n, cap))]
 
 
 class _DevArray:

@@ -141,12 +141,15 @@ int fpc_get_counts(fpc_ctx* ctx, int n, int32_t* count_host, int32_t* n_candidat
 int fpc_get_keypoints(fpc_ctx* ctx, int frame, int cap, int32_t* xy, float* conf, float* desc);
 
 /* Optional per-launch timing for the bench: with `enable`, every kernel launch of
- * fpc_detect / fpc_forward is bracketed by HIP events on the launch stream. */
+ * fpc_detect / fpc_forward is bracketed by HIP events on the launch stream; records
+ * accumulate over calls until the next fpc_set_timing. */
 int fpc_set_timing(fpc_ctx* ctx, int enable);
-/* After fpc_sync: number of launches recorded by the last call; names[i] points
- * into ctx-owned storage; ms[i] is the event-to-event duration; flops[i] the
- * algorithmic FLOPs of that launch (0 for non-conv kernels). */
-int fpc_get_timings(fpc_ctx* ctx, int cap, const char** names, float* ms, double* flops);
+/* After fpc_sync: number of launches recorded since fpc_set_timing; names[i] (layer) and
+ * kernels[i] (kernel symbol, as rocprofv3 prints it) point into ctx-owned storage;
+ * ms[i] is the event-to-event duration; flops[i] the algorithmic FLOPs PER FRAME of
+ * that launch (0 for non-conv kernels). */
+int fpc_get_timings(fpc_ctx* ctx, int cap, const char** names, const char** kernels, float* ms,
+                    double* flops);
 
 #ifdef __cplusplus
 }

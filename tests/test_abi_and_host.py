@@ -1,0 +1,132 @@
+"""CPU-only checks of the boundary and the host logic: the C-ABI library loads and exports
+every symbol include/fpc.h declares, fails loudly without a GPU, and the product never
+touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fpc_amd  # noqa: F401
+from fpc_amd import _lib, arch, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "fpc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpc_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_functions()
+    assert declared, "no declarations parsed from include/fpc.h"
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fpc_abi_version() == 1
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (fpc_[a-z_0-9]+)", out))
+    assert set(declared) <= exported
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"conv_mfma_kernel" in blob and b"nms_rounds_kernel" in blob
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_lib.FpcConfig) == 17 * 4
+    assert ctypes.sizeof(_lib.FpcTensor) == 8 + 8 + 8 + 32
+    cfg = _lib.FpcConfig()
+    assert _lib.load().fpc_default_config(ctypes.byref(cfg)) == 0
+    # python/src/settings.py:2-8
+    assert (cfg.nms_dist, cfg.cell, cfg.border_remove) == (4, 8, 4)
+    assert abs(cfg.conf_thresh - 0.015) < 1e-9 and cfg.descriptor_enabled == 1
+    assert (cfg.height, cfg.width, cfg.max_batch) == (480, 640, 1)
+
+
+def test_error_strings_and_argument_checks():
+    lib = _lib.load()
+    assert b"no CPU fallback" in lib.fpc_strerror(-2)
+    assert lib.fpc_default_config(None) == -1
+    cfg = _lib.FpcConfig()
+    lib.fpc_default_config(ctypes.byref(cfg))
+    ctx = ctypes.c_void_p()
+    cfg.height = 100                       # not a multiple of 16
+    assert lib.fpc_create(ctypes.byref(ctx), ctypes.byref(cfg)) == -1
+    assert lib.fpc_create(None, ctypes.byref(cfg)) == -1
+    assert lib.fpc_sync(None) == -1 and lib.fpc_packed_size(None) == 0
+    lib.fpc_destroy(None)                  # no-op
+
+
+def test_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _lib.load()
+    cfg = _lib.FpcConfig()
+    lib.fpc_default_config(ctypes.byref(cfg))
+    ctx = ctypes.c_void_p()
+    assert lib.fpc_create(ctypes.byref(ctx), ctypes.byref(cfg)) == -2      # FPC_E_NO_DEVICE
+    from fpc_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Engine(480, 640)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "feature-point-cnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp", ".c")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "fpc_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+    code = ("import sys; sys.path.insert(0, %r); import fpc_amd; from fpc_amd import engine, inference, dist, _lib; "
+            "_lib.load(); assert not [m for m in sys.modules if m.startswith('oracle')]; "
+            "assert 'libfpc_oracle' not in open('/proc/self/maps').read()" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])
+    out = subprocess.check_output(["ldd", _lib.LIB_PATH]).decode()
+    assert "oracle" not in out
+
+
+def test_synthetic_checkpoint_matches_table_w():
+    sd = synth.make_state_dict(0)
+    spec = arch.state_dict_spec()
+    assert list(sd.keys()) == list(spec.keys())
+    for k, shp in spec.items():
+        assert sd[k].shape == tuple(shp), k
+    # deterministic, and BatchNorm statistics are non-trivial
+    sd2 = synth.make_state_dict(0)
+    assert all(np.array_equal(sd[k], sd2[k]) for k in sd)
+    assert np.std(sd["encoder.bn1.running_mean"]) > 0.01 and np.std(sd["encoder.bn1.running_var"]) > 0.01
+
+
+def test_synthetic_frames_are_deterministic():
+    a, b = synth.make_frame(5, 64, 96), synth.make_frame(5, 64, 96)
+    assert a.dtype == np.float32 and a.shape == (64, 96, 3) and np.array_equal(a, b)
+    assert 0.0 <= a.min() and a.max() <= 1.0
+    g = synth.make_frame(5, 64, 96, gray=True)
+    assert np.array_equal(g[..., 0], g[..., 1]) and np.array_equal(g[..., 1], g[..., 2])
+    assert synth.make_batch(1, 2, 32, 48).shape == (2, 3, 32, 48)
+
+
+def test_checkpoint_file_round_trip(tmp_path):
+    """The reference's file layout (saveutils.py:57-62) through the host-side loader."""
+    import torch
+    from fpc_amd.inference import load_checkpoint_for_inference
+    sd = synth.make_state_dict(2)
+    f = str(tmp_path / "super_point_3.pt")
+    torch.save({"epoch": 3, "model_state_dict": {k: torch.from_numpy(v.copy()) for k, v in sd.items()},
+                "optimizer_state_dict": {}, "scaler_state_dict": {}}, f)
+    got = load_checkpoint_for_inference(f)
+    assert list(got.keys()) == list(sd.keys())
+    assert all(np.array_equal(got[k].numpy(), sd[k]) for k in sd)
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint_for_inference(str(tmp_path / "nope.pt"))

@@ -1,0 +1,98 @@
+"""The N>1 path on CPU: world_size 2 over gloo.  Covers what bench.py does between ranks --
+rendezvous from the environment, contiguous frame shards, the start-up broadcast of the packed
+weight blob from rank 0, MAX-over-ranks timing -- with a stand-in for the GPU engine (the
+collective logic is backend-independent; nccl == RCCL replaces gloo on the GPU box)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+import fpc_amd  # noqa: F401
+from fpc_amd import dist as fdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeEngine:
+    """Holds a 'packed blob' exactly like Engine does, minus the GPU."""
+
+    def __init__(self, n=4099):
+        self.blob = np.zeros(n, np.uint8)
+        self.loaded = False
+
+    def load_state_dict(self, sd):
+        self.blob[:] = np.frombuffer(sd["blob"], np.uint8)
+        self.loaded = True
+
+    def packed_size(self):
+        return self.blob.size
+
+    def export_packed(self):
+        return self.blob.copy()
+
+    def import_packed(self, buf):
+        self.blob[:] = buf
+        self.loaded = True
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = fdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    eng = FakeEngine()
+    payload = np.random.Generator(np.random.PCG64(7)).integers(0, 256, eng.packed_size(), dtype=np.uint8)
+    sd = {"blob": payload.tobytes()} if rank == 0 else None
+    fdist.broadcast_packed_weights(eng, sd)
+    ok = eng.loaded and np.array_equal(eng.blob, payload)
+    lo, hi = fdist.shard_range(37, world, rank)
+    tmax = fdist.max_over_ranks(1.0 + rank)
+    tsum = fdist.sum_over_ranks(hi - lo)
+    fdist.barrier()
+    q.put((rank, ok, lo, hi, tmax, tsum))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "rank did not receive rank 0's blob"
+    assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 19, 19, 37)
+    assert res[0][4] == 2.0 and res[1][4] == 2.0        # MAX over ranks
+    assert res[0][5] == 37.0
+
+
+def test_shard_ranges_cover_every_frame_once():
+    for n in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [fdist.shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert fdist.shard_range(256, 8, 3) == (96, 128)    # configs[2]: 32 frames per GPU
+
+
+def test_single_process_needs_no_group():
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert fdist.init_from_env() == (0, 1, 0)
+    assert fdist.max_over_ranks(3.5) == 3.5
+    eng = FakeEngine()
+    fdist.broadcast_packed_weights(eng, {"blob": bytes(eng.packed_size())})
+    assert eng.loaded
