@@ -308,3 +308,33 @@ def test_error_codes(torch_gpu):
     with pytest.raises(_lib.FpcError):
         e.load_state_dict(sd)
     e.close()
+
+
+def test_cpp_entry_point(torch_gpu, tmp_path):
+    """superpoint::SuperPoint(file, false).ProcessFrame(gray) (feature-point-cnn_amd/cpp/superpoint.hpp,
+    mirroring cpp/src/superpoint.h:12-18) against the Python host on the same gray frame."""
+    import subprocess
+    torch = torch_gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "feature-point-cnn_amd", "lib", "fpc_demo")
+    assert os.path.exists(demo), "run __graft_entry__.build()"
+    h, w = 240, 320
+    sd = synth.make_state_dict(21, dustbin_bias=7.0)
+    ck = str(tmp_path / "super_point_0.pt")
+    torch.save({"epoch": 0, "model_state_dict": {k: torch.from_numpy(v.copy()) for k, v in sd.items()},
+                "optimizer_state_dict": {}, "scaler_state_dict": {}}, ck)
+    gray = synth.make_frame(300, h, w, gray=True)
+    gray[..., 0].tofile(str(tmp_path / "frame.f32"))
+    out = str(tmp_path / "pts.txt")
+    msg = subprocess.check_output([demo, ck, str(tmp_path / "frame.f32"), str(h), str(w), out]).decode()
+    got = np.loadtxt(out, ndmin=2)
+    e = engine(h, w)
+    e.load_state_dict(sd)
+    xy, conf, d, _ = e.detect(gray.transpose(2, 0, 1)[None])[0]
+    assert msg.startswith("%d feature points" % len(conf))
+    np.testing.assert_array_equal(got[:, 0].astype(np.int32), xy[:, 0])
+    np.testing.assert_array_equal(got[:, 1].astype(np.int32), xy[:, 1])
+    np.testing.assert_allclose(got[:, 2], conf, rtol=1e-6)
+    np.testing.assert_allclose(got[:, 3:6], d[:, 0:3], atol=1e-6)
+    np.testing.assert_allclose(got[:, 6], d[:, 127], atol=1e-6)
+    e.close()
