@@ -1,0 +1,280 @@
+// block_mfma.h -- one whole ResNetBlock (python/src/resnet_blocks.py:14-27) per launch:
+//
+//     h   = relu(bn1(conv3x3_s(x)))                    phase 1  (halo-tile conv, as conv_mfma.h)
+//     out = relu(bn2(conv1x1(h)) + shortcut(x))        phase 2  (GEMM over h, which never leaves LDS)
+//     shortcut(x) = bn(conv1x1_s(x))  (first block of a stage)  or  x  (second block)
+//
+// Phase 1 ends by writing relu(acc + b1) into LDS as the [pixel][channel] A operand of phase
+// 2 (the accumulator layout has the channel on the lane, the A operand wants the pixel on the
+// lane: the LDS round trip IS the transpose).  The projection shortcut is more K for the same
+// accumulators; its A operand (the centre pixels of x, strided for stride-2 blocks) is read
+// straight from global memory -- those lines were just streamed through L2 by phase 1.
+// Compared with separate launches this removes the HBM write + read of h, the re-read of x and
+// one launch (with its own tail) per block.
+//
+// A workgroup owns ALL output channels of its pixel tile (phase 2 needs every channel of h).
+#pragma once
+#include "conv_mfma.h"
+
+namespace fpc {
+
+struct BlockArgs {
+  const float* x;        // NHWC input, already offset to its first channel
+  int csx, nchunk;       // pixel stride (floats), Cin_pad / KC
+  int H, W;              // input size
+  const float4* w1;      // packed 3x3 fragments (steps = nchunk*9*KC/8, nbt blocks)
+  const float* b1;       // [nbt*32]
+  int tapoff4[9];
+  const float4* w2;      // packed 1x1 fragments: k8_h steps over h, then k8_x steps over x
+  const float* b2;       // bn2 bias (+ shortcut bn bias)
+  int k8_h, k8_x;        // k8_x == 0: identity shortcut
+  float* out;
+  int cso, Ho, Wo, tiles_x, tiles_y, nstore, frame0;
+};
+
+template <int TH, int TW, int S, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+struct BlockCfg {
+  using C1 = ConvCfg<TH, TW, S, 3, KC, WM, WN, MB, NB>;
+  static constexpr int ROWH4 = CMIDP / 4 + 1;
+  static constexpr int H_BYTES = C1::M * ROWH4 * 16;
+  static constexpr int LDS_BYTES = C1::LDS_BYTES > H_BYTES ? C1::LDS_BYTES : H_BYTES;
+  static_assert(CMIDP % 8 == 0 && CMIDP <= C1::N, "mid channels must fit the workgroup's N");
+};
+
+template <int TH, int TW, int S, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs a) {
+  using C = ConvCfg<TH, TW, S, 3, KC, WM, WN, MB, NB>;
+  using BC = BlockCfg<TH, TW, S, KC, WM, WN, MB, NB, CMIDP>;
+  constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW4 = C::ROW4, K8 = KC / 8, KC4 = KC / 4;
+  constexpr int NV = HH * HW * KC4, ITER = (NV + NT - 1) / NT, ROWH4 = BC::ROWH4, NBT = WN * NB;
+  extern __shared__ float4 lds4[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bl = blockIdx.x / tiles;
+  const int b = a.frame0 + bl;
+  const int t = blockIdx.x - bl * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+
+  int abase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int m = (wm * MB + mb) * 32 + l31;
+    m = m < TH * TW ? m : TH * TW - 1;
+    const int py = m / TW, px = m - py * TW;
+    abase[mb] = ((py * S) * HW + px * S) * ROW4 + half;
+  }
+  constexpr int stepstride = NBT * 64;
+  const float4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
+
+  const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+  float4 stage[ITER];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC4, c4 = e - pix * KC4;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c4 * 4 : 0;
+      float4 v = *reinterpret_cast<const float4*>(a.x + off);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      stage[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC4, c4 = e - pix * KC4;
+      if (NV % NT == 0 || e < NV) lds4[pix * ROW4 + c4] = stage[i];
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  // ---------------------------------------------------------------- phase 1: 3x3 conv
+  load_chunk(0);
+  float4 b0[NB], b1[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b0[nb] = wp[nb * 64];
+  wp += stepstride;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
+  wp += stepstride;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    if (chunk) __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = a.tapoff4[tap];
+#pragma unroll
+      for (int k8 = 0; k8 < K8; ++k8) {
+        float4 b2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = wp[nb * 64];
+        wp += stepstride;
+        __builtin_amdgcn_sched_barrier(0);
+        float4 av[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[abase[mb] + toff + k8 * 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
+              const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
+            }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          b0[nb] = b1[nb];
+          b1[nb] = b2[nb];
+        }
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- h = relu(acc + b1) -> LDS
+  // start streaming phase 2's weights while the tile is being turned around
+  const float4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b0[nb] = wq[nb * 64];
+  wq += stepstride;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b1[nb] = wq[nb * 64];
+  wq += stepstride;
+  __syncthreads();  // every wave is done reading the halo: its LDS becomes the h tile
+  {
+    float* hl = reinterpret_cast<float*>(lds4);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 32 + l31;
+      const float bias = a.b1[n];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = acc[mb][nb][r] + bias;
+          if (n < CMIDP) hl[m * (ROWH4 * 4) + n] = v > 0.f ? v : 0.f;
+          acc[mb][nb][r] = 0.f;
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase 2a: K over h (LDS)
+  int hbase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH4 + half;
+  for (int k8 = 0; k8 < a.k8_h; ++k8) {
+    float4 b2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
+    wq += stepstride;
+    __builtin_amdgcn_sched_barrier(0);
+    float4 av[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[hbase[mb] + k8 * 2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
+          const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
+        }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      b0[nb] = b1[nb];
+      b1[nb] = b2[nb];
+    }
+  }
+
+  // ---------------------------------------------------------------- phase 2b: K over x (projection)
+  // A operand straight from global: lane (pixel, half) reads 4 channels of its own pixel per step.
+  const float* xrow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int m = (wm * MB + mb) * 32 + l31;
+    m = m < TH * TW ? m : TH * TW - 1;
+    const int py = m / TW, px = m - py * TW;
+    int y = (ty * TH + py) * S, x = (tx * TW + px) * S;
+    y = y < a.H ? y : a.H - 1;  // rows of partial tiles: any valid address, results are not stored
+    x = x < a.W ? x : a.W - 1;
+    xrow[mb] = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 4;
+  }
+  if (a.k8_x > 0) {
+    float4 an[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const float4*>(xrow[mb]);
+    for (int k8 = 0; k8 < a.k8_x; ++k8) {
+      float4 b2[NB], av[MB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
+      wq += stepstride;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        av[mb] = an[mb];
+        const int kn = k8 + 1 < a.k8_x ? k8 + 1 : k8;
+        an[mb] = *reinterpret_cast<const float4*>(xrow[mb] + kn * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
+            const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
+          }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        b0[nb] = b1[nb];
+        b1[nb] = b2[nb];
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const int oyb = ty * TH, oxb = tx * TW;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = (wn * NB + nb) * 32 + l31;
+    const float bias = a.b2[n];
+    const bool nok = n < a.nstore;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int py = m / TW, px = m - py * TW;
+        const int y = oyb + py, x = oxb + px;
+        if (nok && m < TH * TW && y < a.Ho && x < a.Wo) {
+          const size_t opix = (size_t)(b * a.Ho + y) * a.Wo + x;
+          float v = acc[mb][nb][r] + bias;
+          if (a.k8_x == 0) v += a.x[opix * a.csx + n];  // identity shortcut (stride 1, same geometry)
+          a.out[opix * a.cso + n] = v > 0.f ? v : 0.f;
+        }
+      }
+  }
+}
+
+}  // namespace fpc

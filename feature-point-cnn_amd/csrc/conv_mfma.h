@@ -52,6 +52,7 @@ struct ConvArgs {
   int nstore;                  // output channels actually stored
   int relu;
   int nbt;                     // 32-wide N blocks in the packed weights
+  int frame0;                  // first frame of this launch (sub-batches run on separate streams)
   ConvSub sub[4];
 };
 
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(const ConvArgs a
   const int half = lane >> 5, l31 = lane & 31;
 
   const int tiles = a.tiles_x * a.tiles_y;
-  const int b = blockIdx.x / tiles;
-  const int t = blockIdx.x - b * tiles;
+  const int bl = blockIdx.x / tiles;
+  const int b = a.frame0 + bl;
+  const int t = blockIdx.x - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   const ConvSub& sp = a.sub[blockIdx.z];
 

@@ -9,12 +9,14 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/fpc.h"
+#include "block_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "weights.h"
@@ -80,16 +82,64 @@ static const KindInfo g_kinds[K_COUNT] = {
 #undef X
 };
 
+// Fused ResNetBlock instances.  BKIND(name, TH,TW, S, KC, WM,WN, MB,NB, CMIDP)
+#define FPC_BLOCK_KINDS(X)                                   \
+  X(B816_s1_K64_C64, 8, 16, 1, 64, 4, 1, 1, 2, 64)           \
+  X(B620_s2_K32_C128, 6, 20, 2, 32, 2, 2, 2, 2, 128)         \
+  X(B620_s1_K64_C128, 6, 20, 1, 64, 2, 2, 2, 2, 128)         \
+  X(B620_s1_K64_C72, 6, 20, 1, 64, 4, 1, 1, 3, 72)           \
+  X(B620_s1_K72_C72, 6, 20, 1, 72, 4, 1, 1, 3, 72)           \
+  X(B320_s2_K32_C256, 3, 20, 2, 32, 1, 4, 2, 2, 256)         \
+  X(B320_s1_K64_C256, 3, 20, 1, 64, 1, 4, 2, 2, 256)
+
+enum BKind {
+#define X(name, ...) BK_##name,
+  FPC_BLOCK_KINDS(X)
+#undef X
+      BK_COUNT
+};
+
+struct BKindInfo {
+  const char* name;
+  const char* symbol;
+  int TH, TW, S, KC, WM, WN, MB, NB, CMIDP;
+  int lds_bytes;
+  const void* fn;
+  void (*launch)(const BlockArgs&, dim3, hipStream_t);
+};
+
+#define X(name, TH, TW, S, KC, WM, WN, MB, NB, CMIDP)                                                     \
+  static void launchb_##name(const BlockArgs& a, dim3 grid, hipStream_t st) {                             \
+    using BC = BlockCfg<TH, TW, S, KC, WM, WN, MB, NB, CMIDP>;                                            \
+    hipLaunchKernelGGL((block_mfma_kernel<TH, TW, S, KC, WM, WN, MB, NB, CMIDP>), grid, dim3(WM* WN * 64), \
+                       BC::LDS_BYTES, st, a);                                                             \
+  }
+FPC_BLOCK_KINDS(X)
+#undef X
+
+static const BKindInfo g_bkinds[BK_COUNT] = {
+#define X(name, TH, TW, S, KC, WM, WN, MB, NB, CMIDP)                                                      \
+  {#name, "block_mfma_kernel<" #TH ", " #TW ", " #S ", " #KC ", " #WM ", " #WN ", " #MB ", " #NB ", " #CMIDP ">", \
+   TH, TW, S, KC, WM, WN, MB, NB, CMIDP, BlockCfg<TH, TW, S, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES,         \
+   (const void*)block_mfma_kernel<TH, TW, S, KC, WM, WN, MB, NB, CMIDP>, launchb_##name},
+    FPC_BLOCK_KINDS(X)
+#undef X
+};
+
 // ------------------------------------------------------------------------------------
 // Launch plan
 // ------------------------------------------------------------------------------------
-enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_SOFTMAX, OP_NMS, OP_DESC };
+enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_SOFTMAX, OP_NMS, OP_DESC };
 
 struct Op {
   OpType type;
   std::string name;
   Kind kind = K_COUNT;
   ConvArgs args{};
+  BKind bkind = BK_COUNT;
+  BlockArgs bargs{};
+  std::string prefix;          // checkpoint prefix of a fused block
+  int cin = 0, cout = 0;       // real channel counts of a fused block
   int grid_y = 1, grid_z = 1;
   double flops_per_frame = 0;  // algorithmic: 2 * MACs of the real (unpadded) convolution
   bool descriptor_branch = false;
@@ -110,6 +160,12 @@ struct fpc_ctx {
   int cap = 0, sort_cap = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  std::vector<hipStream_t> aux;      // extra streams for sub-batches
+  std::vector<hipEvent_t> ev_join;
+  hipEvent_t ev_fork = nullptr;
+  int min_sub = 4;                   // smallest sub-batch worth its own stream
+  int nms_passes = 2;
+  bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
 
   // one slab for all activations / results; carved below
@@ -132,7 +188,7 @@ struct fpc_ctx {
   StemArgs stem{};
   size_t stem_w_off = 0, stem_b_off = 0;
   struct ConvW {
-    size_t w_off[4] = {0, 0, 0, 0}, b_off = 0;
+    size_t w_off[4] = {0, 0, 0, 0}, b_off = 0, b2_off = 0;
   };
   std::vector<ConvW> convw;  // parallel to ops (unused entries for non-conv ops)
 
@@ -255,6 +311,59 @@ static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
   c->convw.push_back(cw);
 }
 
+struct BlockSpec {
+  std::string prefix;
+  BKind kind;
+  const float* x;
+  int csx, cin, cin_pad, H, W;
+  float* out;
+  int cso, cout, cout_pad;
+  bool proj, desc_branch;
+};
+
+static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
+  const BKindInfo& k = g_bkinds[s.kind];
+  Op op;
+  op.type = OP_BLOCK;
+  op.name = s.prefix + (s.proj ? " [conv1+bn1+relu+conv2+bn2+proj+relu]" : " [conv1+bn1+relu+conv2+bn2+identity+relu]");
+  op.prefix = s.prefix;
+  op.bkind = s.kind;
+  op.cin = s.cin;
+  op.cout = s.cout;
+  op.descriptor_branch = s.desc_branch;
+  BlockArgs& a = op.bargs;
+  const int nbt = k.WN * k.NB, K8 = k.KC / 8;
+  a.x = s.x;
+  a.csx = s.csx;
+  a.nchunk = s.cin_pad / k.KC;
+  a.H = s.H;
+  a.W = s.W;
+  const int HWp = (k.TW - 1) * k.S + 3, ROW4 = k.KC / 4 + 1;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) a.tapoff4[ky * 3 + kx] = (ky * HWp + kx) * ROW4;
+  a.k8_h = k.CMIDP / 8;
+  a.k8_x = s.proj ? s.cin_pad / 8 : 0;
+  a.out = s.out;
+  a.cso = s.cso;
+  a.Ho = s.H / k.S;
+  a.Wo = s.W / k.S;
+  a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
+  a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
+  a.nstore = s.cout_pad;
+  fpc_ctx::ConvW cw;
+  cw.w_off[0] = *blob_off;
+  *blob_off += ((size_t)a.nchunk * 9 * K8 + 2) * nbt * 64 * 4;
+  cw.b_off = *blob_off;
+  *blob_off += (size_t)nbt * 32;
+  cw.w_off[1] = *blob_off;
+  *blob_off += ((size_t)(a.k8_h + a.k8_x) + 2) * nbt * 64 * 4;
+  cw.b2_off = *blob_off;
+  *blob_off += (size_t)nbt * 32;
+  op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
+  c->ops.push_back(op);
+  c->convw.push_back(cw);
+}
+
 static int build_plan(fpc_ctx* c) {
   const int H = c->H, W = c->W, B = c->B;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
@@ -324,7 +433,11 @@ static int build_plan(fpc_ctx* c) {
   }
   auto block = [&](const std::string& p, Kind k3, Kind k1, int stride, const float* x, int csx, int cin, int cinp,
                    int Hx, int Wx, float* h, int csh, int cout, int coutp, float* y, int csy, bool proj,
-                   bool desc) {
+                   bool desc, BKind bk = BK_COUNT) {
+    if (c->fuse_blocks && bk != BK_COUNT) {
+      add_block(c, BlockSpec{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc}, &bo);
+      return;
+    }
     const int Ho = Hx / stride, Wo = Wx / stride;
     ConvSpec s{};
     s.name = p + ".conv1+bn1+relu";
@@ -348,14 +461,16 @@ static int build_plan(fpc_ctx* c) {
   };
   float* feat = c->cat + 128;  // encoder output lives in channels 128..255 of `cat`
   block("encoder.layer1.0", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x0, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
-        c->x1, 64, true, false);
+        c->x1, 64, true, false, BK_B816_s1_K64_C64);
   block("encoder.layer1.1", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x1, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
-        c->x2, 64, false, false);
+        c->x2, 64, false, false, BK_B816_s1_K64_C64);
   block("encoder.layer2.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, c->x2, 64, 64, 64, H4, W4, c->h8, 128,
-        128, 128, c->x3, 128, true, false);
+        128, 128, c->x3, 128, true, false, BK_B620_s2_K32_C128);
   block("encoder.layer2.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->x3, 128, 128, 128, Hc, Wc, c->h8, 128,
-        128, 128, feat, 256, false, false);
-  {  // detector.layer.0: the projection shortcut has K = 128 while conv2 has K = 72 (65 padded):
+        128, 128, feat, 256, false, false, BK_B620_s1_K64_C128);
+  if (c->fuse_blocks) {
+    add_block(c, BlockSpec{"detector.layer.0", BK_B620_s1_K64_C72, feat, 256, 128, 128, Hc, Wc, c->d0, 72, 65, 72, true, false}, &bo);
+  } else {  // detector.layer.0: the projection shortcut has K = 128 while conv2 has K = 72 (65 padded):
      // run the shortcut as its own 1x1 and add it as the residual of conv2
     ConvSpec s{};
     s.name = "detector.layer.0.conv1+bn1+relu";
@@ -378,7 +493,7 @@ static int build_plan(fpc_ctx* c) {
     add_conv(c, t, &bo);
   }
   block("detector.layer.1", K_T620_3x3_K72_N96, K_T620_1x1_K72_N96, 1, c->d0, 72, 65, 72, Hc, Wc, c->dh, 72, 65, 72,
-        c->lg, 72, false, false);
+        c->lg, 72, false, false, BK_B620_s1_K72_C72);
   {
     Op op;
     op.type = OP_SOFTMAX;
@@ -388,9 +503,9 @@ static int build_plan(fpc_ctx* c) {
   }
   if (de) {
     block("descriptor.layer_in.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, feat, 256, 128, 128, Hc, Wc, c->h16,
-          256, 256, 256, c->y16a, 256, true, true);
+          256, 256, 256, c->y16a, 256, true, true, BK_B320_s2_K32_C256);
     block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
-          c->h16, 256, 256, 256, c->y16b, 256, false, true);
+          c->h16, 256, 256, 256, c->y16b, 256, false, true, BK_B320_s1_K64_C256);
     ConvSpec u{};
     u.name = "descriptor.up_sample+bn+relu";
     u.kind = K_T620_2x2_K64_N128; u.ksize = 2; u.stride = 1;
@@ -399,9 +514,9 @@ static int build_plan(fpc_ctx* c) {
     u.desc_branch = true;
     add_conv(c, u, &bo);
     block("descriptor.layer_out.0", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->cat, 256, 256, 256, Hc, Wc,
-          c->lo_h, 128, 128, 128, c->lo0, 128, true, true);
+          c->lo_h, 128, 128, 128, c->lo0, 128, true, true, BK_B620_s1_K64_C128);
     block("descriptor.layer_out.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->lo0, 128, 128, 128, Hc, Wc,
-          c->lo_h, 128, 128, 128, c->desc_map, 128, false, true);
+          c->lo_h, 128, 128, 128, c->desc_map, 128, false, true, BK_B620_s1_K64_C128);
   }
   {
     Op op;
@@ -422,6 +537,12 @@ static int build_plan(fpc_ctx* c) {
   // resolve weight pointers
   for (size_t i = 0; i < c->ops.size(); ++i) {
     Op& op = c->ops[i];
+    if (op.type == OP_BLOCK) {
+      op.bargs.w1 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
+      op.bargs.b1 = c->blob + c->convw[i].b_off;
+      op.bargs.w2 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[1]);
+      op.bargs.b2 = c->blob + c->convw[i].b2_off;
+    }
     if (op.type != OP_CONV) continue;
     for (int z = 0; z < op.grid_z; ++z)
       op.args.sub[z].wfrag = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[z]);
@@ -464,6 +585,36 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
   }
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
+    if (op.type == OP_BLOCK) {
+      const BKindInfo& k = g_bkinds[op.bkind];
+      const BlockArgs& a = op.bargs;
+      const fpc_ctx::ConvW& cw = c->convw[i];
+      const std::string& p = op.prefix;
+      const int ci = op.cin, co = op.cout, nbt = k.WN * k.NB;
+      const float* w1 = need(p + ".conv1.weight", {co, ci, 3, 3});
+      const float* w2 = need(p + ".conv2.weight", {co, co, 1, 1});
+      Fold f1, f2, fp;
+      if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
+        return FPC_E_MISSING_KEY;
+      PackSource s1{ci, a.nchunk * k.KC, 9, [&](int n, int c_, int t) { return (double)w1[((size_t)(n * ci + c_)) * 9 + t]; }, &f1.s};
+      std::vector<float> frag = pack_conv({s1}, co, nbt, k.KC);
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
+      std::vector<PackSource> srcs;
+      srcs.push_back({co, a.k8_h * 8, 1, [&](int n, int c_, int) { return (double)w2[(size_t)n * co + c_]; }, &f2.s});
+      std::vector<double> bias(f2.t);
+      const float* wp = nullptr;
+      if (a.k8_x > 0) {
+        wp = need(p + ".identity_downsample.0.weight", {co, ci, 1, 1});
+        if (!wp || !fold_bn(m, p + ".identity_downsample.1", co, &fp, missing)) return FPC_E_MISSING_KEY;
+        srcs.push_back({ci, a.k8_x * 8, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
+        for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
+      }
+      frag = pack_conv(srcs, co, nbt, 8);
+      memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
+      continue;
+    }
     if (op.type != OP_CONV) continue;
     const KindInfo& k = g_kinds[op.kind];
     const ConvArgs& a = op.args;
@@ -560,6 +711,10 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
 }
 
 // ---- execution -------------------------------------------------------------------------------
+// A call's frames are split into sub-batches that run the whole launch sequence on separate
+// HIP streams: workgroups of one sub-batch fill the CUs another leaves idle in the tail of each
+// (short) launch, and the latency-bound NMS of one overlaps the MFMA-bound convolutions of the
+// other.  Frames are independent, so sub-batches share nothing but the weights.
 static hipEvent_t next_event(fpc_ctx* c) {
   if (c->events_used == c->event_pool.size()) {
     hipEvent_t e;
@@ -569,61 +724,30 @@ static hipEvent_t next_event(fpc_ctx* c) {
   return c->event_pool[c->events_used++];
 }
 
+struct Sub {
+  int f0, n;
+  hipStream_t st;
+};
+
 struct LaunchTimer {
   fpc_ctx* c;
   int op;
+  hipStream_t st;
   hipEvent_t s{}, e{};
-  LaunchTimer(fpc_ctx* c_, int op_) : c(c_), op(op_) {
+  LaunchTimer(fpc_ctx* c_, int op_, hipStream_t st_) : c(c_), op(op_), st(st_) {
     if (c->timing) {
       s = next_event(c);
       e = next_event(c);
-      hipEventRecord(s, c->stream);
+      hipEventRecord(s, st);
     }
   }
   ~LaunchTimer() {
     if (c->timing) {
-      hipEventRecord(e, c->stream);
+      hipEventRecord(e, st);
       c->timings.push_back({s, e, op});
     }
   }
 };
-
-static int run_network(fpc_ctx* c, const float* frames, int n, bool want_desc) {
-  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
-  if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
-  const int H = c->H, W = c->W;
-  for (size_t i = 0; i < c->ops.size(); ++i) {
-    const Op& op = c->ops[i];
-    if (op.descriptor_branch && !want_desc) continue;
-    switch (op.type) {
-      case OP_STEM: {
-        LaunchTimer t(c, (int)i);
-        StemArgs a = c->stem;
-        a.in = frames;
-        hipLaunchKernelGGL(stem_kernel, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, c->stream, a);
-        break;
-      }
-      case OP_POOL: {
-        LaunchTimer t(c, (int)i);
-        const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
-        hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
-                           reinterpret_cast<const float4*>(c->stem_out), reinterpret_cast<float4*>(c->x0), n, H / 2,
-                           W / 2, H / 4, W / 4);
-        break;
-      }
-      case OP_CONV: {
-        LaunchTimer t(c, (int)i);
-        const ConvArgs& a = op.args;
-        g_kinds[op.kind].launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), c->stream);
-        break;
-      }
-      default:
-        break;  // post-processing ops are issued by the callers
-    }
-  }
-  HIPCHECK(hipGetLastError());
-  return FPC_OK;
-}
 
 static int op_index(const fpc_ctx* c, OpType t) {
   for (size_t i = 0; i < c->ops.size(); ++i)
@@ -631,37 +755,112 @@ static int op_index(const fpc_ctx* c, OpType t) {
   return -1;
 }
 
-static int run_softmax(fpc_ctx* c, int n) {
-  HIPCHECK(hipMemsetAsync(c->ncand, 0, sizeof(int32_t) * c->B, c->stream));
-  LaunchTimer t(c, op_index(c, OP_SOFTMAX));
-  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(n * c->Hc), dim3(256), (size_t)16 * c->W * sizeof(float), c->stream,
-                     c->lg, 72, n, c->Hc, c->Wc, c->cfg.conf_thresh, c->prob, c->nmsmap, c->cand, c->ncand);
-  return FPC_OK;
+static void run_network(fpc_ctx* c, const float* frames, const Sub& sb, bool want_desc) {
+  const int H = c->H, W = c->W, n = sb.n, f0 = sb.f0;
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    const Op& op = c->ops[i];
+    if (op.descriptor_branch && !want_desc) continue;
+    switch (op.type) {
+      case OP_STEM: {
+        LaunchTimer t(c, (int)i, sb.st);
+        StemArgs a = c->stem;
+        a.in = frames + (size_t)f0 * 3 * H * W;
+        a.out = c->stem_out + (size_t)f0 * (H / 2) * (W / 2) * 64;
+        hipLaunchKernelGGL(stem_kernel, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
+        break;
+      }
+      case OP_POOL: {
+        LaunchTimer t(c, (int)i, sb.st);
+        const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
+        hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sb.st,
+                           reinterpret_cast<const float4*>(c->stem_out + (size_t)f0 * (H / 2) * (W / 2) * 64),
+                           reinterpret_cast<float4*>(c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64), n, H / 2, W / 2, H / 4,
+                           W / 4);
+        break;
+      }
+      case OP_BLOCK: {
+        LaunchTimer t(c, (int)i, sb.st);
+        BlockArgs a = op.bargs;
+        a.frame0 = f0;
+        g_bkinds[op.bkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
+        break;
+      }
+      case OP_CONV: {
+        LaunchTimer t(c, (int)i, sb.st);
+        ConvArgs a = op.args;
+        a.frame0 = f0;
+        g_kinds[op.kind].launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), sb.st);
+        break;
+      }
+      default:
+        break;  // post-processing ops are issued by the callers
+    }
+  }
 }
 
-static int run_nms(fpc_ctx* c, int n) {
-  LaunchTimer t(c, op_index(c, OP_NMS));
+static void run_softmax(fpc_ctx* c, const Sub& sb) {
+  const size_t HW = (size_t)c->H * c->W;
+  hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
+  LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st);
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)16 * c->W * sizeof(float), sb.st,
+                     c->lg + (size_t)sb.f0 * c->Hc * c->Wc * 72, 72, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
+                     c->prob + sb.f0 * HW, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
+}
+
+static void run_nms(fpc_ctx* c, const Sub& sb) {
+  LaunchTimer t(c, op_index(c, OP_NMS), sb.st);
+  const size_t HW = (size_t)c->H * c->W;
+  const int n = sb.n, f0 = sb.f0;
   NmsArgs a{};
-  a.nmsmap = c->nmsmap; a.cand = c->cand; a.ncand = c->ncand;
-  a.sort_scratch = c->sort_scratch; a.sort_cap = c->sort_cap;
+  a.nmsmap = c->nmsmap + f0 * HW; a.cand = c->cand + f0 * HW; a.ncand = c->ncand + f0;
+  a.sort_scratch = c->sort_scratch + (c->sort_cap > NMS_LDS_KEYS ? (size_t)f0 * c->sort_cap : 0);
+  a.sort_cap = c->sort_cap;
   a.H = c->H; a.W = c->W; a.r = c->cfg.nms_dist; a.border = c->cfg.border_remove; a.cap = c->cap;
-  a.count = c->count; a.xy = c->xy; a.conf = c->conf; a.status = c->status;
+  a.count = c->count + f0; a.xy = c->xy + (size_t)f0 * c->cap * 2; a.conf = c->conf + (size_t)f0 * c->cap;
+  a.status = c->status;
   a.max_rounds = c->H * c->W;
-  // enough workgroups that a typical frame (a few thousand candidates) has about one
-  // candidate per thread, while the whole grid stays co-resident (2 x 1024 threads per CU)
+  // enough workgroups that a typical frame (a few thousand candidates) has about one candidate
+  // per thread; a few launches back to back (each runs rounds while it makes progress), then the
+  // sort kernel finishes whatever is left
   const int G = std::max(1, std::min(16, 256 / n));
-  if (c->cfg.nms_dist == 4)
-    hipLaunchKernelGGL(nms_rounds_kernel<4>, dim3(G, n), dim3(1024), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL(nms_rounds_kernel<0>, dim3(G, n), dim3(1024), 0, c->stream, a);
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), NMS_LDS_KEYS * sizeof(unsigned long long), c->stream, a);
-  return FPC_OK;
+  for (int pass = 0; pass < c->nms_passes; ++pass) {
+    if (c->cfg.nms_dist == 4)
+      hipLaunchKernelGGL(nms_rounds_kernel<4>, dim3(G, n), dim3(1024), 0, sb.st, a);
+    else
+      hipLaunchKernelGGL(nms_rounds_kernel<0>, dim3(G, n), dim3(1024), 0, sb.st, a);
+  }
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), NMS_LDS_KEYS * sizeof(unsigned long long), sb.st, a);
 }
 
-static int run_desc(fpc_ctx* c, int n, const float* dmap_nhwc) {
-  LaunchTimer t(c, op_index(c, OP_DESC));
-  hipLaunchKernelGGL(descriptor_kernel, dim3((c->cap + 3) / 4, n), dim3(256), 0, c->stream, dmap_nhwc, 128, c->Hc,
-                     c->Wc, c->H, c->W, c->count, c->xy, c->cap, c->desc_out);
+static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
+  LaunchTimer t(c, op_index(c, OP_DESC), sb.st);
+  hipLaunchKernelGGL(descriptor_kernel, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
+                     dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
+                     c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128);
+}
+
+// Splits [0,n) over the ctx's streams; aux streams fork from / join into the main stream.
+template <typename F>
+static int for_each_sub(fpc_ctx* c, int n, F&& body) {
+  int parts = std::min<int>((int)c->aux.size() + 1, std::max(1, n / c->min_sub));
+  if (parts <= 1) {
+    body(Sub{0, n, c->stream});
+  } else {
+    HIPCHECK(hipEventRecord(c->ev_fork, c->stream));
+    int f0 = 0;
+    for (int p = 0; p < parts; ++p) {
+      const int cnt = n / parts + (p < n % parts ? 1 : 0);
+      hipStream_t st = p == 0 ? c->stream : c->aux[p - 1];
+      if (p) HIPCHECK(hipStreamWaitEvent(st, c->ev_fork, 0));
+      body(Sub{f0, cnt, st});
+      if (p) {
+        HIPCHECK(hipEventRecord(c->ev_join[p - 1], st));
+        HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_join[p - 1], 0));
+      }
+      f0 += cnt;
+    }
+  }
+  HIPCHECK(hipGetLastError());
   return FPC_OK;
 }
 
@@ -737,8 +936,25 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   while (c->sort_cap < worst) c->sort_cap <<= 1;
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
+  {
+    int nsub = 2;
+    if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
+    if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < nsub; ++i) {
+      hipStream_t st;
+      hipEvent_t ev;
+      HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      c->aux.push_back(st);
+      c->ev_join.push_back(ev);
+    }
+  }
   for (int k = 0; k < K_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
+  for (int k = 0; k < BK_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_bkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bkinds[k].lds_bytes));
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -759,6 +975,9 @@ void fpc_destroy(fpc_ctx* c) {
   hipSetDevice(c->cfg.device);
   hipDeviceSynchronize();
   for (auto e : c->event_pool) hipEventDestroy(e);
+  for (auto e : c->ev_join) hipEventDestroy(e);
+  for (auto st : c->aux) hipStreamDestroy(st);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->slab) hipFree(c->slab);
   if (c->blob) hipFree(c->blob);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -834,11 +1053,14 @@ int fpc_sync(fpc_ctx* c) {
 
 int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc, float* logits) {
   if (!c) return FPC_E_INVALID;
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
-  int rc = run_network(c, frames, n, de);
-  if (rc != FPC_OK) return rc;
-  rc = run_softmax(c, n);
+  int rc = for_each_sub(c, n, [&](const Sub& sb) {
+    run_network(c, frames, sb, de);
+    run_softmax(c, sb);
+  });
   if (rc != FPC_OK) return rc;
   const int HWc = c->Hc * c->Wc;
   if (prob) HIPCHECK(hipMemcpyAsync(prob, c->prob, (size_t)n * c->H * c->W * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -861,15 +1083,16 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
 
 int fpc_detect(fpc_ctx* c, const float* frames, int n) {
   if (!c) return FPC_E_INVALID;
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
-  int rc = run_network(c, frames, n, de);
-  if (rc != FPC_OK) return rc;
-  if ((rc = run_softmax(c, n)) != FPC_OK) return rc;
-  if ((rc = run_nms(c, n)) != FPC_OK) return rc;
-  if (de && (rc = run_desc(c, n, c->desc_map)) != FPC_OK) return rc;
-  HIPCHECK(hipGetLastError());
-  return FPC_OK;
+  return for_each_sub(c, n, [&](const Sub& sb) {
+    run_network(c, frames, sb, de);
+    run_softmax(c, sb);
+    run_nms(c, sb);
+    if (de) run_desc(c, sb, c->desc_map);
+  });
 }
 
 int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n) {
@@ -880,13 +1103,13 @@ int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n)
   const int per = (HW + 255) / 256;
   hipLaunchKernelGGL(threshold_kernel, dim3(per * n), dim3(256), 0, c->stream, prob, n, HW, c->cfg.conf_thresh,
                      c->nmsmap, c->cand, c->ncand);
-  int rc = run_nms(c, n);
-  if (rc != FPC_OK) return rc;
+  const Sub all{0, n, c->stream};
+  run_nms(c, all);
   if (desc_nchw && c->cfg.descriptor_enabled) {
     const size_t tot = (size_t)n * 128 * c->Hc * c->Wc;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, desc_nchw,
                        128, c->Hc * c->Wc, n, c->desc_in_nhwc);
-    if ((rc = run_desc(c, n, c->desc_in_nhwc)) != FPC_OK) return rc;
+    run_desc(c, all, c->desc_in_nhwc);
   }
   HIPCHECK(hipGetLastError());
   return FPC_OK;
@@ -956,6 +1179,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
           case OP_STEM: k = "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
+          case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;
           case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
           case OP_NMS: k = "nms_rounds_kernel+nms_sort_kernel"; break;
           case OP_DESC: k = "descriptor_kernel"; break;

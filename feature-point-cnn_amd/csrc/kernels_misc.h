@@ -243,7 +243,7 @@ struct NmsArgs {
   int32_t* count;          // [B]
   int32_t* xy;             // [B][cap][2]
   float* conf;             // [B][cap]
-  int32_t* status;         // [1] set to 1 if the round limit is hit
+  int32_t* status;         // [1] reserved (the round structure cannot fail to converge)
   int max_rounds;
 };
 
@@ -302,43 +302,52 @@ __device__ __forceinline__ void nms_scan(const uint32_t* map, int H, int W, int 
   *wait = w;
 }
 
+// One pass of rounds over the candidates [first, n) in steps of `stride` owned by this
+// workgroup.  Runs rounds while (a) something of ours is still undecided and (b) the last
+// round decided at least one of ours (`until_done` = false), or until everything is decided
+// (`until_done` = true, legal only when this workgroup owns ALL candidates of the frame).
 template <int R>
-__global__ __launch_bounds__(1024) void nms_rounds_kernel(const NmsArgs a) {
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int H = a.H, W = a.W;
-  uint32_t* map = a.nmsmap + (size_t)b * H * W;
-  uint32_t* cand = a.cand + (size_t)b * H * W;
-  const int n = a.ncand[b];
-  if (n <= 1) {  // nms.py:23-25: a single candidate is returned as is
-    if (n == 1 && blockIdx.x == 0 && tid == 0) st_relaxed(map + cand[0], map[cand[0]] | 0x80000000u);
-    return;
-  }
-  const int first = blockIdx.x * 1024 + tid, stride = gridDim.x * 1024;
-  if (blockIdx.x * 1024 >= n) return;
-  for (int round = 0;; ++round) {
-    int pending = 0;
+__device__ __forceinline__ void nms_run_rounds(uint32_t* map, uint32_t* cand, int n, int first, int stride, int H,
+                                               int W, int r, bool until_done) {
+  while (true) {
+    int pending = 0, progress = 0;
     for (int i = first; i < n; i += stride) {
       const uint32_t ci = cand[i];
-      if (ci & 0x80000000u) continue;  // decided in an earlier round (only this thread writes cand[i])
-      const uint32_t v = map[ci];      // own word: only this thread ever writes it
+      if (ci & 0x80000000u) continue;  // decided earlier (only the owning thread writes cand[i])
+      const uint32_t v = ld_relaxed(map + ci);
       bool kept_nb, wait;
-      nms_scan<R>(map, H, W, a.r, ci, v, &kept_nb, &wait);
+      nms_scan<R>(map, H, W, r, ci, v, &kept_nb, &wait);
       if (kept_nb) {
         st_relaxed(map + ci, 0u);
         cand[i] = ci | 0x80000000u;
+        progress = 1;
       } else if (!wait) {
         st_relaxed(map + ci, v | 0x80000000u);
         cand[i] = ci | 0x80000000u;
+        progress = 1;
       } else {
-        ++pending;
+        pending = 1;
       }
     }
-    if (!__syncthreads_or(pending)) break;
-    if (round >= a.max_rounds) {
-      if (tid == 0) *a.status = 1;
-      break;
-    }
+    const int f = __syncthreads_or(pending | (progress << 1));
+    if (!(f & 1)) break;                  // nothing of ours left
+    if (!until_done && !(f & 2)) break;   // stuck on another workgroup's candidates: let the launch end
   }
+}
+
+// Parallel rounds: grid = (G, B), the frame's candidates are dealt over G workgroups.  A
+// workgroup NEVER waits for another one: when a round decides nothing of its own it exits, and
+// whatever is still undecided is picked up by the next launch (the host issues a few of these
+// back to back) and finally by nms_sort_kernel, whose single workgroup per frame owns every
+// candidate and therefore always terminates.  No co-residency assumption anywhere.
+template <int R>
+__global__ __launch_bounds__(1024) void nms_rounds_kernel(const NmsArgs a) {
+  const int b = blockIdx.y;
+  const size_t HW = (size_t)a.H * a.W;
+  const int n = a.ncand[b];
+  if (n <= 1 || blockIdx.x * 1024 >= n) return;  // n == 1 is settled by nms_sort_kernel
+  nms_run_rounds<R>(a.nmsmap + b * HW, a.cand + b * HW, n, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024, a.H,
+                    a.W, a.r, false);
 }
 
 // Survivors inside the border -> sort -> outputs.  One workgroup per frame.
@@ -396,6 +405,16 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
   if (tid == 0) {
     s_count = 0;
     s_total = 0;
+  }
+  // whatever the parallel launches left undecided (normally nothing): this workgroup owns all of
+  // the frame's candidates, so running rounds to completion cannot wait on anybody
+  uint32_t* wmap = a.nmsmap + (size_t)b * H * W;
+  uint32_t* wcand = a.cand + (size_t)b * H * W;
+  if (n == 1) {  // nms.py:23-25: a single candidate is returned as is
+    if (tid == 0) wmap[wcand[0]] |= 0x80000000u;
+  } else if (n > 1) {
+    if (a.r == 4) nms_run_rounds<4>(wmap, wcand, n, tid, 1024, H, W, a.r, true);
+    else nms_run_rounds<0>(wmap, wcand, n, tid, 1024, H, W, a.r, true);
   }
   __syncthreads();
   // count first so that the LDS / scratch choice is uniform over the workgroup
