@@ -254,26 +254,65 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
   }
 
   // ---------------------------------------------------------------- epilogue
-  const int oyb = ty * TH, oxb = tx * TW;
+  // The accumulators hold one channel per lane: stored as they are, every lane would issue 16*MB*NB
+  // four-byte stores (and as many loads of the identity).  Instead the tile goes through LDS once
+  // more ([pixel][channel], as h did) and leaves as whole 16-byte channel vectors: bias, identity
+  // (read as float4, coalesced), ReLU, store.
+  __syncthreads();  // every wave is done reading h
+  {
+    float* ol = reinterpret_cast<float*>(lds4);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = (wn * NB + nb) * 32 + l31;
-    const float bias = a.b2[n];
-    const bool nok = n < a.nstore;
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 32 + l31;
+      const float bias = a.b2[n];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (n < CMIDP) ol[m * (ROWH4 * 4) + n] = acc[mb][nb][r] + bias;
+        }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int C4 = CMIDP / 4;              // CMIDP == padded output channels of the block
+    constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
+    const int oyb = ty * TH, oxb = tx * TW;
+    const bool ident = a.k8_x == 0;
+    float4 idv[EIT];
+    if (ident) {
+#pragma unroll
+      for (int i = 0; i < EIT; ++i) {
+        const int e = tid + i * NT;
+        const int m = e / C4, c4 = e - m * C4;
         const int py = m / TW, px = m - py * TW;
         const int y = oyb + py, x = oxb + px;
-        if (nok && m < TH * TW && y < a.Ho && x < a.Wo) {
-          const size_t opix = (size_t)(b * a.Ho + y) * a.Wo + x;
-          float v = acc[mb][nb][r] + bias;
-          if (a.k8_x == 0) v += a.x[opix * a.csx + n];  // identity shortcut (stride 1, same geometry)
-          a.out[opix * a.cso + n] = v > 0.f ? v : 0.f;
-        }
+        const bool ok = (NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo;
+        idv[i] = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(b * a.Ho + y) * a.Wo + x) * a.csx + c4 * 4 : 0));
       }
+    }
+#pragma unroll
+    for (int i = 0; i < EIT; ++i) {
+      const int e = tid + i * NT;
+      const int m = e / C4, c4 = e - m * C4;
+      const int py = m / TW, px = m - py * TW;
+      const int y = oyb + py, x = oxb + px;
+      if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
+        float4 v = lds4[m * ROWH4 + c4];
+        if (ident) {
+          v.x += idv[i].x;
+          v.y += idv[i].y;
+          v.z += idv[i].z;
+          v.w += idv[i].w;
+        }
+        v.x = v.x > 0.f ? v.x : 0.f;
+        v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f;
+        v.w = v.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.Ho + y) * a.Wo + x) * a.cso + c4 * 4) = v;
+      }
+    }
   }
 }
 

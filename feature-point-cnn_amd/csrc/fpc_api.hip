@@ -165,6 +165,7 @@ struct fpc_ctx {
   hipEvent_t ev_fork = nullptr;
   int min_sub = 4;                   // smallest sub-batch worth its own stream
   int nms_passes = 2;
+  bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
 
@@ -422,7 +423,7 @@ static int build_plan(fpc_ctx* c) {
     c->ops.push_back(op);
     c->convw.push_back({});
     c->stem_w_off = bo;
-    bo += (size_t)STEM_KG * 2 * 64 * 4;
+    bo += (size_t)(STEM_KG + 2) * 2 * 64 * 4;  // + two zero groups: the fused kernel prefetches ahead
     c->stem_b_off = bo;
     bo += 64;
     op = Op();
@@ -762,6 +763,20 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb, bool wan
     if (op.descriptor_branch && !want_desc) continue;
     switch (op.type) {
       case OP_STEM: {
+        if (c->fuse_stem_pool) {
+          float* x0 = c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
+          hipMemsetAsync(x0, 0, (size_t)n * (H / 4) * (W / 4) * 64 * sizeof(float), sb.st);
+          LaunchTimer t(c, (int)i, sb.st);
+          StemPoolArgs a{};
+          a.in = frames + (size_t)f0 * 3 * H * W;
+          a.wfrag = c->stem.wfrag;
+          a.bias = c->stem.bias;
+          a.out = x0;
+          a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Hp = H / 4; a.Wp = W / 4;
+          a.tiles_x = c->stem.tiles_x; a.tiles_y = c->stem.tiles_y;
+          hipLaunchKernelGGL(stem_pool_kernel, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
+          break;
+        }
         LaunchTimer t(c, (int)i, sb.st);
         StemArgs a = c->stem;
         a.in = frames + (size_t)f0 * 3 * H * W;
@@ -770,6 +785,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb, bool wan
         break;
       }
       case OP_POOL: {
+        if (c->fuse_stem_pool) break;
         LaunchTimer t(c, (int)i, sb.st);
         const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
         hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sb.st,
@@ -940,6 +956,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     int nsub = 2;
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
+    if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < nsub; ++i) {
@@ -1176,7 +1193,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
     if (kernels) {
       const char* k = "?";
       if (op) switch (op->type) {
-          case OP_STEM: k = "stem_kernel"; break;
+          case OP_STEM: k = c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;

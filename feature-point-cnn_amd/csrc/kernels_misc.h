@@ -107,6 +107,149 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Stem + max-pool in one launch (superpoint.py:20-23): the 19.7 MB/frame conv1 output
+// never reaches HBM.  Same GEMM as stem_kernel; the epilogue turns each 32-channel half
+// of the 16x16 conv tile around through LDS and emits MaxPool2d(3, stride 2, padding 1)
+// outputs.  A pooling window that straddles two tiles is completed with atomicMax on the
+// float bits -- exact and order-independent because post-ReLU values are >= +0 -- into a
+// buffer the host zeroes per call; windows inside one tile are stored directly.
+// ---------------------------------------------------------------------------------
+struct StemPoolArgs {
+  const float* in;      // [B,3,H,W]
+  const float4* wfrag;  // [19 + 2][2][64] float4 (two zero groups of prefetch padding)
+  const float* bias;    // [64]
+  float* out;           // [B,Hp,Wp,64], zero-filled
+  int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
+};
+
+constexpr int STEM_TROW = 33;  // floats per pixel of the epilogue tile (32 channels + 1 skew)
+constexpr int STEM_POOL_LDS_FLOATS =
+    STEM_LDS_FLOATS > 256 * STEM_TROW ? STEM_LDS_FLOATS : 256 * STEM_TROW;
+
+__global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
+  __shared__ float lds[STEM_POOL_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x / tiles;
+  const int t = blockIdx.x - b * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
+
+  const float4* wp = a.wfrag + lane;
+  float4 q0[2], q1[2];  // B fragments run two groups ahead
+  q0[0] = wp[0];
+  q0[1] = wp[64];
+  q1[0] = wp[128];
+  q1[1] = wp[192];
+
+  {  // input window -> LDS: all loads of a thread are issued before the first LDS write
+    constexpr int NE = 3 * STEM_HALO * STEM_HALO, IT = (NE + 255) / 256;
+    float v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * 256;
+      const int c = e / (STEM_HALO * STEM_HALO);
+      const int r = e - c * (STEM_HALO * STEM_HALO);
+      const int hy = r / STEM_HALO, hx = r - hy * STEM_HALO;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = e < NE && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float x = a.in[ok ? ((size_t)(b * 3 + c) * a.H + iy) * a.W + ix : 0];
+      v[i] = ok ? x : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * 256;
+      const int c = e / (STEM_HALO * STEM_HALO);
+      const int r = e - c * (STEM_HALO * STEM_HALO);
+      const int hy = r / STEM_HALO, hx = r - hy * STEM_HALO;
+      if (e < NE) lds[(c * STEM_HALO + hy) * STEM_LW + hx] = v[i];
+    }
+  }
+  __syncthreads();
+
+  int abase[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = (wave * 2 + mb) * 32 + l31;
+    abase[mb] = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int g = 0; g < STEM_KG; ++g) {
+    float4 q2[2];
+    q2[0] = wp[((g + 2) * 2 + 0) * 64];
+    q2[1] = wp[((g + 2) * 2 + 1) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = g * 8 + 2 * j;  // lanes 0-31 take k0, lanes 32-63 take k0+1
+      const int off = half ? stem_koff(k0 + 1) : stem_koff(k0);
+      const float bf0 = j == 0 ? q0[0].x : j == 1 ? q0[0].y : j == 2 ? q0[0].z : q0[0].w;
+      const float bf1 = j == 0 ? q0[1].x : j == 1 ? q0[1].y : j == 2 ? q0[1].z : q0[1].w;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float af = lds[abase[mb] + off];
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf0, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf1, acc[mb][1], 0, 0, 0);
+      }
+    }
+    q0[0] = q1[0];
+    q0[1] = q1[1];
+    q1[0] = q2[0];
+    q1[1] = q2[1];
+  }
+
+  // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool
+  const int gy0 = ty * STEM_T, gx0 = tx * STEM_T;       // conv-output origin of the tile
+  const int c = tid & 31;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    __syncthreads();  // nb == 0: halo reads done; nb == 1: previous half's pooling reads done
+    const float bias = a.bias[nb * 32 + l31];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wave * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v = acc[mb][nb][r] + bias;
+        lds[m * STEM_TROW + l31] = v > 0.f ? v : 0.f;
+      }
+    __syncthreads();
+    for (int p = tid >> 5; p < 81; p += 8) {  // 9 x 9 pooled positions touched by this tile
+      const int py = p / 9, px = p - py * 9;
+      const int gpy = ty * 8 + py, gpx = tx * 8 + px;
+      if (gpy >= a.Hp || gpx >= a.Wp) continue;
+      float mx = -1.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int rr = 2 * py - 1 + dy;
+        if (rr < 0 || rr > 15 || gy0 + rr >= a.Ho) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int cc = 2 * px - 1 + dx;
+          if (cc < 0 || cc > 15 || gx0 + cc >= a.Wo) continue;
+          mx = fmaxf(mx, lds[(rr * STEM_T + cc) * STEM_TROW + c]);
+        }
+      }
+      if (mx < 0.f) continue;  // no pixel of this window lies in this tile
+      float* dst = a.out + ((size_t)(b * a.Hp + gpy) * a.Wp + gpx) * 64 + nb * 32 + c;
+      if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
+        *dst = mx;  // whole window inside this tile
+      else
+        atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
+    }
+  }
+}
+
 // MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC, C = 64 (superpoint.py:15,23).
 __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* out, int B, int H, int W,
                                                       int Ho, int Wo) {
