@@ -162,6 +162,9 @@ struct fpc_ctx {
   bool own_stream = false;
   std::vector<hipStream_t> aux;      // extra streams for sub-batches
   std::vector<hipEvent_t> ev_join;
+  std::vector<hipStream_t> side;     // per sub-batch: detector head + NMS next to the descriptor head
+  std::vector<hipEvent_t> ev_enc, ev_det;
+  bool split_heads = true;           // FPC_SPLIT_HEADS=0: one stream per sub-batch
   hipEvent_t ev_fork = nullptr;
   int min_sub = 4;                   // smallest sub-batch worth its own stream
   int nms_passes = 2;
@@ -727,7 +730,9 @@ static hipEvent_t next_event(fpc_ctx* c) {
 
 struct Sub {
   int f0, n;
-  hipStream_t st;
+  hipStream_t st;                  // encoder, descriptor head, descriptor sampling
+  hipStream_t side = nullptr;      // detector head + NMS, concurrent with the descriptor head
+  hipEvent_t ev_enc = nullptr, ev_det = nullptr;
 };
 
 struct LaunchTimer {
@@ -756,11 +761,15 @@ static int op_index(const fpc_ctx* c, OpType t) {
   return -1;
 }
 
-static void run_network(fpc_ctx* c, const float* frames, const Sub& sb, bool want_desc) {
+// which: 0 = encoder, 1 = detector head, 2 = descriptor head
+static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int which, hipStream_t st) {
+  Sub sb = sb0;
+  sb.st = st;
   const int H = c->H, W = c->W, n = sb.n, f0 = sb.f0;
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
-    if (op.descriptor_branch && !want_desc) continue;
+    const int br = op.descriptor_branch ? 2 : (op.name.compare(0, 9, "detector.") == 0 ? 1 : 0);
+    if (br != which) continue;
     switch (op.type) {
       case OP_STEM: {
         if (c->fuse_stem_pool) {
@@ -814,6 +823,12 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb, bool wan
   }
 }
 
+static Sub on(const Sub& sb, hipStream_t st) {
+  Sub r = sb;
+  r.st = st;
+  return r;
+}
+
 static void run_softmax(fpc_ctx* c, const Sub& sb) {
   const size_t HW = (size_t)c->H * c->W;
   hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
@@ -859,25 +874,54 @@ static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
 template <typename F>
 static int for_each_sub(fpc_ctx* c, int n, F&& body) {
   int parts = std::min<int>((int)c->aux.size() + 1, std::max(1, n / c->min_sub));
-  if (parts <= 1) {
-    body(Sub{0, n, c->stream});
-  } else {
-    HIPCHECK(hipEventRecord(c->ev_fork, c->stream));
-    int f0 = 0;
-    for (int p = 0; p < parts; ++p) {
-      const int cnt = n / parts + (p < n % parts ? 1 : 0);
-      hipStream_t st = p == 0 ? c->stream : c->aux[p - 1];
-      if (p) HIPCHECK(hipStreamWaitEvent(st, c->ev_fork, 0));
-      body(Sub{f0, cnt, st});
-      if (p) {
-        HIPCHECK(hipEventRecord(c->ev_join[p - 1], st));
-        HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_join[p - 1], 0));
-      }
-      f0 += cnt;
+  if (parts > 1) HIPCHECK(hipEventRecord(c->ev_fork, c->stream));
+  int f0 = 0;
+  for (int p = 0; p < parts; ++p) {
+    const int cnt = n / parts + (p < n % parts ? 1 : 0);
+    Sub sb;
+    sb.f0 = f0;
+    sb.n = cnt;
+    sb.st = p == 0 ? c->stream : c->aux[p - 1];
+    sb.side = c->side[p];
+    sb.ev_enc = c->ev_enc[p];
+    sb.ev_det = c->ev_det[p];
+    if (p) HIPCHECK(hipStreamWaitEvent(sb.st, c->ev_fork, 0));
+    body(sb);
+    if (p) {
+      HIPCHECK(hipEventRecord(c->ev_join[p - 1], sb.st));
+      HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_join[p - 1], 0));
     }
+    f0 += cnt;
   }
   HIPCHECK(hipGetLastError());
   return FPC_OK;
+}
+
+// The whole path for one sub-batch.  The detector head and its post-processing (latency-bound,
+// few CUs) run on a side stream next to the descriptor head (MFMA-bound); both only need the
+// encoder output.  `upto`: 0 = dense maps only (fpc_forward), 1 = keypoints + descriptors.
+static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, int upto) {
+  run_network(c, frames, sb, 0, sb.st);
+  if (!de || !c->split_heads) {
+    run_network(c, frames, sb, 1, sb.st);
+    run_softmax(c, sb);
+    if (upto) run_nms(c, sb);
+    if (de) {
+      run_network(c, frames, sb, 2, sb.st);
+      if (upto) run_desc(c, sb, c->desc_map);
+    }
+    return;
+  }
+  hipEventRecord(sb.ev_enc, sb.st);
+  hipStreamWaitEvent(sb.side, sb.ev_enc, 0);
+  const Sub det = on(sb, sb.side);
+  run_network(c, frames, sb, 1, sb.side);
+  run_softmax(c, det);
+  if (upto) run_nms(c, det);
+  hipEventRecord(sb.ev_det, sb.side);
+  run_network(c, frames, sb, 2, sb.st);
+  hipStreamWaitEvent(sb.st, sb.ev_det, 0);
+  if (upto) run_desc(c, sb, c->desc_map);
 }
 
 }  // namespace fpc
@@ -967,6 +1011,17 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
       c->aux.push_back(st);
       c->ev_join.push_back(ev);
     }
+    if (const char* e = getenv("FPC_SPLIT_HEADS")) c->split_heads = atoi(e) != 0;
+    for (int i = 0; i < nsub; ++i) {
+      hipStream_t st;
+      hipEvent_t e1, e2;
+      HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      c->side.push_back(st);
+      c->ev_enc.push_back(e1);
+      c->ev_det.push_back(e2);
+    }
   }
   for (int k = 0; k < K_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
@@ -994,6 +1049,9 @@ void fpc_destroy(fpc_ctx* c) {
   for (auto e : c->event_pool) hipEventDestroy(e);
   for (auto e : c->ev_join) hipEventDestroy(e);
   for (auto st : c->aux) hipStreamDestroy(st);
+  for (auto st : c->side) hipStreamDestroy(st);
+  for (auto e : c->ev_enc) hipEventDestroy(e);
+  for (auto e : c->ev_det) hipEventDestroy(e);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->slab) hipFree(c->slab);
   if (c->blob) hipFree(c->blob);
@@ -1074,10 +1132,7 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
-  int rc = for_each_sub(c, n, [&](const Sub& sb) {
-    run_network(c, frames, sb, de);
-    run_softmax(c, sb);
-  });
+  int rc = for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 0); });
   if (rc != FPC_OK) return rc;
   const int HWc = c->Hc * c->Wc;
   if (prob) HIPCHECK(hipMemcpyAsync(prob, c->prob, (size_t)n * c->H * c->W * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -1104,12 +1159,7 @@ int fpc_detect(fpc_ctx* c, const float* frames, int n) {
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
-  return for_each_sub(c, n, [&](const Sub& sb) {
-    run_network(c, frames, sb, de);
-    run_softmax(c, sb);
-    run_nms(c, sb);
-    if (de) run_desc(c, sb, c->desc_map);
-  });
+  return for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 1); });
 }
 
 int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n) {
@@ -1120,7 +1170,10 @@ int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n)
   const int per = (HW + 255) / 256;
   hipLaunchKernelGGL(threshold_kernel, dim3(per * n), dim3(256), 0, c->stream, prob, n, HW, c->cfg.conf_thresh,
                      c->nmsmap, c->cand, c->ncand);
-  const Sub all{0, n, c->stream};
+  Sub all;
+  all.f0 = 0;
+  all.n = n;
+  all.st = c->stream;
   run_nms(c, all);
   if (desc_nchw && c->cfg.descriptor_enabled) {
     const size_t tot = (size_t)n * 128 * c->Hc * c->Wc;
