@@ -15,7 +15,7 @@ import subprocess
 import torch  # noqa: F401
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "lib", "libfpc.so")
+LIB_PATH = os.environ.get("FPC_LIB_PATH") or os.path.join(_DIR, "lib", "libfpc.so")   # FPC_LIB_PATH: A/B builds
 CSRC = os.path.join(_DIR, "csrc")
 
 # every symbol include/fpc.h declares (tests/test_abi.py checks the header against this list)

@@ -18,6 +18,19 @@
 
 namespace fpc {
 
+#ifdef FPC_DIAG
+// In-kernel stamps (diagnostic build, `make diag`): wave 0 of every workgroup records the shader
+// clock at its phase boundaries plus where it ran.  Never compiled into libfpc.so.
+#define FPC_STAMP(i)                                                                     \
+  if (a.stamps && threadIdx.x == 0) {                                                    \
+    unsigned long long t_;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    a.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                         \
+  }
+#else
+#define FPC_STAMP(i)
+#endif
+
 struct BlockArgs {
   const float* x;        // NHWC input, already offset to its first channel
   int csx, nchunk;       // pixel stride (floats), Cin_pad / KC
@@ -30,6 +43,9 @@ struct BlockArgs {
   int k8_h, k8_x;        // k8_x == 0: identity shortcut
   float* out;
   int cso, Ho, Wo, tiles_x, tiles_y, nstore, frame0;
+#ifdef FPC_DIAG
+  unsigned long long* stamps;  // diagnostic build only: 8 words per workgroup
+#endif
 };
 
 template <int TH, int TW, int S, int KC, int WM, int WN, int MB, int NB, int CMIDP>
@@ -42,7 +58,7 @@ struct BlockCfg {
 };
 
 template <int TH, int TW, int S, int KC, int WM, int WN, int MB, int NB, int CMIDP>
-__global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockArgs a) {
   using C = ConvCfg<TH, TW, S, 3, KC, WM, WN, MB, NB>;
   using BC = BlockCfg<TH, TW, S, KC, WM, WN, MB, NB, CMIDP>;
   constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW4 = C::ROW4, K8 = KC / 8, KC4 = KC / 4;
@@ -58,6 +74,13 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
   const int t = blockIdx.x - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
 
+  FPC_STAMP(0)
+#ifdef FPC_DIAG
+  if (a.stamps && threadIdx.x == 0) {
+    a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492);          // HW_ID
+    a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+#endif
   int abase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -116,18 +139,25 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
     store_chunk();
     __syncthreads();
     if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    if (chunk == 0) { FPC_STAMP(1) }
+    // A fragments run one step ahead of the MFMAs that consume them (LDS latency would
+    // otherwise sit between every group of MFMAs), B fragments two steps ahead.
+    float4 av[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[abase[mb] + a.tapoff4[0]];
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = a.tapoff4[tap];
+      const int toffn = a.tapoff4[tap < 8 ? tap + 1 : 8];
 #pragma unroll
       for (int k8 = 0; k8 < K8; ++k8) {
-        float4 b2[NB];
+        float4 b2[NB], an[MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b2[nb] = wp[nb * 64];
         wp += stepstride;
-        __builtin_amdgcn_sched_barrier(0);
-        float4 av[MB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[abase[mb] + toff + k8 * 2];
+        for (int mb = 0; mb < MB; ++mb)
+          an[mb] = lds4[abase[mb] + (k8 + 1 < K8 ? toff + (k8 + 1) * 2 : toffn)];  // last step of a chunk: unused
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -143,10 +173,13 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
           b0[nb] = b1[nb];
           b1[nb] = b2[nb];
         }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
       }
     }
   }
 
+  FPC_STAMP(2)
   // ---------------------------------------------------------------- h = relu(acc + b1) -> LDS
   // start streaming phase 2's weights while the tile is being turned around
   const float4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
@@ -176,33 +209,41 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
   }
   __syncthreads();
 
+  FPC_STAMP(3)
   // ---------------------------------------------------------------- phase 2a: K over h (LDS)
   int hbase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH4 + half;
-  for (int k8 = 0; k8 < a.k8_h; ++k8) {
-    float4 b2[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
-    wq += stepstride;
-    __builtin_amdgcn_sched_barrier(0);
+  {
     float4 av[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[hbase[mb] + k8 * 2];
+    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[hbase[mb]];
+    for (int k8 = 0; k8 < a.k8_h; ++k8) {
+      float4 b2[NB], an[MB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
+      wq += stepstride;
+      const int kn = k8 + 1 < a.k8_h ? k8 + 1 : k8;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb) an[mb] = lds4[hbase[mb] + kn * 2];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
-          const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
-        }
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      b0[nb] = b1[nb];
-      b1[nb] = b2[nb];
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
+            const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
+          }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        b0[nb] = b1[nb];
+        b1[nb] = b2[nb];
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
     }
   }
 
@@ -258,6 +299,7 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
   // four-byte stores (and as many loads of the identity).  Instead the tile goes through LDS once
   // more ([pixel][channel], as h did) and leaves as whole 16-byte channel vectors: bias, identity
   // (read as float4, coalesced), ReLU, store.
+  FPC_STAMP(4)
   __syncthreads();  // every wave is done reading h
   {
     float* ol = reinterpret_cast<float*>(lds4);
@@ -314,6 +356,7 @@ __global__ __launch_bounds__(WM* WN * 64) void block_mfma_kernel(const BlockArgs
       }
     }
   }
+  FPC_STAMP(5)
 }
 
 }  // namespace fpc

@@ -70,7 +70,7 @@ struct ConvCfg {
 };
 
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArgs a) {
   using C = ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>;
   constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW4 = C::ROW4, K8 = KC / 8, KC4 = KC / 4;
   constexpr int NV = HH * HW * KC4;                   // float4 per halo chunk

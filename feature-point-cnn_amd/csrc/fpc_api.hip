@@ -85,6 +85,7 @@ static const KindInfo g_kinds[K_COUNT] = {
 // Fused ResNetBlock instances.  BKIND(name, TH,TW, S, KC, WM,WN, MB,NB, CMIDP)
 #define FPC_BLOCK_KINDS(X)                                   \
   X(B816_s1_K64_C64, 8, 16, 1, 64, 4, 1, 1, 2, 64)           \
+  X(B1616_s1_K32_C64, 16, 16, 1, 32, 4, 1, 2, 2, 64)         \
   X(B620_s2_K32_C128, 6, 20, 2, 32, 2, 2, 2, 2, 128)         \
   X(B620_s1_K64_C128, 6, 20, 1, 64, 2, 2, 2, 2, 128)         \
   X(B620_s1_K64_C72, 6, 20, 1, 64, 4, 1, 1, 3, 72)           \
@@ -169,6 +170,10 @@ struct fpc_ctx {
   int min_sub = 4;                   // smallest sub-batch worth its own stream
   int nms_passes = 2;
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
+#ifdef FPC_DIAG
+  unsigned long long* diag_stamps = nullptr;
+  int diag_n = 0;
+#endif
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
 
@@ -464,10 +469,11 @@ static int build_plan(fpc_ctx* c) {
     add_conv(c, t, &bo);
   };
   float* feat = c->cat + 128;  // encoder output lives in channels 128..255 of `cat`
+  const BKind l1kind = getenv("FPC_L1_T816") ? BK_B816_s1_K64_C64 : BK_B1616_s1_K32_C64;
   block("encoder.layer1.0", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x0, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
-        c->x1, 64, true, false, BK_B816_s1_K64_C64);
+        c->x1, 64, true, false, l1kind);
   block("encoder.layer1.1", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x1, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
-        c->x2, 64, false, false, BK_B816_s1_K64_C64);
+        c->x2, 64, false, false, l1kind);
   block("encoder.layer2.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, c->x2, 64, 64, 64, H4, W4, c->h8, 128,
         128, 128, c->x3, 128, true, false, BK_B620_s2_K32_C128);
   block("encoder.layer2.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->x3, 128, 128, 128, Hc, Wc, c->h8, 128,
@@ -807,6 +813,16 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         LaunchTimer t(c, (int)i, sb.st);
         BlockArgs a = op.bargs;
         a.frame0 = f0;
+#ifdef FPC_DIAG
+        a.stamps = nullptr;
+        if (const char* e = getenv("FPC_STAMP_OP"))
+          if (op.name.find(e) != std::string::npos) {
+            if (!c->diag_stamps) hipHostMalloc((void**)&c->diag_stamps, (size_t)65536 * 8 * sizeof(unsigned long long));
+            memset(c->diag_stamps, 0, (size_t)65536 * 8 * sizeof(unsigned long long));
+            a.stamps = c->diag_stamps;
+            c->diag_n = a.tiles_x * a.tiles_y * n;
+          }
+#endif
         g_bkinds[op.bkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
         break;
       }
@@ -853,12 +869,12 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
   // enough workgroups that a typical frame (a few thousand candidates) has about one candidate
   // per thread; a few launches back to back (each runs rounds while it makes progress), then the
   // sort kernel finishes whatever is left
-  const int G = std::max(1, std::min(16, 256 / n));
+  const int G = std::max(1, std::min(32, 512 / n));
   for (int pass = 0; pass < c->nms_passes; ++pass) {
     if (c->cfg.nms_dist == 4)
-      hipLaunchKernelGGL(nms_rounds_kernel<4>, dim3(G, n), dim3(1024), 0, sb.st, a);
+      hipLaunchKernelGGL(nms_rounds_kernel<4>, dim3(G, n), dim3(NMS_ROUNDS_THREADS), 0, sb.st, a);
     else
-      hipLaunchKernelGGL(nms_rounds_kernel<0>, dim3(G, n), dim3(1024), 0, sb.st, a);
+      hipLaunchKernelGGL(nms_rounds_kernel<0>, dim3(G, n), dim3(NMS_ROUNDS_THREADS), 0, sb.st, a);
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), NMS_LDS_KEYS * sizeof(unsigned long long), sb.st, a);
 }
@@ -1031,6 +1047,20 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
                                16 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
+#ifdef FPC_DIAG
+  for (int k = 0; k < BK_COUNT; ++k) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_bkinds[k].fn, g_bkinds[k].WM * g_bkinds[k].WN * 64, g_bkinds[k].lds_bytes);
+    hipFuncAttributes fa{};
+    hipFuncGetAttributes(&fa, g_bkinds[k].fn);
+    fprintf(stderr, "[diag] %s: lds %d B, regs %d, static lds %zu, occupancy %d blocks/CU\n", g_bkinds[k].name, g_bkinds[k].lds_bytes, fa.numRegs, fa.sharedSizeBytes, nb);
+  }
+  for (int k = 0; k < K_COUNT; ++k) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_kinds[k].fn, g_kinds[k].threads, g_kinds[k].lds_bytes);
+    fprintf(stderr, "[diag] %s: lds %d B, occupancy %d blocks/CU\n", g_kinds[k].name, g_kinds[k].lds_bytes, nb);
+  }
+#endif
   int rc = build_plan(c.get());
   if (rc != FPC_OK) {
     if (c->slab) hipFree(c->slab);
@@ -1123,6 +1153,14 @@ void* fpc_get_stream(fpc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int fpc_sync(fpc_ctx* c) {
   if (!c) return FPC_E_INVALID;
   HIPCHECK(hipStreamSynchronize(c->stream));
+#ifdef FPC_DIAG
+  if (c->diag_stamps && c->diag_n) {
+    if (FILE* f = fopen(getenv("FPC_STAMP_FILE") ? getenv("FPC_STAMP_FILE") : "/tmp/fpc_stamps.bin", "wb")) {
+      fwrite(c->diag_stamps, sizeof(unsigned long long) * 8, c->diag_n, f);
+      fclose(f);
+    }
+  }
+#endif
   return FPC_OK;
 }
 

@@ -409,27 +409,32 @@ __device__ __forceinline__ void nms_scan(const uint32_t* map, int H, int W, int 
                                          bool* kept_nb, bool* wait) {
   const int y = ci / W, x = ci - y * W;
   bool k = false, w = false;
-  if (R > 0) {  // compile-time radius: all (2R+1)^2 loads are issued before any is tested
-    uint32_t u[(2 * R + 1) * (2 * R + 1)];
+  if (R > 0) {  // compile-time radius: three window rows (3*(2R+1) loads) in flight at a time --
+                // the whole window at once would not fit in registers (it went to scratch)
+    constexpr int D = 2 * R + 1;
 #pragma unroll
-    for (int dy = -R; dy <= R; ++dy)
+    for (int g = -R; g <= R; g += 3) {
+      uint32_t u[3 * D];
 #pragma unroll
-      for (int dx = -R; dx <= R; ++dx) {
-        const int yy = y + dy, xx = x + dx;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        u[(dy + R) * (2 * R + 1) + dx + R] = ld_relaxed(map + (ok ? yy * W + xx : (int)ci));
-      }
+      for (int dy = g; dy < g + 3 && dy <= R; ++dy)
 #pragma unroll
-    for (int dy = -R; dy <= R; ++dy)
+        for (int dx = -R; dx <= R; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          u[(dy - g) * D + dx + R] = ld_relaxed(map + (ok ? yy * W + xx : (int)ci));
+        }
 #pragma unroll
-      for (int dx = -R; dx <= R; ++dx) {
-        if (dy == 0 && dx == 0) continue;
-        const int yy = y + dy, xx = x + dx;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const uint32_t q = yy * W + xx, uu = u[(dy + R) * (2 * R + 1) + dx + R];
-        k |= ok && (uu & 0x80000000u);
-        w |= ok && !(uu & 0x80000000u) && (uu > v || (uu == v && q < ci));
-      }
+      for (int dy = g; dy < g + 3 && dy <= R; ++dy)
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) {
+          if (dy == 0 && dx == 0) continue;
+          const int yy = y + dy, xx = x + dx;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const uint32_t q = yy * W + xx, uu = u[(dy - g) * D + dx + R];
+          k |= ok && (uu & 0x80000000u);
+          w |= ok && !(uu & 0x80000000u) && (uu > v || (uu == v && q < ci));
+        }
+    }
   } else {
     const int y0 = max(y - r, 0), y1 = min(y + r, H - 1), x0 = max(x - r, 0), x1 = min(x + r, W - 1);
     for (int yy = y0; yy <= y1 && !k; ++yy)
@@ -483,14 +488,16 @@ __device__ __forceinline__ void nms_run_rounds(uint32_t* map, uint32_t* cand, in
 // whatever is still undecided is picked up by the next launch (the host issues a few of these
 // back to back) and finally by nms_sort_kernel, whose single workgroup per frame owns every
 // candidate and therefore always terminates.  No co-residency assumption anywhere.
+constexpr int NMS_ROUNDS_THREADS = 512;  // 8 waves: the unrolled window scan needs > 128 VGPRs
+
 template <int R>
-__global__ __launch_bounds__(1024) void nms_rounds_kernel(const NmsArgs a) {
+__global__ __launch_bounds__(NMS_ROUNDS_THREADS) void nms_rounds_kernel(const NmsArgs a) {
   const int b = blockIdx.y;
   const size_t HW = (size_t)a.H * a.W;
   const int n = a.ncand[b];
-  if (n <= 1 || blockIdx.x * 1024 >= n) return;  // n == 1 is settled by nms_sort_kernel
-  nms_run_rounds<R>(a.nmsmap + b * HW, a.cand + b * HW, n, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024, a.H,
-                    a.W, a.r, false);
+  if (n <= 1 || (int)(blockIdx.x * NMS_ROUNDS_THREADS) >= n) return;  // n == 1 is settled by nms_sort_kernel
+  nms_run_rounds<R>(a.nmsmap + b * HW, a.cand + b * HW, n, blockIdx.x * NMS_ROUNDS_THREADS + threadIdx.x,
+                    gridDim.x * NMS_ROUNDS_THREADS, a.H, a.W, a.r, false);
 }
 
 // Survivors inside the border -> sort -> outputs.  One workgroup per frame.
@@ -503,13 +510,21 @@ __device__ __forceinline__ void nms_sort_body(const NmsArgs& a, KeyPtr keys, int
   const int H = a.H, W = a.W, bw = a.border;
   for (int i = tid; i < P; i += 1024) keys[i] = 0ull;
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const uint32_t ci = cand[i] & 0x7fffffffu;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const uint32_t ci = i < n ? cand[i] & 0x7fffffffu : 0u;
     const int y = ci / W, x = ci - y * W;
-    const uint32_t u = map[ci];
-    if ((u & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw) {
-      const int pos = atomicAdd(s_count, 1);
-      keys[pos] = ((unsigned long long)(u & 0x7fffffffu) << 32) | (0xffffffffu - ci);
+    const uint32_t u = i < n ? map[ci] : 0u;
+    const bool keep = (u & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
+    // one LDS atomic per wave, not per survivor (same-address atomics serialise)
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      int base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(s_count, __popcll(mask));
+      base = __shfl(base, 0);
+      if (keep)
+        keys[base + __popcll(mask & ((1ull << (tid & 63)) - 1))] =
+            ((unsigned long long)(u & 0x7fffffffu) << 32) | (0xffffffffu - ci);
     }
   }
   __syncthreads();
@@ -556,8 +571,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
   if (n == 1) {  // nms.py:23-25: a single candidate is returned as is
     if (tid == 0) wmap[wcand[0]] |= 0x80000000u;
   } else if (n > 1) {
-    if (a.r == 4) nms_run_rounds<4>(wmap, wcand, n, tid, 1024, H, W, a.r, true);
-    else nms_run_rounds<0>(wmap, wcand, n, tid, 1024, H, W, a.r, true);
+    nms_run_rounds<0>(wmap, wcand, n, tid, 1024, H, W, a.r, true);
   }
   __syncthreads();
   // count first so that the LDS / scratch choice is uniform over the workgroup
@@ -568,7 +582,9 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
     const int y = ci / W, x = ci - y * W;
     mine += (map[ci] & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
   }
-  if (mine) atomicAdd(&s_total, mine);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((tid & 63) == 0 && mine) atomicAdd(&s_total, mine);
   __syncthreads();
   const int K = s_total;
   int P = 1;
