@@ -17,6 +17,7 @@
 
 #include "../../include/fpc.h"
 #include "block_mfma.h"
+#include "wblock_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "weights.h"
@@ -127,10 +128,46 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
 #undef X
 };
 
+// Winograd ResNetBlock instances.  WKIND(name, KC, NBT)
+#define FPC_WBLOCK_KINDS(X) \
+  X(W816_K32_C64, 32, 2)    \
+  X(W816_K32_C128, 32, 4)
+
+enum WKind {
+#define X(name, ...) WK_##name,
+  FPC_WBLOCK_KINDS(X)
+#undef X
+      WK_COUNT
+};
+
+struct WKindInfo {
+  const char* name;
+  const char* symbol;
+  int KC, NBT, lds_bytes;
+  const void* fn;
+  void (*launch)(const WBlockArgs&, dim3, hipStream_t);
+};
+
+#define X(name, KC, NBT)                                                                                  \
+  static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
+    constexpr int lds = WBlockCfg<KC, NBT>::LDS_BYTES;                                                    \
+    hipLaunchKernelGGL((wblock_mfma_kernel<KC, NBT>), grid, dim3(512), lds, st, a);                       \
+  }
+FPC_WBLOCK_KINDS(X)
+#undef X
+
+static const WKindInfo g_wkinds[WK_COUNT] = {
+#define X(name, KC, NBT)                                                                                  \
+  {#name, "wblock_mfma_kernel<" #KC ", " #NBT ">", KC, NBT, WBlockCfg<KC, NBT>::LDS_BYTES,                \
+   (const void*)wblock_mfma_kernel<KC, NBT>, launchw_##name},
+    FPC_WBLOCK_KINDS(X)
+#undef X
+};
+
 // ------------------------------------------------------------------------------------
 // Launch plan
 // ------------------------------------------------------------------------------------
-enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_SOFTMAX, OP_NMS, OP_DESC };
+enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_WBLOCK, OP_SOFTMAX, OP_NMS, OP_DESC };
 
 struct Op {
   OpType type;
@@ -139,6 +176,8 @@ struct Op {
   ConvArgs args{};
   BKind bkind = BK_COUNT;
   BlockArgs bargs{};
+  WKind wkind = WK_COUNT;
+  WBlockArgs wargs{};
   std::string prefix;          // checkpoint prefix of a fused block
   int cin = 0, cout = 0;       // real channel counts of a fused block
   int grid_y = 1, grid_z = 1;
@@ -174,6 +213,7 @@ struct fpc_ctx {
   unsigned long long* diag_stamps = nullptr;
   int diag_n = 0;
 #endif
+  bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
 
@@ -373,6 +413,43 @@ static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
   c->convw.push_back(cw);
 }
 
+static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_off) {
+  const WKindInfo& k = g_wkinds[wk];
+  Op op;
+  op.type = OP_WBLOCK;
+  op.name = s.prefix + (s.proj ? " [winograd conv1+bn1+relu+conv2+bn2+proj+relu]" : " [winograd conv1+bn1+relu+conv2+bn2+identity+relu]");
+  op.prefix = s.prefix;
+  op.wkind = wk;
+  op.cin = s.cin;
+  op.cout = s.cout;
+  op.descriptor_branch = s.desc_branch;
+  WBlockArgs& a = op.wargs;
+  const int K8 = k.KC / 8;
+  a.x = s.x;
+  a.csx = s.csx;
+  a.nchunk = s.cin_pad / k.KC;
+  a.H = s.H;
+  a.W = s.W;
+  a.k8_h = k.NBT * 32 / 8;
+  a.k8_x = s.proj ? s.cin_pad / 8 : 0;
+  a.out = s.out;
+  a.cso = s.cso;
+  a.tiles_x = (s.W + 15) / 16;
+  a.tiles_y = (s.H + 7) / 8;
+  fpc_ctx::ConvW cw;
+  cw.w_off[0] = *blob_off;
+  *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
+  cw.b_off = *blob_off;
+  *blob_off += (size_t)k.NBT * 32;
+  cw.w_off[1] = *blob_off;
+  *blob_off += ((size_t)(a.k8_h + a.k8_x) + 2) * k.NBT * 64 * 4;
+  cw.b2_off = *blob_off;
+  *blob_off += (size_t)k.NBT * 32;
+  op.flops_per_frame = 2.0 * s.H * s.W * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
+  c->ops.push_back(op);
+  c->convw.push_back(cw);
+}
+
 static int build_plan(fpc_ctx* c) {
   const int H = c->H, W = c->W, B = c->B;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
@@ -444,7 +521,11 @@ static int build_plan(fpc_ctx* c) {
                    int Hx, int Wx, float* h, int csh, int cout, int coutp, float* y, int csy, bool proj,
                    bool desc, BKind bk = BK_COUNT) {
     if (c->fuse_blocks && bk != BK_COUNT) {
-      add_block(c, BlockSpec{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc}, &bo);
+      const BlockSpec bs{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc};
+      if (c->winograd && stride == 1 && cin % 32 == 0 && (cout == 64 || cout == 128))
+        add_wblock(c, bs, cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128, &bo);
+      else
+        add_block(c, bs, &bo);
       return;
     }
     const int Ho = Hx / stride, Wo = Wx / stride;
@@ -547,6 +628,12 @@ static int build_plan(fpc_ctx* c) {
   // resolve weight pointers
   for (size_t i = 0; i < c->ops.size(); ++i) {
     Op& op = c->ops[i];
+    if (op.type == OP_WBLOCK) {
+      op.wargs.w1 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
+      op.wargs.b1 = c->blob + c->convw[i].b_off;
+      op.wargs.w2 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[1]);
+      op.wargs.b2 = c->blob + c->convw[i].b2_off;
+    }
     if (op.type == OP_BLOCK) {
       op.bargs.w1 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
       op.bargs.b1 = c->blob + c->convw[i].b_off;
@@ -595,6 +682,59 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
   }
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
+    if (op.type == OP_WBLOCK) {
+      const WKindInfo& k = g_wkinds[op.wkind];
+      const WBlockArgs& a = op.wargs;
+      const fpc_ctx::ConvW& cw = c->convw[i];
+      const std::string& p = op.prefix;
+      const int ci = op.cin, co = op.cout, nbt = k.NBT, K8 = k.KC / 8;
+      const float* w1 = need(p + ".conv1.weight", {co, ci, 3, 3});
+      const float* w2 = need(p + ".conv2.weight", {co, co, 1, 1});
+      Fold f1, f2, fp;
+      if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
+        return FPC_E_MISSING_KEY;
+      // U = G (g * s) G^T in double, rounded once; [chunk][xi][k8][nb][lane] float4
+      static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+      std::vector<double> U((size_t)co * ci * 16);
+      for (int n = 0; n < co; ++n)
+        for (int cc = 0; cc < ci; ++cc) {
+          const float* g = w1 + ((size_t)n * ci + cc) * 9;
+          double t[4][3];
+          for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+          for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+              U[((size_t)n * ci + cc) * 16 + i * 4 + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * f1.s[n];
+        }
+      float* dst = blob.data() + cw.w_off[0];
+      for (int ch = 0; ch < a.nchunk; ++ch)
+        for (int xi = 0; xi < 16; ++xi)
+          for (int k8 = 0; k8 < K8; ++k8)
+            for (int nb = 0; nb < nbt; ++nb)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int n = nb * 32 + (lane & 31), half = lane >> 5;
+                float* d4 = dst + (((((size_t)ch * 16 + xi) * K8 + k8) * nbt + nb) * 64 + lane) * 4;
+                for (int j = 0; j < 4; ++j) {
+                  const int cc = ch * k.KC + k8 * 8 + 4 * half + j;
+                  d4[j] = (n < co && cc < ci) ? (float)U[((size_t)n * ci + cc) * 16 + xi] : 0.f;
+                }
+              }
+      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
+      std::vector<PackSource> srcs;
+      srcs.push_back({co, a.k8_h * 8, 1, [&](int n, int c_, int) { return (double)w2[(size_t)n * co + c_]; }, &f2.s});
+      std::vector<double> bias(f2.t);
+      const float* wp = nullptr;
+      if (a.k8_x > 0) {
+        wp = need(p + ".identity_downsample.0.weight", {co, ci, 1, 1});
+        if (!wp || !fold_bn(m, p + ".identity_downsample.1", co, &fp, missing)) return FPC_E_MISSING_KEY;
+        srcs.push_back({ci, a.k8_x * 8, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
+        for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
+      }
+      std::vector<float> frag = pack_conv(srcs, co, nbt, 8);
+      memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
+      continue;
+    }
     if (op.type == OP_BLOCK) {
       const BKindInfo& k = g_bkinds[op.bkind];
       const BlockArgs& a = op.bargs;
@@ -809,6 +949,23 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
                            W / 4);
         break;
       }
+      case OP_WBLOCK: {
+        LaunchTimer t(c, (int)i, sb.st);
+        WBlockArgs a = op.wargs;
+        a.frame0 = f0;
+#ifdef FPC_DIAG
+        a.stamps = nullptr;
+        if (const char* e = getenv("FPC_STAMP_OP"))
+          if (op.name.find(e) != std::string::npos) {
+            if (!c->diag_stamps) hipHostMalloc((void**)&c->diag_stamps, (size_t)65536 * 8 * sizeof(unsigned long long));
+            memset(c->diag_stamps, 0, (size_t)65536 * 8 * sizeof(unsigned long long));
+            a.stamps = c->diag_stamps;
+            c->diag_n = a.tiles_x * a.tiles_y * n;
+          }
+#endif
+        g_wkinds[op.wkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
+        break;
+      }
       case OP_BLOCK: {
         LaunchTimer t(c, (int)i, sb.st);
         BlockArgs a = op.bargs;
@@ -1016,6 +1173,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     int nsub = 2;
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
+    if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
     if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1041,6 +1199,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   }
   for (int k = 0; k < K_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
+  for (int k = 0; k < WK_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_wkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_wkinds[k].lds_bytes));
   for (int k = 0; k < BK_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_bkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bkinds[k].lds_bytes));
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1288,6 +1448,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;
+          case OP_WBLOCK: k = g_wkinds[op->wkind].symbol; break;
           case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
           case OP_NMS: k = "nms_rounds_kernel+nms_sort_kernel"; break;
           case OP_DESC: k = "descriptor_kernel"; break;

@@ -1,0 +1,389 @@
+// wblock_mfma.h -- a stride-1 ResNetBlock (python/src/resnet_blocks.py:14-27) per launch with the
+// 3x3 convolution computed by Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+//     V = B^T d B   (4x4 input patch of every 2x2 output tile, per channel)      VALU, in LDS
+//     M_xi = V_xi . U_xi   for the 16 patch positions xi, U = G g G^T (host)      16 GEMMs on MFMA
+//     Y = A^T M A   (+ folded-BN bias, ReLU)  -> h                                VALU, in LDS
+//     out = relu(conv1x1(h) + shortcut(x))                                       as block_mfma.h
+//
+// 16 multiplications per output tile and channel pair instead of 36: the 3x3 costs 2.25x fewer
+// MFMAs.  The transforms only use the constants 0, +-1 (input, output) and 1/2 (filters, folded on
+// the host in double), so the result stays within a few 1e-6 of the direct fp32 convolution.
+//
+// One workgroup = 8 waves = an 8x16 pixel tile (32 Winograd tiles = exactly one 32-row MFMA block
+// per position xi) x ALL output channels (64 or 128).  Wave (gx, gn): positions gx*PX..gx*PX+PX-1,
+// N blocks gn*NBW..gn*NBW+NBW-1, so every wave owns PX*NBW accumulator blocks.
+#pragma once
+#include "block_mfma.h"
+
+namespace fpc {
+
+struct WBlockArgs {
+  const float* x;        // NHWC input, already offset to its first channel
+  int csx, nchunk;       // pixel stride (floats), Cin / KC
+  int H, W;              // input == output size (stride 1)
+  const float4* w1;      // Winograd-domain fragments: [chunk][xi][k8][nb][64] float4 (+2 steps of padding)
+  const float* b1;       // [NBT*32]
+  const float4* w2;      // 1x1 fragments: k8_h steps over h, then k8_x steps over x
+  const float* b2;
+  int k8_h, k8_x;        // k8_x == 0: identity shortcut
+  float* out;
+  int cso, tiles_x, tiles_y, frame0;
+#ifdef FPC_DIAG
+  unsigned long long* stamps;
+#endif
+};
+
+template <int KC, int NBT>
+struct WBlockCfg {
+  static constexpr int TH = 8, TW = 16, NT = 512;
+  static constexpr int HW = TW + 2, HH = TH + 2;
+  static constexpr int ROW4 = KC / 4 + 1;                       // float4 per halo pixel / per V row
+  static constexpr int CMID = NBT * 32;
+  static constexpr int ROWH4 = CMID / 4 + 1;
+  static constexpr int HALO_BYTES = HH * HW * ROW4 * 16;
+  static constexpr int V_BYTES = 16 * 32 * ROW4 * 16;
+  static constexpr int M_BYTES = 16 * 32 * 33 * 4;              // one 32-channel quarter, all 16 positions
+  static constexpr int H_BYTES = 128 * ROWH4 * 16;
+  static constexpr int LDS_BYTES = (HALO_BYTES + V_BYTES) > (M_BYTES + H_BYTES) ? (HALO_BYTES + V_BYTES) : (M_BYTES + H_BYTES);
+  static constexpr int GN = NBT >= 4 ? 2 : 1;                   // wave grid: GX position groups x GN channel groups
+  static constexpr int GX = 8 / GN;
+  static constexpr int PX = 16 / GX;                            // positions per wave
+  static constexpr int NBW = NBT / GN;                          // N blocks per wave
+};
+
+template <int KC, int NBT>
+__global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a) {
+  using C = WBlockCfg<KC, NBT>;
+  constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HW = C::HW, HH = C::HH, ROW4 = C::ROW4, K8 = KC / 8, KC4 = KC / 4;
+  constexpr int NV = HH * HW * KC4, ITER = (NV + NT - 1) / NT, ROWH4 = C::ROWH4, CMID = C::CMID;
+  constexpr int GN = C::GN, PX = C::PX, NBW = C::NBW;
+  extern __shared__ float4 lds4[];
+  float4* halo4 = lds4;
+  float4* v4 = lds4 + C::HALO_BYTES / 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gx = wave / GN, gn = wave % GN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bl = blockIdx.x / tiles;
+  const int b = a.frame0 + bl;
+  const int t = blockIdx.x - bl * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  FPC_STAMP(0)
+
+  const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+  float4 stage[ITER];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC4, c4 = e - pix * KC4;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c4 * 4 : 0;
+      float4 v = *reinterpret_cast<const float4*>(a.x + off);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      stage[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC4, c4 = e - pix * KC4;
+      if (NV % NT == 0 || e < NV) halo4[pix * ROW4 + c4] = stage[i];
+    }
+  };
+
+  f32x16 acc[PX][NBW];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][nb][r] = 0.f;
+
+  // B fragments of this wave: step s = (chunk, local position p, k8), laid out
+  // [chunk][xi][k8][nb][lane]; consecutive (p, k8) of one chunk are contiguous.
+  constexpr int STEPS = PX * K8;                  // per chunk
+  constexpr int stepstride = NBT * 64;
+  const float4* wbase = a.w1 + (size_t)(gx * PX * K8 * NBT + gn * NBW) * 64 + lane;
+  auto wptr = [&](int s) {                        // s = global step index of this wave
+    const int chunk = s / STEPS, ls = s - chunk * STEPS;
+    return wbase + (size_t)(chunk * 16 * K8 + ls) * stepstride;
+  };
+
+  // ---------------------------------------------------------------- phase 1: Winograd 3x3
+  load_chunk(0);
+  float4 b0[NBW], b1[NBW];
+  {
+    const float4* p0 = wptr(0);
+    const float4* p1 = wptr(1);
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      b0[nb] = p0[nb * 64];
+      b1[nb] = p1[nb * 64];
+    }
+  }
+  int gs = 0;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    if (chunk) __syncthreads();   // GEMM of the previous chunk is done with V (and the transform with the halo)
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    {
+      // input transform V = B^T d B for (tile, channel pair): 512 items = 32 tiles x KC/2 pairs (KC = 32)
+      const float2* halo2 = reinterpret_cast<const float2*>(halo4);
+      float2* v2 = reinterpret_cast<float2*>(v4);
+      for (int item = tid; item < 32 * (KC / 2); item += NT) {
+        const int wt = item & 31, c2 = item >> 5;
+        const int ty2 = wt >> 3, tx2 = wt & 7;
+        const int base = ((2 * ty2) * HW + 2 * tx2) * (ROW4 * 2) + c2;
+        float2 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i][j] = halo2[base + (i * HW + j) * (ROW4 * 2)];
+        float2 r[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // B^T d (rows)
+          r[0][j] = make_float2(d[0][j].x - d[2][j].x, d[0][j].y - d[2][j].y);
+          r[1][j] = make_float2(d[1][j].x + d[2][j].x, d[1][j].y + d[2][j].y);
+          r[2][j] = make_float2(d[2][j].x - d[1][j].x, d[2][j].y - d[1][j].y);
+          r[3][j] = make_float2(d[1][j].x - d[3][j].x, d[1][j].y - d[3][j].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // (B^T d) B (columns)
+          const float2 q0 = make_float2(r[i][0].x - r[i][2].x, r[i][0].y - r[i][2].y);
+          const float2 q1 = make_float2(r[i][1].x + r[i][2].x, r[i][1].y + r[i][2].y);
+          const float2 q2 = make_float2(r[i][2].x - r[i][1].x, r[i][2].y - r[i][1].y);
+          const float2 q3 = make_float2(r[i][1].x - r[i][3].x, r[i][1].y - r[i][3].y);
+          v2[((i * 4 + 0) * 32 + wt) * (ROW4 * 2) + c2] = q0;
+          v2[((i * 4 + 1) * 32 + wt) * (ROW4 * 2) + c2] = q1;
+          v2[((i * 4 + 2) * 32 + wt) * (ROW4 * 2) + c2] = q2;
+          v2[((i * 4 + 3) * 32 + wt) * (ROW4 * 2) + c2] = q3;
+        }
+      }
+    }
+    __syncthreads();
+    if (chunk == 0) { FPC_STAMP(1) }
+    // 16 GEMMs, one 32-row block each: this wave's PX positions x NBW channel blocks
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      const int abase = ((gx * PX + p) * 32 + l31) * ROW4 + half;
+#pragma unroll
+      for (int k8 = 0; k8 < K8; ++k8) {
+        float4 b2[NBW];
+        const float4* pn = wptr(gs + 2);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) b2[nb] = pn[nb * 64];
+        ++gs;
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 av = v4[abase + k8 * 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) {
+            const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
+            const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
+            acc[p][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[p][nb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          b0[nb] = b1[nb];
+          b1[nb] = b2[nb];
+        }
+      }
+    }
+  }
+  FPC_STAMP(2)
+
+  // ---------------------------------------------------------------- output transform -> h (LDS)
+  // per 32-channel quarter: M[xi][tile][c] of all 16 positions -> LDS, then Y = A^T M A, + bias, ReLU
+  const float4* wq = a.w2 + lane;
+  float* mreg = reinterpret_cast<float*>(lds4);                       // [16][32][33]
+  float* hl = reinterpret_cast<float*>(lds4) + C::M_BYTES / 4;        // [128][ROWH4*4]
+  for (int q = 0; q < NBT; ++q) {
+    __syncthreads();  // q == 0: GEMMs done with V; q > 0: previous quarter's transform done with M
+    if (q / NBW == gn) {
+      const int nb = q - gn * NBW;
+#pragma unroll
+      for (int nbi = 0; nbi < NBW; ++nbi)
+        if (nbi == nb) {
+#pragma unroll
+          for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int wt = (r & 3) + 8 * (r >> 2) + 4 * half;
+              mreg[((gx * PX + p) * 32 + wt) * 33 + l31] = acc[p][nbi][r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int item = tid; item < 32 * 32; item += NT) {
+      const int c = item & 31, wt = item >> 5;
+      float m[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = mreg[((i * 4 + j) * 32 + wt) * 33 + c];
+      float s0[4], s1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // A^T M
+        s0[j] = m[0][j] + m[1][j] + m[2][j];
+        s1[j] = m[1][j] - m[2][j] - m[3][j];
+      }
+      const float bias = a.b1[q * 32 + c];
+      const float y00 = s0[0] + s0[1] + s0[2] + bias, y01 = s0[1] - s0[2] - s0[3] + bias;
+      const float y10 = s1[0] + s1[1] + s1[2] + bias, y11 = s1[1] - s1[2] - s1[3] + bias;
+      const int ty2 = wt >> 3, tx2 = wt & 7;
+      const int pm = (2 * ty2) * TW + 2 * tx2;
+      const int ch = q * 32 + c;
+      hl[(pm) * (ROWH4 * 4) + ch] = y00 > 0.f ? y00 : 0.f;
+      hl[(pm + 1) * (ROWH4 * 4) + ch] = y01 > 0.f ? y01 : 0.f;
+      hl[(pm + TW) * (ROWH4 * 4) + ch] = y10 > 0.f ? y10 : 0.f;
+      hl[(pm + TW + 1) * (ROWH4 * 4) + ch] = y11 > 0.f ? y11 : 0.f;
+    }
+  }
+  __syncthreads();
+  FPC_STAMP(3)
+
+  // ---------------------------------------------------------------- phase 2: 1x1 over h (+ projection over x)
+  // 4 M blocks (128 pixels) x NBT channel blocks over 8 waves
+  constexpr int BLK = 4 * NBT / 8;               // accumulator blocks per wave (2 for N=128, 1 for N=64)
+  constexpr int NB2 = BLK;                       // this wave: M block mw, channel blocks nb0..nb0+NB2-1
+  const int mw = wave & 3, nb0 = (wave >> 2) * NB2;
+  f32x16 acc2[NB2];
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+  const float4* h4 = lds4 + C::M_BYTES / 16;
+  const int hbase = (mw * 32 + l31) * ROWH4 + half;
+  const float4* wq2 = wq + (size_t)nb0 * 64;
+  float4 c0[NB2], c1[NB2];
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) {
+    c0[nb] = wq2[nb * 64];
+    c1[nb] = wq2[stepstride + nb * 64];
+  }
+  wq2 += 2 * stepstride;
+  {
+    float4 av = h4[hbase];
+    for (int k8 = 0; k8 < a.k8_h; ++k8) {
+      float4 c2[NB2];
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) c2[nb] = wq2[nb * 64];
+      wq2 += stepstride;
+      const float4 an = h4[hbase + (k8 + 1 < a.k8_h ? k8 + 1 : k8) * 2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb) {
+          const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
+          const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
+          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
+        }
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) {
+        c0[nb] = c1[nb];
+        c1[nb] = c2[nb];
+      }
+      av = an;
+    }
+  }
+  if (a.k8_x > 0) {  // projection shortcut: A straight from global (centre pixels of x)
+    int m = mw * 32 + l31;
+    const int py = m / TW, px = m - py * TW;
+    int y = ty * TH + py, x = tx * TW + px;
+    y = y < a.H ? y : a.H - 1;
+    x = x < a.W ? x : a.W - 1;
+    const float* xrow = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 4;
+    float4 an = *reinterpret_cast<const float4*>(xrow);
+    for (int k8 = 0; k8 < a.k8_x; ++k8) {
+      float4 c2[NB2];
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) c2[nb] = wq2[nb * 64];
+      wq2 += stepstride;
+      const float4 av = an;
+      an = *reinterpret_cast<const float4*>(xrow + (k8 + 1 < a.k8_x ? k8 + 1 : k8) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb) {
+          const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
+          const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
+          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
+        }
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) {
+        c0[nb] = c1[nb];
+        c1[nb] = c2[nb];
+      }
+    }
+  }
+  FPC_STAMP(4)
+
+  // ---------------------------------------------------------------- epilogue (as block_mfma.h)
+  __syncthreads();  // every wave is done reading h
+  {
+    float* ol = reinterpret_cast<float*>(lds4);  // [128][ROWH4*4], over the (dead) M region
+#pragma unroll
+    for (int nb = 0; nb < NB2; ++nb) {
+      const int n = (nb0 + nb) * 32 + l31;
+      const float bias = a.b2[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        ol[m * (ROWH4 * 4) + n] = acc2[nb][r] + bias;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int C4 = CMID / 4;
+    constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
+    const int oyb = ty * TH, oxb = tx * TW;
+    const bool ident = a.k8_x == 0;
+    float4 idv[EIT];
+    if (ident) {
+#pragma unroll
+      for (int i = 0; i < EIT; ++i) {
+        const int e = tid + i * NT;
+        const int m = e / C4, c4 = e - m * C4;
+        const int py = m / TW, px = m - py * TW;
+        const int y = oyb + py, x = oxb + px;
+        const bool ok = (NE % NT == 0 || e < NE) && y < a.H && x < a.W;
+        idv[i] = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4 : 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EIT; ++i) {
+      const int e = tid + i * NT;
+      const int m = e / C4, c4 = e - m * C4;
+      const int py = m / TW, px = m - py * TW;
+      const int y = oyb + py, x = oxb + px;
+      if ((NE % NT == 0 || e < NE) && y < a.H && x < a.W) {
+        float4 v = lds4[m * ROWH4 + c4];
+        if (ident) {
+          v.x += idv[i].x;
+          v.y += idv[i].y;
+          v.z += idv[i].z;
+          v.w += idv[i].w;
+        }
+        v.x = v.x > 0.f ? v.x : 0.f;
+        v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f;
+        v.w = v.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) = v;
+      }
+    }
+  }
+  FPC_STAMP(5)
+}
+
+}  // namespace fpc
