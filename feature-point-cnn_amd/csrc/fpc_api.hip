@@ -182,12 +182,14 @@ struct Op {
   int cin = 0, cout = 0;       // real channel counts of a fused block
   int grid_y = 1, grid_z = 1;
   double flops_per_frame = 0;  // algorithmic: 2 * MACs of the real (unpadded) convolution
+  double mfma_flops_per_frame = 0;  // issued on the matrix cores (padding included; Winograd: 16/36 of the 3x3)
   bool descriptor_branch = false;
 };
 
 struct Timing {
   hipEvent_t start, stop;
   int op;
+  int frames;  // frames covered by this launch (a sub-batch)
 };
 
 }  // namespace fpc
@@ -339,6 +341,7 @@ static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
       macs += (double)sp.ntaps;
     }
     op.flops_per_frame = 2.0 * macs * s.H0 * s.W0 * s.cin0 * s.cout;
+    op.mfma_flops_per_frame = 2.0 * macs * ((s.H0 + k.TH - 1) / k.TH) * ((s.W0 + k.TW - 1) / k.TW) * (k.WM * k.MB * 32.0) * (a.nchunk0 * k.KC) * (nbt * 32.0);
   } else {
     a.Ho = a.OH = s.Ho;
     a.Wo = a.OW = s.Wo;
@@ -351,6 +354,8 @@ static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
     cw.w_off[0] = *blob_off;
     *blob_off += ((size_t)(a.nchunk0 * sp.ntaps + a.nchunk1) * K8 + 2) * nbt * 64 * 4;
     op.flops_per_frame = 2.0 * s.Ho * s.Wo * s.cout * ((double)s.cin0 * sp.ntaps + s.cin1);
+    op.mfma_flops_per_frame = 2.0 * ((s.Ho + k.TH - 1) / k.TH) * ((s.Wo + k.TW - 1) / k.TW) * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
+                              ((double)a.nchunk0 * k.KC * sp.ntaps + (double)a.nchunk1 * k.KC);
   }
   cw.b_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
@@ -409,6 +414,8 @@ static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
   cw.b2_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
   op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
+  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
+                            ((double)a.nchunk * k.KC * 9 + (a.k8_h + a.k8_x) * 8.0);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -446,6 +453,9 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   cw.b2_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   op.flops_per_frame = 2.0 * s.H * s.W * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
+  // 16 GEMMs of 32 rows per 128-pixel tile instead of 9 taps x 128 rows; then the 1x1 on 128 rows
+  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) *
+                            (16.0 * 32 * a.nchunk * k.KC + 128.0 * (a.k8_h + a.k8_x) * 8.0);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -505,6 +515,7 @@ static int build_plan(fpc_ctx* c) {
     op.type = OP_STEM;
     op.name = "encoder.conv1+bn1+relu";
     op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;
+    op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
     c->ops.push_back(op);
     c->convw.push_back({});
     c->stem_w_off = bo;
@@ -885,8 +896,9 @@ struct LaunchTimer {
   fpc_ctx* c;
   int op;
   hipStream_t st;
+  int frames;
   hipEvent_t s{}, e{};
-  LaunchTimer(fpc_ctx* c_, int op_, hipStream_t st_) : c(c_), op(op_), st(st_) {
+  LaunchTimer(fpc_ctx* c_, int op_, hipStream_t st_, int frames_) : c(c_), op(op_), st(st_), frames(frames_) {
     if (c->timing) {
       s = next_event(c);
       e = next_event(c);
@@ -896,7 +908,7 @@ struct LaunchTimer {
   ~LaunchTimer() {
     if (c->timing) {
       hipEventRecord(e, st);
-      c->timings.push_back({s, e, op});
+      c->timings.push_back({s, e, op, frames});
     }
   }
 };
@@ -921,7 +933,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         if (c->fuse_stem_pool) {
           float* x0 = c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
           hipMemsetAsync(x0, 0, (size_t)n * (H / 4) * (W / 4) * 64 * sizeof(float), sb.st);
-          LaunchTimer t(c, (int)i, sb.st);
+          LaunchTimer t(c, (int)i, sb.st, n);
           StemPoolArgs a{};
           a.in = frames + (size_t)f0 * 3 * H * W;
           a.wfrag = c->stem.wfrag;
@@ -932,7 +944,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
           hipLaunchKernelGGL(stem_pool_kernel, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
           break;
         }
-        LaunchTimer t(c, (int)i, sb.st);
+        LaunchTimer t(c, (int)i, sb.st, n);
         StemArgs a = c->stem;
         a.in = frames + (size_t)f0 * 3 * H * W;
         a.out = c->stem_out + (size_t)f0 * (H / 2) * (W / 2) * 64;
@@ -941,7 +953,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
       }
       case OP_POOL: {
         if (c->fuse_stem_pool) break;
-        LaunchTimer t(c, (int)i, sb.st);
+        LaunchTimer t(c, (int)i, sb.st, n);
         const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
         hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sb.st,
                            reinterpret_cast<const float4*>(c->stem_out + (size_t)f0 * (H / 2) * (W / 2) * 64),
@@ -950,7 +962,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         break;
       }
       case OP_WBLOCK: {
-        LaunchTimer t(c, (int)i, sb.st);
+        LaunchTimer t(c, (int)i, sb.st, n);
         WBlockArgs a = op.wargs;
         a.frame0 = f0;
 #ifdef FPC_DIAG
@@ -967,7 +979,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         break;
       }
       case OP_BLOCK: {
-        LaunchTimer t(c, (int)i, sb.st);
+        LaunchTimer t(c, (int)i, sb.st, n);
         BlockArgs a = op.bargs;
         a.frame0 = f0;
 #ifdef FPC_DIAG
@@ -984,7 +996,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         break;
       }
       case OP_CONV: {
-        LaunchTimer t(c, (int)i, sb.st);
+        LaunchTimer t(c, (int)i, sb.st, n);
         ConvArgs a = op.args;
         a.frame0 = f0;
         g_kinds[op.kind].launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), sb.st);
@@ -1005,14 +1017,14 @@ static Sub on(const Sub& sb, hipStream_t st) {
 static void run_softmax(fpc_ctx* c, const Sub& sb) {
   const size_t HW = (size_t)c->H * c->W;
   hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
-  LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st);
+  LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st, sb.n);
   hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)16 * c->W * sizeof(float), sb.st,
                      c->lg + (size_t)sb.f0 * c->Hc * c->Wc * 72, 72, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
                      c->prob + sb.f0 * HW, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
 }
 
 static void run_nms(fpc_ctx* c, const Sub& sb) {
-  LaunchTimer t(c, op_index(c, OP_NMS), sb.st);
+  LaunchTimer t(c, op_index(c, OP_NMS), sb.st, sb.n);
   const size_t HW = (size_t)c->H * c->W;
   const int n = sb.n, f0 = sb.f0;
   NmsArgs a{};
@@ -1037,7 +1049,7 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
 }
 
 static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
-  LaunchTimer t(c, op_index(c, OP_DESC), sb.st);
+  LaunchTimer t(c, op_index(c, OP_DESC), sb.st, sb.n);
   hipLaunchKernelGGL(descriptor_kernel, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
                      dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
                      c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128);
@@ -1432,7 +1444,8 @@ int fpc_set_timing(fpc_ctx* c, int enable) {
   return FPC_OK;
 }
 
-int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernels, float* ms, double* flops) {
+int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernels, float* ms, double* flops,
+                    double* mfma_flops) {
   if (!c) return FPC_E_INVALID;
   const int n = (int)c->timings.size();
   for (int i = 0; i < n && i < cap; ++i) {
@@ -1456,7 +1469,8 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
       kernels[i] = k;
     }
     if (ms) ms[i] = v;
-    if (flops) flops[i] = op ? op->flops_per_frame : 0.0;
+    if (flops) flops[i] = op ? op->flops_per_frame * t.frames : 0.0;
+    if (mfma_flops) mfma_flops[i] = op ? op->mfma_flops_per_frame * t.frames : 0.0;
   }
   return n;
 }

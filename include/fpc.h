@@ -146,10 +146,12 @@ int fpc_get_keypoints(fpc_ctx* ctx, int frame, int cap, int32_t* xy, float* conf
 int fpc_set_timing(fpc_ctx* ctx, int enable);
 /* After fpc_sync: number of launches recorded since fpc_set_timing; names[i] (layer) and
  * kernels[i] (kernel symbol, as rocprofv3 prints it) point into ctx-owned storage;
- * ms[i] is the event-to-event duration; flops[i] the algorithmic FLOPs PER FRAME of
- * that launch (0 for non-conv kernels). */
+ * ms[i] is the event-to-event duration; flops[i] the ALGORITHMIC FLOPs of that launch
+ * (2 x MACs of the direct convolution x its frames, 0 for non-conv kernels); mfma_flops[i]
+ * the FLOPs actually issued on the matrix cores (tile / channel padding included;
+ * Winograd launches issue 16/36 of their 3x3 convolution's count).  Any array may be NULL. */
 int fpc_get_timings(fpc_ctx* ctx, int cap, const char** names, const char** kernels, float* ms,
-                    double* flops);
+                    double* flops, double* mfma_flops);
 
 #ifdef __cplusplus
 }
