@@ -128,10 +128,12 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
 #undef X
 };
 
-// Winograd ResNetBlock instances.  WKIND(name, KC, NBT)
-#define FPC_WBLOCK_KINDS(X) \
-  X(W816_K32_C64, 32, 2)    \
-  X(W816_K32_C128, 32, 4)
+// Winograd ResNetBlock instances.  WKIND(name, KC, NBT, CMID)
+#define FPC_WBLOCK_KINDS(X)     \
+  X(W816_K32_C64, 32, 2, 64)    \
+  X(W816_K32_C128, 32, 4, 128)  \
+  X(W816_K32_C72, 32, 3, 72)    \
+  X(W816_K24_C72, 24, 3, 72)
 
 enum WKind {
 #define X(name, ...) WK_##name,
@@ -143,23 +145,23 @@ enum WKind {
 struct WKindInfo {
   const char* name;
   const char* symbol;
-  int KC, NBT, lds_bytes;
+  int KC, NBT, CMID, lds_bytes;
   const void* fn;
   void (*launch)(const WBlockArgs&, dim3, hipStream_t);
 };
 
-#define X(name, KC, NBT)                                                                                  \
+#define X(name, KC, NBT, CMID)                                                                            \
   static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
-    constexpr int lds = WBlockCfg<KC, NBT>::LDS_BYTES;                                                    \
-    hipLaunchKernelGGL((wblock_mfma_kernel<KC, NBT>), grid, dim3(512), lds, st, a);                       \
+    constexpr int lds = WBlockCfg<KC, NBT, CMID>::LDS_BYTES;                                              \
+    hipLaunchKernelGGL((wblock_mfma_kernel<KC, NBT, CMID>), grid, dim3(512), lds, st, a);                 \
   }
 FPC_WBLOCK_KINDS(X)
 #undef X
 
 static const WKindInfo g_wkinds[WK_COUNT] = {
-#define X(name, KC, NBT)                                                                                  \
-  {#name, "wblock_mfma_kernel<" #KC ", " #NBT ">", KC, NBT, WBlockCfg<KC, NBT>::LDS_BYTES,                \
-   (const void*)wblock_mfma_kernel<KC, NBT>, launchw_##name},
+#define X(name, KC, NBT, CMID)                                                                            \
+  {#name, "wblock_mfma_kernel<" #KC ", " #NBT ", " #CMID ">", KC, NBT, CMID,                              \
+   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
     FPC_WBLOCK_KINDS(X)
 #undef X
 };
@@ -215,6 +217,7 @@ struct fpc_ctx {
   unsigned long long* diag_stamps = nullptr;
   int diag_n = 0;
 #endif
+  bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
@@ -437,7 +440,7 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   a.nchunk = s.cin_pad / k.KC;
   a.H = s.H;
   a.W = s.W;
-  a.k8_h = k.NBT * 32 / 8;
+  a.k8_h = k.CMID / 8;
   a.k8_x = s.proj ? s.cin_pad / 8 : 0;
   a.out = s.out;
   a.cso = s.cso;
@@ -533,8 +536,15 @@ static int build_plan(fpc_ctx* c) {
                    bool desc, BKind bk = BK_COUNT) {
     if (c->fuse_blocks && bk != BK_COUNT) {
       const BlockSpec bs{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc};
-      if (c->winograd && stride == 1 && cin % 32 == 0 && (cout == 64 || cout == 128))
-        add_wblock(c, bs, cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128, &bo);
+      WKind wk = WK_COUNT;
+      if (c->winograd && stride == 1) {
+        if (cinp % 32 == 0 && cout == 64) wk = WK_W816_K32_C64;
+        else if (cinp % 32 == 0 && cout == 128) wk = WK_W816_K32_C128;
+        else if (c->winograd_det && cinp % 32 == 0 && coutp == 72) wk = WK_W816_K32_C72;
+        else if (c->winograd_det && cinp == 72 && coutp == 72) wk = WK_W816_K24_C72;
+      }
+      if (wk != WK_COUNT)
+        add_wblock(c, bs, wk, &bo);
       else
         add_block(c, bs, &bo);
       return;
@@ -571,7 +581,9 @@ static int build_plan(fpc_ctx* c) {
   block("encoder.layer2.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->x3, 128, 128, 128, Hc, Wc, c->h8, 128,
         128, 128, feat, 256, false, false, BK_B620_s1_K64_C128);
   if (c->fuse_blocks) {
-    add_block(c, BlockSpec{"detector.layer.0", BK_B620_s1_K64_C72, feat, 256, 128, 128, Hc, Wc, c->d0, 72, 65, 72, true, false}, &bo);
+    const BlockSpec bs{"detector.layer.0", BK_B620_s1_K64_C72, feat, 256, 128, 128, Hc, Wc, c->d0, 72, 65, 72, true, false};
+    if (c->winograd && c->winograd_det) add_wblock(c, bs, WK_W816_K32_C72, &bo);
+    else add_block(c, bs, &bo);
   } else {  // detector.layer.0: the projection shortcut has K = 128 while conv2 has K = 72 (65 padded):
      // run the shortcut as its own 1x1 and add it as the residual of conv2
     ConvSpec s{};
@@ -1186,6 +1198,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
+    if (const char* e = getenv("FPC_WINOGRAD_DET")) c->winograd_det = atoi(e) != 0;
     if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

@@ -34,12 +34,12 @@ struct WBlockArgs {
 #endif
 };
 
-template <int KC, int NBT>
+template <int KC, int NBT, int CMID_>
 struct WBlockCfg {
   static constexpr int TH = 8, TW = 16, NT = 512;
   static constexpr int HW = TW + 2, HH = TH + 2;
   static constexpr int ROW4 = KC / 4 + 1;                       // float4 per halo pixel / per V row
-  static constexpr int CMID = NBT * 32;
+  static constexpr int CMID = CMID_;                             // real (8-padded) channel count, <= NBT*32
   static constexpr int ROWH4 = CMID / 4 + 1;
   static constexpr int HALO_BYTES = HH * HW * ROW4 * 16;
   static constexpr int V_BYTES = 16 * 32 * ROW4 * 16;
@@ -52,9 +52,9 @@ struct WBlockCfg {
   static constexpr int NBW = NBT / GN;                          // N blocks per wave
 };
 
-template <int KC, int NBT>
+template <int KC, int NBT, int CMID_>
 __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a) {
-  using C = WBlockCfg<KC, NBT>;
+  using C = WBlockCfg<KC, NBT, CMID_>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HW = C::HW, HH = C::HH, ROW4 = C::ROW4, K8 = KC / 8, KC4 = KC / 4;
   constexpr int NV = HH * HW * KC4, ITER = (NV + NT - 1) / NT, ROWH4 = C::ROWH4, CMID = C::CMID;
   constexpr int GN = C::GN, PX = C::PX, NBW = C::NBW;
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
         s0[j] = m[0][j] + m[1][j] + m[2][j];
         s1[j] = m[1][j] - m[2][j] - m[3][j];
       }
+      if (q * 32 + c >= CMID) continue;
       const float bias = a.b1[q * 32 + c];
       const float y00 = s0[0] + s0[1] + s0[2] + bias, y01 = s0[1] - s0[2] - s0[3] + bias;
       const float y10 = s1[0] + s1[1] + s1[2] + bias, y11 = s1[1] - s1[2] - s1[3] + bias;
@@ -252,8 +253,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
 
   // ---------------------------------------------------------------- phase 2: 1x1 over h (+ projection over x)
   // 4 M blocks (128 pixels) x NBT channel blocks over 8 waves
-  constexpr int BLK = 4 * NBT / 8;               // accumulator blocks per wave (2 for N=128, 1 for N=64)
-  constexpr int NB2 = BLK;                       // this wave: M block mw, channel blocks nb0..nb0+NB2-1
+  constexpr int NB2 = (NBT + 1) / 2;             // channel blocks per wave: M block mw, blocks nb0..nb0+NB2-1 (< NBT)
   const int mw = wave & 3, nb0 = (wave >> 2) * NB2;
   f32x16 acc2[NB2];
 #pragma unroll
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int nb = 0; nb < NB2; ++nb) {
+          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave group has one block less
           const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
           const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
           acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int nb = 0; nb < NB2; ++nb) {
+          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave group has one block less
           const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
           const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
           acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
 #pragma unroll
     for (int nb = 0; nb < NB2; ++nb) {
       const int n = (nb0 + nb) * 32 + l31;
+      if (n >= CMID) continue;
       const float bias = a.b2[n];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
