@@ -135,9 +135,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
   wp += stepstride;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    if (chunk) __syncthreads();
+    if (chunk) FPC_LDS_BARRIER();
     store_chunk();
-    __syncthreads();
+    FPC_LDS_BARRIER();
     if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
     if (chunk == 0) { FPC_STAMP(1) }
     // A fragments run one step ahead of the MFMAs that consume them (LDS latency would
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) b1[nb] = wq[nb * 64];
   wq += stepstride;
-  __syncthreads();  // every wave is done reading the halo: its LDS becomes the h tile
+  FPC_LDS_BARRIER();  // every wave is done reading the halo: its LDS becomes the h tile
   {
     float* hl = reinterpret_cast<float*>(lds4);
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
         }
     }
   }
-  __syncthreads();
+  FPC_LDS_BARRIER();
 
   FPC_STAMP(3)
   // ---------------------------------------------------------------- phase 2a: K over h (LDS)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   // more ([pixel][channel], as h did) and leaves as whole 16-byte channel vectors: bias, identity
   // (read as float4, coalesced), ReLU, store.
   FPC_STAMP(4)
-  __syncthreads();  // every wave is done reading h
+  FPC_LDS_BARRIER();  // every wave is done reading h
   {
     float* ol = reinterpret_cast<float*>(lds4);
 #pragma unroll
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
         }
     }
   }
-  __syncthreads();
+  FPC_LDS_BARRIER();
   {
     constexpr int C4 = CMIDP / 4;              // CMIDP == padded output channels of the block
     constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;

@@ -26,6 +26,12 @@ namespace fpc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, not for its global
+// loads / stores.  __syncthreads() also drains vmcnt, which would stall every barrier behind the
+// prefetched next halo chunk and -- in the persistent kernels -- behind the previous tile's output
+// stores (vmcnt counts stores on gfx950).
+#define FPC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 struct ConvSub {               // one output-parity phase (plain convs use sub[0] only)
   const float4* wfrag;         // packed B fragments, see pack_conv_weights()
   int ntaps;
@@ -87,7 +93,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArg
   const int b = a.frame0 + bl;
   const int t = blockIdx.x - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-  const ConvSub& sp = a.sub[blockIdx.z];
+  // sub-problems (ConvTranspose parity phases) are dispatched heaviest first: blockIdx.z = 0 is
+  // the last sub-problem (4 taps), so the short ones fill the tail of the launch
+  const int subi = gridDim.z - 1 - blockIdx.z;
+  const ConvSub& sp = a.sub[subi];
 
   // LDS read base of this lane for each of its M blocks (float4 units)
   int abase[MB];

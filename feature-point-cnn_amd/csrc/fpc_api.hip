@@ -211,6 +211,8 @@ struct fpc_ctx {
   bool split_heads = true;           // FPC_SPLIT_HEADS=0: one stream per sub-batch
   hipEvent_t ev_fork = nullptr;
   int min_sub = 4;                   // smallest sub-batch worth its own stream
+  int num_cus = 256;
+  int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
   int nms_passes = 2;
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
 #ifdef FPC_DIAG
@@ -987,7 +989,11 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             c->diag_n = a.tiles_x * a.tiles_y * n;
           }
 #endif
-        g_wkinds[op.wkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
+        a.total = a.tiles_x * a.tiles_y * n;
+        // persistent (one workgroup per CU walking the tiles) when a workgroup gets enough tiles to
+        // amortise; otherwise one workgroup per tile
+        const int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
+        g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid)), sb.st);
         break;
       }
       case OP_BLOCK: {
@@ -1179,6 +1185,11 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   }
   HIPCHECK(hipSetDevice(cfg->device));
   std::unique_ptr<fpc_ctx> c(new fpc_ctx());
+  {
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, cfg->device));
+    c->num_cus = std::max(1, prop.multiProcessorCount);
+  }
   c->cfg = *cfg;
   c->H = cfg->height;
   c->W = cfg->width;
@@ -1198,6 +1209,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
+    if (const char* e = getenv("FPC_PERSIST_MIN")) c->persist_min_tiles = atoi(e);
     if (const char* e = getenv("FPC_WINOGRAD_DET")) c->winograd_det = atoi(e) != 0;
     if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));

@@ -29,6 +29,7 @@ struct WBlockArgs {
   int k8_h, k8_x;        // k8_x == 0: identity shortcut
   float* out;
   int cso, tiles_x, tiles_y, frame0;
+  int total;             // tiles_x * tiles_y * frames of this launch; the grid is persistent
 #ifdef FPC_DIAG
   unsigned long long* stamps;
 #endif
@@ -43,7 +44,7 @@ struct WBlockCfg {
   static constexpr int ROWH4 = CMID / 4 + 1;
   static constexpr int HALO_BYTES = HH * HW * ROW4 * 16;
   static constexpr int V_BYTES = 16 * 32 * ROW4 * 16;
-  static constexpr int M_BYTES = 16 * 32 * 33 * 4;              // one 32-channel quarter, all 16 positions
+  static constexpr int M_BYTES = 16 * 32 * 36 * 4;              // one 32-channel quarter (+4 skew), all 16 positions
   static constexpr int H_BYTES = 128 * ROWH4 * 16;
   static constexpr int LDS_BYTES = (HALO_BYTES + V_BYTES) > (M_BYTES + H_BYTES) ? (HALO_BYTES + V_BYTES) : (M_BYTES + H_BYTES);
   static constexpr int GN = NBT >= 4 ? 2 : 1;                   // wave grid: GX position groups x GN channel groups
@@ -66,15 +67,18 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
   const int gx = wave / GN, gn = wave % GN;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bl = blockIdx.x / tiles;
-  const int b = a.frame0 + bl;
-  const int t = blockIdx.x - bl * tiles;
-  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   FPC_STAMP(0)
 
-  const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+  // Persistent workgroups: tile indices blockIdx.x, blockIdx.x + gridDim.x, ...  The first halo
+  // chunk of the NEXT tile is fetched while the current one is in its last GEMM / transforms /
+  // epilogue, so only the very first tile of a workgroup waits for global memory.
   float4 stage[ITER];
-  auto load_chunk = [&](int chunk) {
+  auto load_chunk = [&](int wg, int chunk) {
+    const int bl = wg / tiles;
+    const int bb = a.frame0 + bl;
+    const int t = wg - bl * tiles;
+    const int tyy = t / a.tiles_x, txx = t - tyy * a.tiles_x;
+    const int iy0 = tyy * TH - 1, ix0 = txx * TW - 1;
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int e = tid + i * NT;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       const int hy = pix / HW, hx = pix - hy * HW;
       const int iy = iy0 + hy, ix = ix0 + hx;
       const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c4 * 4 : 0;
+      const size_t off = ok ? ((size_t)(bb * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c4 * 4 : 0;
       float4 v = *reinterpret_cast<const float4*>(a.x + off);
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       stage[i] = v;
@@ -97,6 +101,27 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     }
   };
 
+  // B fragments of this wave: step s = (chunk, local position p, k8), laid out
+  // [chunk][xi][k8][nb][lane]; consecutive (p, k8) of one chunk are contiguous.
+  constexpr int STEPS = PX * K8;                  // per chunk
+  constexpr int stepstride = NBT * 64;
+  const float4* wbase = a.w1 + (size_t)(gx * PX * K8 * NBT + gn * NBW) * 64 + lane;
+  auto wptr = [&](int s) {                        // s = step index of this wave within a tile
+    const int chunk = s / STEPS, ls = s - chunk * STEPS;
+    return wbase + (size_t)(chunk * 16 * K8 + ls) * stepstride;
+  };
+
+  if ((int)blockIdx.x < a.total) load_chunk(blockIdx.x, 0);
+  for (int wg = blockIdx.x; wg < a.total; wg += gridDim.x) {
+  const int bl = wg / tiles;
+  const int b = a.frame0 + bl;
+  const int t = wg - bl * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  // per-thread index math below is cheap; recompute it per tile rather than let the compiler hoist it
+  // out of the persistent loop and keep dozens of values alive (they spilled to scratch)
+  int tid_t = tid;
+  asm volatile("" : "+v"(tid_t));
+
   f32x16 acc[PX][NBW];
 #pragma unroll
   for (int p = 0; p < PX; ++p)
@@ -105,18 +130,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][nb][r] = 0.f;
 
-  // B fragments of this wave: step s = (chunk, local position p, k8), laid out
-  // [chunk][xi][k8][nb][lane]; consecutive (p, k8) of one chunk are contiguous.
-  constexpr int STEPS = PX * K8;                  // per chunk
-  constexpr int stepstride = NBT * 64;
-  const float4* wbase = a.w1 + (size_t)(gx * PX * K8 * NBT + gn * NBW) * 64 + lane;
-  auto wptr = [&](int s) {                        // s = global step index of this wave
-    const int chunk = s / STEPS, ls = s - chunk * STEPS;
-    return wbase + (size_t)(chunk * 16 * K8 + ls) * stepstride;
-  };
-
   // ---------------------------------------------------------------- phase 1: Winograd 3x3
-  load_chunk(0);
   float4 b0[NBW], b1[NBW];
   {
     const float4* p0 = wptr(0);
@@ -129,15 +143,16 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
   }
   int gs = 0;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    if (chunk) __syncthreads();   // GEMM of the previous chunk is done with V (and the transform with the halo)
+    FPC_LDS_BARRIER();   // previous chunk's GEMM is done with V / previous tile's epilogue with the LDS
     store_chunk();
-    __syncthreads();
-    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    FPC_LDS_BARRIER();
+    if (chunk + 1 < a.nchunk) load_chunk(wg, chunk + 1);
+    else if (wg + (int)gridDim.x < a.total) load_chunk(wg + gridDim.x, 0);
     {
       // input transform V = B^T d B for (tile, channel pair): 512 items = 32 tiles x KC/2 pairs (KC = 32)
       const float2* halo2 = reinterpret_cast<const float2*>(halo4);
       float2* v2 = reinterpret_cast<float2*>(v4);
-      for (int item = tid; item < 32 * (KC / 2); item += NT) {
+      for (int item = tid_t; item < 32 * (KC / 2); item += NT) {
         const int wt = item & 31, c2 = item >> 5;
         const int ty2 = wt >> 3, tx2 = wt & 7;
         const int base = ((2 * ty2) * HW + 2 * tx2) * (ROW4 * 2) + c2;
@@ -167,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
         }
       }
     }
-    __syncthreads();
-    if (chunk == 0) { FPC_STAMP(1) }
+    FPC_LDS_BARRIER();
+    if (chunk == 0 && wg == (int)blockIdx.x) { FPC_STAMP(1) }
     // 16 GEMMs, one 32-row block each: this wave's PX positions x NBW channel blocks
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
@@ -198,15 +213,16 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
   }
-  FPC_STAMP(2)
+  if (wg == (int)blockIdx.x) { FPC_STAMP(2) }
 
   // ---------------------------------------------------------------- output transform -> h (LDS)
+  const int lane_t = tid_t & 63, l31_t = lane_t & 31, half_t = lane_t >> 5, wave_t = tid_t >> 6;
   // per 32-channel quarter: M[xi][tile][c] of all 16 positions -> LDS, then Y = A^T M A, + bias, ReLU
-  const float4* wq = a.w2 + lane;
-  float* mreg = reinterpret_cast<float*>(lds4);                       // [16][32][33]
-  float* hl = reinterpret_cast<float*>(lds4) + C::M_BYTES / 4;        // [128][ROWH4*4]
+  const float4* wq = a.w2 + lane_t;
+  float* mreg = reinterpret_cast<float*>(lds4);                       // [16][32][36]
+  float4* h4w = lds4 + C::M_BYTES / 16;                               // [128][ROWH4] float4
   for (int q = 0; q < NBT; ++q) {
-    __syncthreads();  // q == 0: GEMMs done with V; q > 0: previous quarter's transform done with M
+    FPC_LDS_BARRIER();  // q == 0: GEMMs done with V; q > 0: previous quarter's transform done with M
     if (q / NBW == gn) {
       const int nb = q - gn * NBW;
 #pragma unroll
@@ -216,52 +232,64 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
           for (int p = 0; p < PX; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int wt = (r & 3) + 8 * (r >> 2) + 4 * half;
-              mreg[((gx * PX + p) * 32 + wt) * 33 + l31] = acc[p][nbi][r];
+              const int wt = (r & 3) + 8 * (r >> 2) + 4 * half_t;
+              mreg[((gx * PX + p) * 32 + wt) * 36 + l31_t] = acc[p][nbi][r];
             }
         }
     }
-    __syncthreads();
-    for (int item = tid; item < 32 * 32; item += NT) {
-      const int c = item & 31, wt = item >> 5;
-      float m[4][4];
+    FPC_LDS_BARRIER();
+    // Y = A^T M A on 2 channels at a time: 512 items = 32 tiles x 16 channel pairs (float2 keeps the
+    // register footprint next to the live accumulators small; float4 spilled)
+    if (q * 32 + (tid_t & 15) * 2 < CMID) {
+      const int c2 = tid_t & 15, wt = tid_t >> 4;
+      const float2* m2 = reinterpret_cast<const float2*>(mreg);
+      float2 m[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = mreg[((i * 4 + j) * 32 + wt) * 33 + c];
-      float s0[4], s1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {  // A^T M
-        s0[j] = m[0][j] + m[1][j] + m[2][j];
-        s1[j] = m[1][j] - m[2][j] - m[3][j];
+        for (int j = 0; j < 4; ++j) m[i][j] = m2[((i * 4 + j) * 32 + wt) * 18 + c2];
+      const float2 bias = *reinterpret_cast<const float2*>(a.b1 + q * 32 + c2 * 2);
+      float2 y[4];
+#define FPC_WOUT(comp)                                                                         \
+      {                                                                                        \
+        float s0[4], s1[4];                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+          s0[j] = m[0][j].comp + m[1][j].comp + m[2][j].comp;                                  \
+          s1[j] = m[1][j].comp - m[2][j].comp - m[3][j].comp;                                  \
+        }                                                                                      \
+        const float y00 = s0[0] + s0[1] + s0[2] + bias.comp, y01 = s0[1] - s0[2] - s0[3] + bias.comp; \
+        const float y10 = s1[0] + s1[1] + s1[2] + bias.comp, y11 = s1[1] - s1[2] - s1[3] + bias.comp; \
+        y[0].comp = y00 > 0.f ? y00 : 0.f;                                                     \
+        y[1].comp = y01 > 0.f ? y01 : 0.f;                                                     \
+        y[2].comp = y10 > 0.f ? y10 : 0.f;                                                     \
+        y[3].comp = y11 > 0.f ? y11 : 0.f;                                                     \
       }
-      if (q * 32 + c >= CMID) continue;
-      const float bias = a.b1[q * 32 + c];
-      const float y00 = s0[0] + s0[1] + s0[2] + bias, y01 = s0[1] - s0[2] - s0[3] + bias;
-      const float y10 = s1[0] + s1[1] + s1[2] + bias, y11 = s1[1] - s1[2] - s1[3] + bias;
+      FPC_WOUT(x) FPC_WOUT(y)
+#undef FPC_WOUT
       const int ty2 = wt >> 3, tx2 = wt & 7;
       const int pm = (2 * ty2) * TW + 2 * tx2;
-      const int ch = q * 32 + c;
-      hl[(pm) * (ROWH4 * 4) + ch] = y00 > 0.f ? y00 : 0.f;
-      hl[(pm + 1) * (ROWH4 * 4) + ch] = y01 > 0.f ? y01 : 0.f;
-      hl[(pm + TW) * (ROWH4 * 4) + ch] = y10 > 0.f ? y10 : 0.f;
-      hl[(pm + TW + 1) * (ROWH4 * 4) + ch] = y11 > 0.f ? y11 : 0.f;
+      float2* h2w = reinterpret_cast<float2*>(h4w);
+      const int cq = q * 16 + c2;
+      h2w[(pm) * (ROWH4 * 2) + cq] = y[0];
+      h2w[(pm + 1) * (ROWH4 * 2) + cq] = y[1];
+      h2w[(pm + TW) * (ROWH4 * 2) + cq] = y[2];
+      h2w[(pm + TW + 1) * (ROWH4 * 2) + cq] = y[3];
     }
   }
-  __syncthreads();
-  FPC_STAMP(3)
+  FPC_LDS_BARRIER();
+  if (wg == (int)blockIdx.x) { FPC_STAMP(3) }
 
   // ---------------------------------------------------------------- phase 2: 1x1 over h (+ projection over x)
   // 4 M blocks (128 pixels) x NBT channel blocks over 8 waves
-  constexpr int NB2 = (NBT + 1) / 2;             // channel blocks per wave: M block mw, blocks nb0..nb0+NB2-1 (< NBT)
-  const int mw = wave & 3, nb0 = (wave >> 2) * NB2;
+  constexpr int NB2 = (NBT + 1) / 2;             // channel blocks per wave_t: M block mw, blocks nb0..nb0+NB2-1 (< NBT)
+  const int mw = wave_t & 3, nb0 = (wave_t >> 2) * NB2;
   f32x16 acc2[NB2];
 #pragma unroll
   for (int nb = 0; nb < NB2; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
   const float4* h4 = lds4 + C::M_BYTES / 16;
-  const int hbase = (mw * 32 + l31) * ROWH4 + half;
+  const int hbase = (mw * 32 + l31_t) * ROWH4 + half_t;
   const float4* wq2 = wq + (size_t)nb0 * 64;
   float4 c0[NB2], c1[NB2];
 #pragma unroll
@@ -283,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int nb = 0; nb < NB2; ++nb) {
-          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave group has one block less
+          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave_t group has one block less
           const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
           const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
           acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
@@ -297,12 +325,12 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     }
   }
   if (a.k8_x > 0) {  // projection shortcut: A straight from global (centre pixels of x)
-    int m = mw * 32 + l31;
+    int m = mw * 32 + l31_t;
     const int py = m / TW, px = m - py * TW;
     int y = ty * TH + py, x = tx * TW + px;
     y = y < a.H ? y : a.H - 1;
     x = x < a.W ? x : a.W - 1;
-    const float* xrow = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 4;
+    const float* xrow = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + half_t * 4;
     float4 an = *reinterpret_cast<const float4*>(xrow);
     for (int k8 = 0; k8 < a.k8_x; ++k8) {
       float4 c2[NB2];
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int nb = 0; nb < NB2; ++nb) {
-          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave group has one block less
+          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave_t group has one block less
           const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
           const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
           acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
@@ -328,25 +356,25 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
   }
-  FPC_STAMP(4)
+  if (wg == (int)blockIdx.x) { FPC_STAMP(4) }
 
   // ---------------------------------------------------------------- epilogue (as block_mfma.h)
-  __syncthreads();  // every wave is done reading h
+  FPC_LDS_BARRIER();  // every wave_t is done reading h
   {
     float* ol = reinterpret_cast<float*>(lds4);  // [128][ROWH4*4], over the (dead) M region
 #pragma unroll
     for (int nb = 0; nb < NB2; ++nb) {
-      const int n = (nb0 + nb) * 32 + l31;
+      const int n = (nb0 + nb) * 32 + l31_t;
       if (n >= CMID) continue;
       const float bias = a.b2[n];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half_t;
         ol[m * (ROWH4 * 4) + n] = acc2[nb][r] + bias;
       }
     }
   }
-  __syncthreads();
+  FPC_LDS_BARRIER();
   {
     constexpr int C4 = CMID / 4;
     constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     if (ident) {
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
-        const int e = tid + i * NT;
+        const int e = tid_t + i * NT;
         const int m = e / C4, c4 = e - m * C4;
         const int py = m / TW, px = m - py * TW;
         const int y = oyb + py, x = oxb + px;
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     }
 #pragma unroll
     for (int i = 0; i < EIT; ++i) {
-      const int e = tid + i * NT;
+      const int e = tid_t + i * NT;
       const int m = e / C4, c4 = e - m * C4;
       const int py = m / TW, px = m - py * TW;
       const int y = oyb + py, x = oxb + px;
@@ -386,7 +414,8 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
   }
-  FPC_STAMP(5)
+  if (wg == (int)blockIdx.x) { FPC_STAMP(5) }
+  }  // persistent tile loop
 }
 
 }  // namespace fpc
