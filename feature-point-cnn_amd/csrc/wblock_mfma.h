@@ -146,14 +146,17 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     FPC_LDS_BARRIER();   // previous chunk's GEMM is done with V / previous tile's epilogue with the LDS
     store_chunk();
     FPC_LDS_BARRIER();
+    if (chunk == 0 && wg == (int)blockIdx.x) { FPC_STAMP(6) }
     if (chunk + 1 < a.nchunk) load_chunk(wg, chunk + 1);
     else if (wg + (int)gridDim.x < a.total) load_chunk(wg + gridDim.x, 0);
     {
       // input transform V = B^T d B for (tile, channel pair): 512 items = 32 tiles x KC/2 pairs (KC = 32)
       const float2* halo2 = reinterpret_cast<const float2*>(halo4);
       float2* v2 = reinterpret_cast<float2*>(v4);
+      // lanes run over channel pairs first (16 lanes = one pixel's 128 contiguous bytes): with the
+      // tile index fastest, the 288-byte tile pitch put 32 lanes on 8 bank groups (4-way conflicts)
       for (int item = tid_t; item < 32 * (KC / 2); item += NT) {
-        const int wt = item & 31, c2 = item >> 5;
+        const int c2 = item % (KC / 2), wt = item / (KC / 2);
         const int ty2 = wt >> 3, tx2 = wt & 7;
         const int base = ((2 * ty2) * HW + 2 * tx2) * (ROW4 * 2) + c2;
         float2 d[4][4];
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
         }
       }
     }
+    if (chunk == 0 && wg == (int)blockIdx.x) { FPC_STAMP(7) }
   }
   if (wg == (int)blockIdx.x) { FPC_STAMP(2) }
 
@@ -281,6 +285,21 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
 
   // ---------------------------------------------------------------- phase 2: 1x1 over h (+ projection over x)
   // 4 M blocks (128 pixels) x NBT channel blocks over 8 waves
+  // identity shortcut: fetch this thread's share of x now, it is consumed in the epilogue
+  constexpr int C4E = CMID / 4;
+  constexpr int NEE = TH * TW * C4E, EITE = (NEE + NT - 1) / NT;
+  float4 idv[EITE];
+  if (a.k8_x == 0) {
+#pragma unroll
+    for (int i = 0; i < EITE; ++i) {
+      const int e = tid_t + i * NT;
+      const int m = e / C4E, c4 = e - m * C4E;
+      const int py = m / TW, px = m - py * TW;
+      const int y = ty * TH + py, x = tx * TW + px;
+      const bool ok = (NEE % NT == 0 || e < NEE) && y < a.H && x < a.W;
+      idv[i] = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4 : 0));
+    }
+  }
   constexpr int NB2 = (NBT + 1) / 2;             // channel blocks per wave_t: M block mw, blocks nb0..nb0+NB2-1 (< NBT)
   const int mw = wave_t & 3, nb0 = (wave_t >> 2) * NB2;
   f32x16 acc2[NB2];
@@ -380,18 +399,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
     const int oyb = ty * TH, oxb = tx * TW;
     const bool ident = a.k8_x == 0;
-    float4 idv[EIT];
-    if (ident) {
-#pragma unroll
-      for (int i = 0; i < EIT; ++i) {
-        const int e = tid_t + i * NT;
-        const int m = e / C4, c4 = e - m * C4;
-        const int py = m / TW, px = m - py * TW;
-        const int y = oyb + py, x = oxb + px;
-        const bool ok = (NE % NT == 0 || e < NE) && y < a.H && x < a.W;
-        idv[i] = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4 : 0));
-      }
-    }
+    static_assert(EIT == EITE, "epilogue partition");
 #pragma unroll
     for (int i = 0; i < EIT; ++i) {
       const int e = tid_t + i * NT;
