@@ -24,7 +24,7 @@ SYMBOLS = [
     "fpc_destroy", "fpc_load_weights", "fpc_packed_size", "fpc_packed_device_ptr",
     "fpc_export_packed", "fpc_import_packed", "fpc_mark_weights_loaded", "fpc_set_stream",
     "fpc_get_stream", "fpc_sync", "fpc_forward", "fpc_detect", "fpc_get_points", "fpc_results",
-    "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings",
+    "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
 ]
 
 
@@ -103,6 +103,8 @@ def load():
     l.fpc_results.argtypes = [vp, ctypes.POINTER(FpcDeviceResults)]
     l.fpc_get_counts.argtypes = [vp, ci, vp, vp]
     l.fpc_get_keypoints.argtypes = [vp, ci, ci, vp, vp, vp]
+    l.fpc_match.argtypes = [vp, vp, ci, vp, ci, ci, ctypes.c_float, vp, vp]
+    l.fpc_first_within.argtypes = [vp, vp, ci, vp, ci, ctypes.c_float, vp]
     l.fpc_set_timing.argtypes = [vp, ci]
     l.fpc_get_timings.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double),

@@ -20,6 +20,7 @@
 #include "wblock_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
+#include "match.h"
 #include "weights.h"
 
 namespace fpc {
@@ -234,6 +235,7 @@ struct fpc_ctx {
   int32_t *ncand, *count, *xy, *status;
   float *conf, *desc_out;
   unsigned long long* sort_scratch;
+  unsigned long long *rowbest, *colbest;  // descriptor matching workspace, `cap` entries each
 
   // packed weights
   float* blob = nullptr;
@@ -489,6 +491,7 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>(de ? (size_t)B * c->cap * 128 : 64);
   const size_t o_sort = cv.take<unsigned long long>(c->sort_cap > NMS_LDS_KEYS ? (size_t)B * c->sort_cap : 64);
+  const size_t o_rowbest = cv.take<unsigned long long>(c->cap), o_colbest = cv.take<unsigned long long>(c->cap);
   c->slab_bytes = cv.off;
   if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
     g_hip_err = "hipMalloc(workspace " + std::to_string(c->slab_bytes >> 20) + " MiB) failed";
@@ -510,6 +513,8 @@ static int build_plan(fpc_ctx* c) {
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
   c->sort_scratch = reinterpret_cast<unsigned long long*>(c->slab + o_sort);
+  c->rowbest = reinterpret_cast<unsigned long long*>(c->slab + o_rowbest);
+  c->colbest = reinterpret_cast<unsigned long long*>(c->slab + o_colbest);
 
   // ---- ops
   size_t bo = 0;  // blob offset in floats
@@ -1416,6 +1421,47 @@ int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n)
                        128, c->Hc * c->Wc, n, c->desc_in_nhwc);
     run_desc(c, all, c->desc_in_nhwc);
   }
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+int fpc_match(fpc_ctx* c, const float* q, int nq, const float* t, int nt, int cross_check, float max_dist,
+              int32_t* match, float* dist) {
+  if (!c || nq < 0 || nt < 0 || nq > c->cap || nt > c->cap || (!q && nq) || (!t && nt) || (!match && nq))
+    return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  if (nq == 0) return FPC_OK;
+  if (nt == 0) {
+    HIPCHECK(hipMemsetAsync(match, 0xff, sizeof(int32_t) * nq, c->stream));  // -1
+    return FPC_OK;
+  }
+  HIPCHECK(hipMemsetAsync(c->rowbest, 0xff, sizeof(unsigned long long) * nq, c->stream));
+  HIPCHECK(hipMemsetAsync(c->colbest, 0xff, sizeof(unsigned long long) * nt, c->stream));
+  MatchArgs a{};
+  a.q = q; a.t = t; a.nq = nq; a.nt = nt; a.rowbest = c->rowbest; a.colbest = c->colbest; a.first = nullptr; a.tol2 = -1.f;
+  hipLaunchKernelGGL(match_gemm_kernel, dim3((nq + 127) / 128, (nt + 127) / 128), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(match_finalize_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->rowbest, c->colbest, nq,
+                     cross_check, max_dist, match, dist);
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+int fpc_first_within(fpc_ctx* c, const float* key, int nk, const float* cur, int nc, float tolerance, int32_t* first) {
+  if (!c || nk < 0 || nc < 0 || nk > c->cap || nc > c->cap || !(tolerance >= 0.f) || (!key && nk) || (!cur && nc) ||
+      (!first && nk))
+    return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  if (nk == 0) return FPC_OK;
+  if (nc == 0) {
+    HIPCHECK(hipMemsetAsync(first, 0xff, sizeof(int32_t) * nk, c->stream));
+    return FPC_OK;
+  }
+  unsigned int* ws = reinterpret_cast<unsigned int*>(c->rowbest);
+  HIPCHECK(hipMemsetAsync(ws, 0xff, sizeof(unsigned int) * nk, c->stream));
+  MatchArgs a{};
+  a.q = key; a.t = cur; a.nq = nk; a.nt = nc; a.rowbest = nullptr; a.colbest = nullptr; a.first = ws; a.tol2 = tolerance * tolerance;
+  hipLaunchKernelGGL(match_gemm_kernel, dim3((nk + 127) / 128, (nc + 127) / 128), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(first_finalize_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream, ws, nk, first);
   HIPCHECK(hipGetLastError());
   return FPC_OK;
 }

@@ -1,0 +1,164 @@
+// match.h -- brute-force descriptor matching, the step right after the path in both demos:
+//   Python: cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(query, train)
+//           (python/src/inference.py:88-96)
+//   C++   : SearchKeyFrameCorrespondence -- the FIRST descriptor of the current frame whose L2
+//           distance to a key-frame descriptor is below the tolerance (cpp/src/main.cc:9-29,79-92)
+//
+// S = Q . T^T is a [nq x nt x D] GEMM on the fp32 matrix cores; both operands are already in the
+// per-lane order MFMA wants (a row of 128 floats per descriptor, lane = row, 16 bytes per step), so
+// they are read straight from global memory.  d^2 = |q|^2 + |t|^2 - 2 q.t; the row / column
+// arg-minima are merged across workgroups with 64-bit atomicMin on (float bits of d^2, index):
+// exact, order-independent, ties go to the lower index (OpenCV scans the train set in ascending
+// order and keeps the first minimum).
+#pragma once
+#include "conv_mfma.h"
+
+namespace fpc {
+
+struct MatchArgs {
+  const float* q;   // [nq][128]
+  const float* t;   // [nt][128]
+  int nq, nt;
+  unsigned long long* rowbest;  // [nq]  (d^2 bits << 32 | t index), pre-filled with ~0
+  unsigned long long* colbest;  // [nt]  (d^2 bits << 32 | q index), pre-filled with ~0
+  unsigned int* first;          // [nq]  lowest t index with d < tol (first-within mode), pre-filled with ~0
+  float tol2;                   // tol^2; < 0: arg-min mode
+};
+
+__global__ __launch_bounds__(256) void match_gemm_kernel(const MatchArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q0 = blockIdx.x * 128 + (wave >> 1) * 64, t0 = blockIdx.y * 128 + (wave & 1) * 64;
+  // operand rows of this lane (clamped; out-of-range rows / columns are masked in the epilogue)
+  const float* qrow[2];
+  const float* trow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    qrow[i] = a.q + (size_t)min(q0 + i * 32 + l31, a.nq - 1) * 128 + half * 4;
+    trow[i] = a.t + (size_t)min(t0 + i * 32 + l31, a.nt - 1) * 128 + half * 4;
+  }
+  f32x16 acc[2][2];
+  float qn[2] = {0.f, 0.f}, tn[2] = {0.f, 0.f};  // partial squared norms of this lane's rows (its half of each k8)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 qa[2], ta[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    qa[i] = *reinterpret_cast<const float4*>(qrow[i]);
+    ta[i] = *reinterpret_cast<const float4*>(trow[i]);
+  }
+#pragma unroll 4
+  for (int k8 = 0; k8 < 16; ++k8) {
+    float4 qc[2], tc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      qc[i] = qa[i];
+      tc[i] = ta[i];
+      const int kn = k8 + 1 < 16 ? k8 + 1 : k8;
+      qa[i] = *reinterpret_cast<const float4*>(qrow[i] + kn * 8);
+      ta[i] = *reinterpret_cast<const float4*>(trow[i] + kn * 8);
+      qn[i] += qc[i].x * qc[i].x + qc[i].y * qc[i].y + qc[i].z * qc[i].z + qc[i].w * qc[i].w;
+      tn[i] += tc[i].x * tc[i].x + tc[i].y * tc[i].y + tc[i].z * tc[i].z + tc[i].w * tc[i].w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float af = j == 0 ? qc[mi].x : j == 1 ? qc[mi].y : j == 2 ? qc[mi].z : qc[mi].w;
+          const float bf = j == 0 ? tc[ni].x : j == 1 ? tc[ni].y : j == 2 ? tc[ni].z : tc[ni].w;
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mi][ni], 0, 0, 0);
+        }
+  }
+  // full squared norms: lanes l and l+32 hold the two halves of the same row
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    qn[i] += __shfl_xor(qn[i], 32);
+    tn[i] += __shfl_xor(tn[i], 32);
+  }
+  // C/D map: column (t) = lane & 31, row (q) = (r&3) + 8*(r>>2) + 4*half.
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rowl = (r & 3) + 8 * (r >> 2) + 4 * half;            // row within the 32-block
+      const int qi = q0 + mi * 32 + rowl;
+      const float qnr = __shfl(qn[mi], rowl);                         // |q|^2 of that row lives in lane `rowl`
+      unsigned long long best = ~0ull;
+      unsigned int firstj = ~0u;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int tj = t0 + ni * 32 + l31;
+        float d2 = qnr + tn[ni] - 2.f * acc[mi][ni][r];
+        d2 = d2 > 0.f ? d2 : 0.f;
+        if (tj < a.nt) {
+          const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)tj;
+          best = key < best ? key : best;
+          if (a.tol2 >= 0.f && d2 < a.tol2) firstj = min(firstj, (unsigned)tj);
+        }
+      }
+      // row arg-min over the 32 lanes of this half
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(best, o);
+        best = ob < best ? ob : best;
+        firstj = min(firstj, (unsigned)__shfl_xor((int)firstj, o));
+      }
+      if (l31 == 0 && qi < a.nq) {
+        if (a.tol2 < 0.f) atomicMin(a.rowbest + qi, best);
+        else if (firstj != ~0u) atomicMin(a.first + qi, firstj);
+      }
+    }
+  }
+  if (a.tol2 < 0.f) {  // column arg-min (for the cross check)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int tj = t0 + ni * 32 + l31;
+      unsigned long long best = ~0ull;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowl = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int qi = q0 + mi * 32 + rowl;
+          const float qnr = __shfl(qn[mi], rowl);
+          float d2 = qnr + tn[ni] - 2.f * acc[mi][ni][r];
+          d2 = d2 > 0.f ? d2 : 0.f;
+          if (qi < a.nq) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
+            best = key < best ? key : best;
+          }
+        }
+      const unsigned long long ob = __shfl_xor(best, 32);
+      best = ob < best ? ob : best;
+      if (half == 0 && tj < a.nt) atomicMin(a.colbest + tj, best);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void match_finalize_kernel(const unsigned long long* rowbest, const unsigned long long* colbest,
+                                                             int nq, int cross_check, float max_dist, int32_t* match,
+                                                             float* dist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  const unsigned long long rb = rowbest[i];
+  const int j = (int)(rb & 0xffffffffu);
+  const float d = sqrtf(__uint_as_float((unsigned)(rb >> 32)));
+  bool ok = rb != ~0ull;
+  if (ok && cross_check) ok = (int)(colbest[j] & 0xffffffffu) == i;
+  if (ok && max_dist > 0.f) ok = d < max_dist;
+  match[i] = ok ? j : -1;
+  if (dist) dist[i] = d;
+}
+
+__global__ __launch_bounds__(256) void first_finalize_kernel(const unsigned int* first, int nq, int32_t* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nq) out[i] = first[i] == ~0u ? -1 : (int)first[i];
+}
+
+}  // namespace fpc

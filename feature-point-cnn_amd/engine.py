@@ -184,6 +184,37 @@ class Engine:
             out.append((xy, conf, desc, int(ncand[f])))
         return out
 
+    # -- descriptor matching (next row of the path) -------------------------------------
+    def _desc(self, d):
+        if not isinstance(d, torch.Tensor):
+            d = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32))
+        d = d.to(self.torch_device, torch.float32).contiguous()
+        if d.dim() != 2 or d.shape[1] != 128:
+            raise ValueError("descriptors must be [n,128]")
+        return d
+
+    def match(self, query, train, cross_check=True, max_dist=0.0):
+        """cv2.BFMatcher(NORM_L2, crossCheck).match(query, train): -> (match int32[nq] (train index or
+        -1), dist float32[nq])."""
+        q, t = self._desc(query), self._desc(train)
+        m = torch.empty(q.shape[0], dtype=torch.int32, device=self.torch_device)
+        d = torch.empty(q.shape[0], dtype=torch.float32, device=self.torch_device)
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_match(self._ctx, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0],
+                                     int(bool(cross_check)), float(max_dist), m.data_ptr(), d.data_ptr()), "fpc_match")
+        self.sync()
+        return m.cpu().numpy(), d.cpu().numpy()
+
+    def first_within(self, key, cur, tolerance=0.8):
+        """SearchKeyFrameCorrespondence (cpp/src/main.cc:18-29): first index in `cur` closer than tolerance."""
+        k, c = self._desc(key), self._desc(cur)
+        out = torch.empty(k.shape[0], dtype=torch.int32, device=self.torch_device)
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_first_within(self._ctx, k.data_ptr(), k.shape[0], c.data_ptr(), c.shape[0],
+                                            float(tolerance), out.data_ptr()), "fpc_first_within")
+        self.sync()
+        return out.cpu().numpy()
+
     # -- timing ----------------------------------------------------------------------
     def set_timing(self, on):
         _lib.check(self._l.fpc_set_timing(self._ctx, int(bool(on))), "fpc_set_timing")

@@ -112,6 +112,21 @@ def get_descriptors(points, descriptors_map, img_h, img_w, settings, engine=None
                               "points and descriptors are produced in one device pass")
 
 
+def get_features(frame, net):
+    """python/src/inference.py:99-104: rows [x, y, confidence, descriptor(128)]."""
+    points, descriptors = net.run(frame)
+    return np.hstack((points.T, descriptors.T))
+
+
+def get_best_correspondences(stop_features, features, engine):
+    """python/src/inference.py:88-96 (cv2.BFMatcher(NORM_L2, crossCheck=True)) on the GPU:
+    -> (rows of `features` that found a mutual nearest neighbour, their indices into `stop_features`)."""
+    match, _ = engine.match(features[:, 3:].astype(np.float32), stop_features[:, 3:].astype(np.float32),
+                            cross_check=True)
+    keep = np.flatnonzero(match >= 0)
+    return features[keep], match[keep]
+
+
 def _points_array(xy, conf):
     pts = np.zeros((3, len(conf)))
     pts[0], pts[1], pts[2] = xy[:, 0], xy[:, 1], conf

@@ -132,6 +132,21 @@ int fpc_detect(fpc_ctx* ctx, const float* frames_dev, int n);
  * sampled from desc_nchw_dev [n,128,H/8,W/8] when it is not NULL. */
 int fpc_get_points(fpc_ctx* ctx, const float* prob_map_dev, const float* desc_nchw_dev, int n);
 
+/* --- next row of the path: descriptor matching ----------------
+ * ~ cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(query, train) (python/src/inference.py:88-96):
+ * for every query descriptor the nearest train descriptor in L2 (ties: lower index); with
+ * cross_check != 0 only mutual nearest neighbours survive; with max_dist > 0 only matches closer
+ * than max_dist.  q [nq][128], t [nt][128], match [nq] (train index or -1), dist [nq] (L2
+ * distance to the nearest train descriptor; may be NULL) -- all device pointers; nq, nt <=
+ * the ctx's keypoint capacity.  Asynchronous on the ctx stream. */
+int fpc_match(fpc_ctx* ctx, const float* q_dev, int nq, const float* t_dev, int nt, int cross_check,
+              float max_dist, int32_t* match_dev, float* dist_dev);
+/* ~ SearchKeyFrameCorrespondence (cpp/src/main.cc:18-29,79-83): for every key-frame descriptor the
+ * index of the FIRST current-frame descriptor (in the order given, i.e. descending confidence)
+ * whose L2 distance is below `tolerance` (cpp/src/main.cc:54: 0.8), or -1. */
+int fpc_first_within(fpc_ctx* ctx, const float* key_dev, int nk, const float* cur_dev, int nc,
+                     float tolerance, int32_t* first_dev);
+
 int fpc_results(fpc_ctx* ctx, fpc_device_results* out);
 /* Synchronises, then copies the per-frame counts to the host. */
 int fpc_get_counts(fpc_ctx* ctx, int n, int32_t* count_host, int32_t* n_candidates_host);

@@ -460,3 +460,65 @@ void oracle_get_descriptors(const float* desc_map, int D, int Hc, int Wc, int H,
     for (int d = 0; d < D; ++d) out[(size_t)k * D + d] /= nrm;
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* Descriptor matching.                        */
+/* PARITY UNPINNED for this block: the Python flavour is OpenCV's             */
+/* cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(query, train)            */
+/* (python/src/inference.py:88-96) and cv2 is not installed here, so no        */
+/* golden vectors could be produced; the semantics below restate OpenCV's     */
+/* documented behaviour (nearest train descriptor per query, first minimum,   */
+/* cross check = the query is also the nearest of its match).  The C++        */
+/* flavour restates cpp/src/main.cc:9-29 (DescriptorDist,                     */
+/* SearchKeyFrameCorrespondence), which cannot be built here either           */
+/* (OpenCV / TRTorch).                                                        */
+/* ------------------------------------------------------------------------- */
+static double l2_dist(const float* a, const float* b, int D) {
+  double sum = 0; /* cpp/src/main.cc:11-15: float differences, double accumulation */
+  for (int i = 0; i < D; ++i) sum += (double)((a[i] - b[i]) * (a[i] - b[i]));
+  return sqrt(sum);
+}
+
+void oracle_match(const float* q, int nq, const float* t, int nt, int D, int cross_check,
+                  float max_dist, int32_t* match, float* dist) {
+  int32_t* tbest = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1));
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < nt; ++j) {
+    double bd = 1e300;
+    int bi = -1;
+    for (int i = 0; i < nq; ++i) {
+      const double d = l2_dist(q + (size_t)i * D, t + (size_t)j * D, D);
+      if (d < bd) { bd = d; bi = i; }
+    }
+    tbest[j] = bi;
+  }
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nq; ++i) {
+    double bd = 1e300;
+    int bj = -1;
+    for (int j = 0; j < nt; ++j) {
+      const double d = l2_dist(q + (size_t)i * D, t + (size_t)j * D, D);
+      if (d < bd) { bd = d; bj = j; }
+    }
+    int ok = bj >= 0;
+    if (ok && cross_check) ok = tbest[bj] == i;
+    if (ok && max_dist > 0.f) ok = bd < (double)max_dist;
+    match[i] = ok ? bj : -1;
+    if (dist) dist[i] = bj >= 0 ? (float)bd : 0.f;
+  }
+  free(tbest);
+}
+
+/* SearchKeyFrameCorrespondence, cpp/src/main.cc:18-29: first current-frame point below the tolerance */
+void oracle_first_within(const float* key, int nk, const float* cur, int nc, int D, double tolerance,
+                         int32_t* first) {
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    first[k] = -1;
+    for (int j = 0; j < nc; ++j)
+      if (l2_dist(cur + (size_t)j * D, key + (size_t)k * D, D) < tolerance) {
+        first[k] = j;
+        break;
+      }
+  }
+}

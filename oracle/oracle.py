@@ -124,3 +124,26 @@ def get_descriptors(desc_map, xs, ys, h, w):
         lib().oracle_get_descriptors(_p(desc_map), d, hc, wc, h, w, xs.ctypes.data_as(_i32p),
                                      ys.ctypes.data_as(_i32p), k, _p(out))
     return out
+
+
+def match(query, train, cross_check=True, max_dist=0.0):
+    """BFMatcher(NORM_L2, crossCheck).match restated (parity unpinned: cv2 is absent) -> (match, dist)."""
+    q = np.ascontiguousarray(query, np.float32)
+    t = np.ascontiguousarray(train, np.float32)
+    m = np.full(len(q), -1, np.int32)
+    d = np.zeros(len(q), np.float32)
+    if len(q):
+        lib().oracle_match(_p(q), len(q), _p(t), len(t), q.shape[1], int(bool(cross_check)),
+                           ctypes.c_float(max_dist), m.ctypes.data_as(_i32p), _p(d))
+    return m, d
+
+
+def first_within(key, cur, tolerance=0.8):
+    """SearchKeyFrameCorrespondence (cpp/src/main.cc:18-29) restated -> first index or -1 per key descriptor."""
+    k = np.ascontiguousarray(key, np.float32)
+    c = np.ascontiguousarray(cur, np.float32)
+    out = np.full(len(k), -1, np.int32)
+    if len(k):
+        lib().oracle_first_within(_p(k), len(k), _p(c), len(c), k.shape[1], ctypes.c_double(tolerance),
+                                  out.ctypes.data_as(_i32p))
+    return out

@@ -338,3 +338,59 @@ def test_cpp_entry_point(torch_gpu, tmp_path):
     np.testing.assert_allclose(got[:, 3:6], d[:, 0:3], atol=1e-6)
     np.testing.assert_allclose(got[:, 6], d[:, 127], atol=1e-6)
     e.close()
+
+
+def test_hd_frames_and_odd_batch(torch_gpu):
+    """BASELINE.json configs[4] geometry (1280x960) in fp32, and a batch that does not split evenly
+    over the sub-batch streams: dense maps against the oracle, post-processing exact."""
+    h, w, n = 960, 1280, 3
+    sd = synth.make_state_dict(5, dustbin_bias=7.0)
+    frames = synth.make_batch(700, n, h, w)
+    e = engine(h, w, n)
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(frames)
+    res = e.detect(frames)
+    oracle = oracle_mod()
+    o_prob, o_desc, o_logits = oracle.forward(frames[2:3], sd, SPEC)
+    assert np.max(np.abs(logits[2].cpu().numpy() - o_logits[0])) < ATOL
+    assert np.max(np.abs(desc[2].cpu().numpy() - o_desc[0])) < ATOL
+    assert np.max(np.abs(prob[2].cpu().numpy() - o_prob[0])) < ATOL
+    for i in range(n):
+        _check_frame_against_oracle_postproc(oracle, prob[i].cpu().numpy(), desc[i].cpu().numpy(), res[i], h, w)
+        assert len(res[i][1]) > 1000
+    e.close()
+
+
+def test_descriptor_matching(torch_gpu):
+    """Next row: brute-force L2 matching with cross check (inference.py:88-96) and
+    first-within-tolerance (cpp/src/main.cc:18-29) against the CPU restatement.  Parity for this row
+    is unpinned (cv2 is not installed, no golden vectors); indices must agree exactly on tie-safe data."""
+    oracle = oracle_mod()
+    h, w = 240, 320
+    sd = synth.make_state_dict(21, dustbin_bias=7.0)
+    e = engine(h, w, 2)
+    e.load_state_dict(sd)
+    res = e.detect(synth.make_batch(300, 2, h, w))
+    da, db = res[0][2], res[1][2]                       # real unit-norm descriptors of two frames
+    assert len(da) > 300 and len(db) > 300
+    rng = np.random.Generator(np.random.PCG64(3))
+    db_near = (da[rng.permutation(len(da))[:400]] + rng.normal(0, 0.02, (400, 128))).astype(np.float32)  # true matches
+    db_near /= np.linalg.norm(db_near, axis=1, keepdims=True)
+    for q, t in ((da, db), (da, db_near), (db_near, da), (da[:1], db), (da[:130], db[:129])):
+        for cross, md in ((True, 0.0), (False, 0.0), (True, 0.7)):
+            m, d = e.match(q, t, cross, md)
+            om, od = oracle.match(q, t, cross, md)
+            np.testing.assert_array_equal(m, om)
+            np.testing.assert_allclose(d, od, rtol=0, atol=2e-5)
+        np.testing.assert_array_equal(e.first_within(q, t, 0.8), oracle.first_within(q, t, 0.8))
+        np.testing.assert_array_equal(e.first_within(q, t, 0.3), oracle.first_within(q, t, 0.3))
+    m, _ = e.match(da, db_near, True)
+    assert (m >= 0).sum() >= 100                        # planted pairs survive the cross check
+    m, _ = e.match(da, np.zeros((0, 128), np.float32))
+    assert (m == -1).all()
+    from fpc_amd.inference import get_best_correspondences
+    fa = np.hstack((np.zeros((len(da), 3)), da))
+    fb = np.hstack((np.zeros((len(db_near), 3)), db_near))
+    corr, idx = get_best_correspondences(fb, fa, e)
+    assert len(corr) == len(idx) and len(idx) >= 100
+    e.close()
