@@ -105,6 +105,7 @@ def main():
     rank, world, local = fdist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    local = local % max(1, torch.cuda.device_count())   # (a gloo rehearsal may put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -22,11 +22,15 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # FPC_DIST_BACKEND=gloo: rehearse the N>1 path with several ranks on ONE GPU (RCCL refuses
+            # two ranks on the same device); the data path has no collective, so only start-up differs
+            backend = os.environ.get("FPC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -50,11 +54,23 @@ def broadcast_packed_weights(engine, state_dict, src=0):
     if rank == src:
         engine.load_state_dict(state_dict)
     if dist.get_backend() == "nccl":
-        view = engine.packed_view()
-        dist.broadcast(view, src=src)
-        torch.cuda.synchronize()
-        if rank != src:
-            engine.mark_weights_loaded()
+        # RCCL broadcast over xGMI, device to device.  Preferred: straight into the library's blob
+        # (zero copies); if aliasing library memory as a tensor is not possible in this torch build,
+        # through a torch-owned device buffer and one host round trip (start-up only).
+        try:
+            view = engine.packed_view()
+            dist.broadcast(view, src=src)
+            torch.cuda.synchronize()
+            if rank != src:
+                engine.mark_weights_loaded()
+        except (RuntimeError, TypeError, ValueError):
+            n = engine.packed_size()
+            dev = torch.device("cuda", torch.cuda.current_device())
+            buf = (torch.from_numpy(engine.export_packed()).to(dev) if rank == src
+                   else torch.empty(n, dtype=torch.uint8, device=dev))
+            dist.broadcast(buf, src=src)
+            if rank != src:
+                engine.import_packed(buf.cpu().numpy())
     else:
         n = engine.packed_size()
         buf = torch.from_numpy(engine.export_packed()) if rank == src else torch.empty(n, dtype=torch.uint8)

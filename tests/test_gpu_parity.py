@@ -394,3 +394,31 @@ def test_descriptor_matching(torch_gpu):
     corr, idx = get_best_correspondences(fb, fa, e)
     assert len(corr) == len(idx) and len(idx) >= 100
     e.close()
+
+
+def test_packed_weight_blob_round_trip(torch_gpu):
+    """The blob rank 0 broadcasts: the zero-copy tensor view aliases the library's buffer, and an
+    engine that only ever received the blob computes the same results."""
+    torch = torch_gpu
+    h, w = 64, 96
+    sd = synth.make_state_dict(9, dustbin_bias=4.0)
+    frame = synth.make_batch(11, 1, h, w)
+    a = engine(h, w)
+    a.load_state_dict(sd)
+    blob = a.export_packed()
+    view = a.packed_view()
+    assert view.dtype == torch.uint8 and view.numel() == a.packed_size() == blob.nbytes
+    np.testing.assert_array_equal(view.cpu().numpy(), blob)
+    b = engine(h, w)
+    vb = b.packed_view()
+    vb.copy_(view)                       # what dist.broadcast does on the receiving ranks
+    torch.cuda.synchronize()
+    b.mark_weights_loaded()
+    ra, rb = a.detect(frame)[0], b.detect(frame)[0]
+    np.testing.assert_array_equal(ra[0], rb[0])
+    np.testing.assert_array_equal(ra[2], rb[2])
+    c = engine(h, w)
+    c.import_packed(blob)
+    np.testing.assert_array_equal(c.detect(frame)[0][2], ra[2])
+    for e in (a, b, c):
+        e.close()
