@@ -422,3 +422,41 @@ def test_packed_weight_blob_round_trip(torch_gpu):
     np.testing.assert_array_equal(c.detect(frame)[0][2], ra[2])
     for e in (a, b, c):
         e.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"FPC_WINOGRAD": "0"},                                   # direct fused blocks everywhere
+    {"FPC_WINOGRAD_DET": "0"},                               # Winograd encoder/descriptor, direct detector
+    {"FPC_FUSE": "0", "FPC_FUSE_STEM": "0"},                 # one launch per convolution, separate max-pool
+    {"FPC_STREAMS": "1", "FPC_SPLIT_HEADS": "0"},            # everything on one stream
+    {"FPC_STREAMS": "3", "FPC_NMS_PASSES": "0"},             # three sub-batches; NMS finished by the sort kernel alone
+    {"FPC_PERSIST_MIN": "0"},                                # Winograd kernel with one workgroup per tile
+])
+def test_alternative_plans_agree(torch_gpu, golden_dir, env):
+    """Every launch plan the library can be switched to (environment knobs read at fpc_create) must
+    meet the same bar: dense maps within 1e-4 of the reference's probes, keypoint set identical."""
+    g = np.load(os.path.join(golden_dir, "f5_e2e_qvga.npz"))
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frames = np.repeat(synth.make_batch(int(g["seed_frame"]), 1, h, w), 13, axis=0)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = engine(h, w, 13)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(frames)
+    np.testing.assert_allclose(logits[12].cpu().numpy().ravel()[::7], g["logits_probe"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(desc[5].cpu().numpy().ravel()[::11], g["desc_map_probe"], rtol=0, atol=ATOL)
+    res = e.detect(frames)
+    gx, gy = g["points_x"].astype(np.int64), g["points_y"].astype(np.int64)
+    for i in (0, 6, 12):
+        xy, conf, d, ncand = res[i]
+        assert ncand == int(g["n_candidates"])
+        np.testing.assert_array_equal(np.sort(xy[:, 1].astype(np.int64) * w + xy[:, 0]), np.sort(gy * w + gx))
+    e.close()
