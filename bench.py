@@ -97,6 +97,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("FPC_BENCH_CONTEXTS", "1")),
+                    help="fpc contexts used round-robin (double buffering: batch k+1 starts while batch k drains)")
+    ap.add_argument("--gray", action="store_true",
+                    help="feed gray frames [n,1,H,W] (in_channels=1: stem filters summed over the input channels); "
+                         "default is the reference network's 3-channel input")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra one-stream pass that gives clean per-kernel durations")
     ap.add_argument("--no-timing-events", action="store_true",
                     help="do not bracket launches with HIP events (roofline then comes from a separate pass)")
@@ -111,46 +116,55 @@ def main():
 
     # synthetic checkpoint in the reference's layout; rank 0 packs and broadcasts it
     sd = synth.make_state_dict(0, dustbin_bias=7.0) if rank == 0 else None
-    eng = Engine(H, W, max_batch=BATCH, device=local)
+    cin = 1 if args.gray else 3
+    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin)
     fdist.broadcast_packed_weights(eng, sd)
+    engs = [eng]
+    for _ in range(1, max(1, args.contexts)):
+        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin)
+        e2.import_packed(eng.export_packed())
+        engs.append(e2)
     # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
-    frames_np = synth.make_batch(100 + BATCH * rank, BATCH, H, W)
+    frames_np = synth.make_batch(100 + BATCH * rank, BATCH, H, W, gray=args.gray)
+    if args.gray:
+        frames_np = np.ascontiguousarray(frames_np[:, :1])
     frames = torch.from_numpy(frames_np).to(dev)
     torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        eng.detect_async(frames, BATCH)
-    eng.sync()
+    for i in range(args.warmup):
+        engs[i % len(engs)].detect_async(frames, BATCH)
+    for e_ in engs:
+        e_.sync()
     cnt, ncand = eng.counts(BATCH)
 
     use_events = not args.no_timing_events
-    eng.set_timing(use_events)
+    for e_ in engs:
+        e_.set_timing(use_events)
     per_kernel, per_symbol = {}, {}
     fdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.detect_async(frames, BATCH)
-        if use_events:
-            # events of a step are read back after the step has drained; the next step's
-            # launches are already queued behind it, so the GPU does not idle
-            pass
-    eng.sync()
+    for i in range(args.steps):
+        engs[i % len(engs)].detect_async(frames, BATCH)
+    for e_ in engs:
+        e_.sync()
     torch.cuda.synchronize(dev)
     fdist.barrier()
     dt = time.perf_counter() - t0
     if use_events:
         # every launch of the timed region: layer name / kernel symbol -> [(ms, algorithmic flops, mfma flops)]
-        for name, kern, ms, fl, mf in eng.timings():
-            per_kernel.setdefault(name, []).append((ms, fl, mf))
-    timed_timings = eng.timings() if use_events else []
-    eng.set_timing(False)
+        for e_ in engs:
+            for name, kern, ms, fl, mf in e_.timings():
+                per_kernel.setdefault(name, []).append((ms, fl, mf))
+    timed_timings = [t for e_ in engs for t in e_.timings()] if use_events else []
+    for e_ in engs:
+        e_.set_timing(False)
     dt = fdist.max_over_ranks(dt)
     serial = None
     if use_events and rank == 0 and world == 1 and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
         os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"] = "1", "0"
-        e1 = Engine(H, W, max_batch=BATCH, device=local)
+        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
             e1.detect_async(frames, BATCH)
@@ -177,7 +191,7 @@ def main():
             "data": "synthetic (seeded frames + seeded checkpoint in the reference's layout)",
             "config": {"workload": "batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
                                    "(BASELINE.json configs[1]; configs[2] when n_gpus=8)",
-                       "frames_per_step_per_gpu": BATCH, "height": H, "width": W,
+                       "frames_per_step_per_gpu": BATCH, "height": H, "width": W, "input_channels": cin,
                        "parallelism": "frame-sharded x%d, no data-path collective" % world},
             "frames_per_sec_per_gpu": round(value / world, 2),
             "whole_path_tflops": round(value * flops_frame / 1e12, 3),
@@ -210,9 +224,11 @@ def main():
                     lay.setdefault(name, []).append(ms)
                 out["layer_ms_serial"] = {k: round(float(np.mean(v)), 4) for k, v in lay.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, frames_np[:8])
+            cb_frames = frames_np[:8] if not args.gray else np.repeat(frames_np[:8], 3, axis=1)
+            out["cpu_baseline"] = cpu_baseline(sd, cb_frames)
         print(json.dumps(out))
-    eng.close()
+    for e_ in engs:
+        e_.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

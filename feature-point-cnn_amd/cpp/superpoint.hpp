@@ -66,16 +66,13 @@ class SuperPoint {
 
   // frame: rows x cols floats (gray)
   std::vector<FeaturePoint> ProcessFrame(const float* frame, int rows, int cols) {
-    ensure(rows, cols);
-    const size_t hw = (size_t)rows * cols;
-    staging_.resize(3 * hw);
-    for (int c = 0; c < 3; ++c) std::copy(frame, frame + hw, staging_.begin() + c * hw);
-    hip(hipMemcpy(frame_dev_, staging_.data(), 3 * hw * sizeof(float), hipMemcpyHostToDevice), "upload");
+    ensure(rows, cols, 1);   // gray plane as is: the library sums the stem filters over the input channels
+    hip(hipMemcpy(frame_dev_, frame, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice), "upload");
     return run();
   }
   // frame: 3 x rows x cols planar RGB
   std::vector<FeaturePoint> ProcessFrameRGB(const float* chw, int rows, int cols) {
-    ensure(rows, cols);
+    ensure(rows, cols, 3);
     hip(hipMemcpy(frame_dev_, chw, (size_t)3 * rows * cols * sizeof(float), hipMemcpyHostToDevice), "upload");
     return run();
   }
@@ -98,8 +95,8 @@ class SuperPoint {
     if (frame_dev_) (void)hipFree(frame_dev_);
     frame_dev_ = nullptr;
   }
-  void ensure(int rows, int cols) {
-    if (ctx_ && rows == rows_ && cols == cols_) return;
+  void ensure(int rows, int cols, int channels) {
+    if (ctx_ && rows == rows_ && cols == cols_ && channels == channels_) return;
     release();
     fpc_config cfg;
     chk(fpc_default_config(&cfg), "fpc_default_config");
@@ -107,6 +104,7 @@ class SuperPoint {
     cfg.height = rows;
     cfg.width = cols;
     cfg.max_batch = 1;
+    cfg.in_channels = channels;
     cfg.nms_dist = settings_.nms_dist;
     cfg.conf_thresh = settings_.confidence_thresh;
     cfg.border_remove = settings_.border_remove;
@@ -126,6 +124,7 @@ class SuperPoint {
     hip(hipMalloc((void**)&frame_dev_, (size_t)3 * rows * cols * sizeof(float)), "hipMalloc");
     rows_ = rows;
     cols_ = cols;
+    channels_ = channels;
   }
   std::vector<FeaturePoint> run() {
     chk(fpc_detect(ctx_, frame_dev_, 1), "fpc_detect");
@@ -148,12 +147,12 @@ class SuperPoint {
   }
 
   Settings settings_;
-  int device_ = 0, rows_ = 0, cols_ = 0;
+  int device_ = 0, rows_ = 0, cols_ = 0, channels_ = 0;
   fpc_pt::Checkpoint ckpt_;
   fpc_ctx* ctx_ = nullptr;
   float* frame_dev_ = nullptr;
   // memory management buffers (superpoint.h:31-35)
-  std::vector<float> staging_, conf_, desc_;
+  std::vector<float> conf_, desc_;
   std::vector<int32_t> xy_;
   std::vector<FeaturePoint> feature_points_;
 };

@@ -202,6 +202,7 @@ using namespace fpc;
 struct fpc_ctx {
   fpc_config cfg{};
   int H = 0, W = 0, B = 0, Hc = 0, Wc = 0;
+  int cin = 3;                       // 3: [n,3,H,W] frames (the reference's layout); 1: gray [n,1,H,W]
   int cap = 0, sort_cap = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -524,7 +525,7 @@ static int build_plan(fpc_ctx* c) {
     Op op;
     op.type = OP_STEM;
     op.name = "encoder.conv1+bn1+relu";
-    op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;
+    op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;  // of the reference's 3-channel convolution, also for gray frames
     op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
     c->ops.push_back(op);
     c->convw.push_back({});
@@ -701,12 +702,19 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
     Fold f;
     if (!w || !fold_bn(m, "encoder.bn1", 64, &f, missing)) return FPC_E_MISSING_KEY;
     float* dst = blob.data() + c->stem_w_off;
-    for (int g = 0; g < STEM_KG; ++g)
+    const int kreal = c->cin * 49, kg = (kreal + 7) / 8;
+    for (int g = 0; g < kg; ++g)
       for (int nb = 0; nb < 2; ++nb)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 4; ++j) {
             const int k = g * 8 + 2 * j + (lane >> 5), n = nb * 32 + (lane & 31);
-            dst[(((size_t)g * 2 + nb) * 64 + lane) * 4 + j] = k < 147 ? (float)((double)w[n * 147 + k] * f.s[n]) : 0.f;
+            double v = 0.0;
+            if (k < kreal) {
+              if (c->cin == 3) v = (double)w[n * 147 + k];
+              else  // gray frame == the same plane in all three channels: sum the three filters
+                v = (double)w[n * 147 + k] + (double)w[n * 147 + 49 + k] + (double)w[n * 147 + 98 + k];
+            }
+            dst[(((size_t)g * 2 + nb) * 64 + lane) * 4 + j] = (float)(v * f.s[n]);
           }
     for (int n = 0; n < 64; ++n) blob[c->stem_b_off + n] = (float)f.t[n];
   }
@@ -949,18 +957,21 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
     if (br != which) continue;
     switch (op.type) {
       case OP_STEM: {
-        if (c->fuse_stem_pool) {
+        if (c->fuse_stem_pool || c->cin == 1) {
           float* x0 = c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
           hipMemsetAsync(x0, 0, (size_t)n * (H / 4) * (W / 4) * 64 * sizeof(float), sb.st);
           LaunchTimer t(c, (int)i, sb.st, n);
           StemPoolArgs a{};
-          a.in = frames + (size_t)f0 * 3 * H * W;
+          a.in = frames + (size_t)f0 * c->cin * H * W;
           a.wfrag = c->stem.wfrag;
           a.bias = c->stem.bias;
           a.out = x0;
           a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Hp = H / 4; a.Wp = W / 4;
           a.tiles_x = c->stem.tiles_x; a.tiles_y = c->stem.tiles_y;
-          hipLaunchKernelGGL(stem_pool_kernel, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
+          if (c->cin == 1)
+            hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
+          else
+            hipLaunchKernelGGL(stem_pool_kernel<3>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
           break;
         }
         LaunchTimer t(c, (int)i, sb.st, n);
@@ -971,7 +982,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         break;
       }
       case OP_POOL: {
-        if (c->fuse_stem_pool) break;
+        if (c->fuse_stem_pool || c->cin == 1) break;
         LaunchTimer t(c, (int)i, sb.st, n);
         const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
         hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sb.st,
@@ -1179,6 +1190,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   // the descriptor head halves the 1/8 map and doubles it again (superpoint.py:43-59): odd
   // H/8 or W/8 breaks its concat, so frames must be multiples of 16 unless it is disabled
   const int mult = cfg->descriptor_enabled ? 16 : 8;
+  if (cfg->in_channels != 0 && cfg->in_channels != 1 && cfg->in_channels != 3) return FPC_E_INVALID;
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30))
@@ -1201,6 +1213,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->B = cfg->max_batch;
   c->Hc = c->H / 8;
   c->Wc = c->W / 8;
+  c->cin = cfg->in_channels == 1 ? 1 : 3;
   // kept points are pairwise > nms_dist apart (infinity norm): at most one per (r+1)^2 cell
   const int r1 = cfg->nms_dist + 1;
   const int worst = ((c->H + r1 - 1) / r1) * ((c->W + r1 - 1) / r1);

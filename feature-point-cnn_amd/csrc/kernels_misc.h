@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
 // ---------------------------------------------------------------------------------
 struct StemPoolArgs {
   const float* in;      // [B,3,H,W]
-  const float4* wfrag;  // [19 + 2][2][64] float4 (two zero groups of prefetch padding)
+  const float4* wfrag;  // [KG + 2][2][64] float4 (two zero groups of prefetch padding); KG = 19 (RGB) / 7 (gray)
   const float* bias;    // [64]
   float* out;           // [B,Hp,Wp,64], zero-filled
   int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
@@ -127,7 +127,15 @@ constexpr int STEM_TROW = 33;  // floats per pixel of the epilogue tile (32 chan
 constexpr int STEM_POOL_LDS_FLOATS =
     STEM_LDS_FLOATS > 256 * STEM_TROW ? STEM_LDS_FLOATS : 256 * STEM_TROW;
 
+template <int KREAL>
+__device__ __forceinline__ constexpr int stem_koff_c(int k) {
+  k = k < KREAL ? k : KREAL - 1;  // padded k: weight is zero, any valid address will do
+  return (k / 49) * (STEM_HALO * STEM_LW) + ((k % 49) / 7) * STEM_LW + (k % 7);
+}
+
+template <int CIN>
 __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
+  constexpr int KREAL = CIN * 49, KG = (KREAL + 7) / 8;  // 147 -> 19 groups of 8; 49 -> 7
   __shared__ float lds[STEM_POOL_LDS_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   q1[1] = wp[192];
 
   {  // input window -> LDS: all loads of a thread are issued before the first LDS write
-    constexpr int NE = 3 * STEM_HALO * STEM_HALO, IT = (NE + 255) / 256;
+    constexpr int NE = CIN * STEM_HALO * STEM_HALO, IT = (NE + 255) / 256;
     float v[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
       const int hy = r / STEM_HALO, hx = r - hy * STEM_HALO;
       const int iy = iy0 + hy, ix = ix0 + hx;
       const bool ok = e < NE && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float x = a.in[ok ? ((size_t)(b * 3 + c) * a.H + iy) * a.W + ix : 0];
+      const float x = a.in[ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0];
       v[i] = ok ? x : 0.f;
     }
 #pragma unroll
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-  for (int g = 0; g < STEM_KG; ++g) {
+  for (int g = 0; g < KG; ++g) {
     float4 q2[2];
     q2[0] = wp[((g + 2) * 2 + 0) * 64];
     q2[1] = wp[((g + 2) * 2 + 1) * 64];
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k0 = g * 8 + 2 * j;  // lanes 0-31 take k0, lanes 32-63 take k0+1
-      const int off = half ? stem_koff(k0 + 1) : stem_koff(k0);
+      const int off = half ? stem_koff_c<KREAL>(k0 + 1) : stem_koff_c<KREAL>(k0);
       const float bf0 = j == 0 ? q0[0].x : j == 1 ? q0[0].y : j == 2 ? q0[0].z : q0[0].w;
       const float bf1 = j == 0 ? q0[1].x : j == 1 ? q0[1].y : j == 2 ? q0[1].z : q0[1].w;
 #pragma unroll

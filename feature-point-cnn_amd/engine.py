@@ -43,7 +43,7 @@ def _as_tensor_table(state_dict):
 
 class Engine:
     def __init__(self, height, width, max_batch=1, device=0, nms_dist=4, conf_thresh=0.015,
-                 border_remove=4, descriptor_enabled=True, max_keypoints=0):
+                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3):
         self._l = _lib.load()          # raises if libfpc.so is not built: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("fpc_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -53,6 +53,8 @@ class Engine:
         cfg.device, cfg.height, cfg.width, cfg.max_batch = device, height, width, max_batch
         cfg.nms_dist, cfg.conf_thresh, cfg.border_remove = nms_dist, conf_thresh, border_remove
         cfg.descriptor_enabled, cfg.max_keypoints = int(bool(descriptor_enabled)), max_keypoints
+        cfg.in_channels = in_channels
+        self.in_channels = 1 if in_channels == 1 else 3
         self.cfg = cfg
         self.h, self.w, self.max_batch, self.device = height, width, max_batch, device
         self.descriptor_enabled = bool(descriptor_enabled)
@@ -114,8 +116,8 @@ class Engine:
         if not isinstance(frames, torch.Tensor):
             frames = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32))
         frames = frames.to(self.torch_device, torch.float32).contiguous()
-        if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[2] != self.h or frames.shape[3] != self.w:
-            raise ValueError("frames must be [n,3,%d,%d], got %s" % (self.h, self.w, tuple(frames.shape)))
+        if frames.dim() != 4 or frames.shape[1] != self.in_channels or frames.shape[2] != self.h or frames.shape[3] != self.w:
+            raise ValueError("frames must be [n,%d,%d,%d], got %s" % (self.in_channels, self.h, self.w, tuple(frames.shape)))
         if frames.shape[0] > self.max_batch:
             raise ValueError("batch %d > max_batch %d" % (frames.shape[0], self.max_batch))
         return frames

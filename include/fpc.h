@@ -54,7 +54,10 @@ typedef struct fpc_config {
   int border_remove;      /* 4   settings.py:8                                     */
   int descriptor_enabled; /* 0 = MagicPoint, detector only (superpoint.py:103-109) */
   int max_keypoints;      /* per-frame output capacity; 0 = worst case for nms_dist */
-  int reserved[7];
+  int in_channels;        /* 0 or 3: frames [n,3,H,W] (superpoint.py:12); 1: gray frames   */
+                          /* [n,1,H,W] -- what the reference feeds after replicating the   */
+                          /* plane x3 (dataset_utils.py:19-20, cpp/src/camera.cc:17-18)    */
+  int reserved[6];
 } fpc_config;
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']
@@ -114,7 +117,8 @@ int fpc_set_stream(fpc_ctx* ctx, void* hip_stream);
 void* fpc_get_stream(fpc_ctx* ctx);
 int fpc_sync(fpc_ctx* ctx);
 
-/* ~ SuperPoint.forward (python/src/superpoint.py:91-115): frames [n,3,H,W] float32
+/* ~ SuperPoint.forward (python/src/superpoint.py:91-115): frames [n,3,H,W] ([n,1,H,W] with
+ * in_channels = 1) float32
  * on the device -> prob_map [n,H,W], desc [n,128,H/8,W/8], logits [n,65,H/8,W/8]
  * (device, NCHW like the reference; any output may be NULL).  Asynchronous. */
 int fpc_forward(fpc_ctx* ctx, const float* frames_dev, int n, float* prob_map_dev,

@@ -328,9 +328,9 @@ def test_cpp_entry_point(torch_gpu, tmp_path):
     out = str(tmp_path / "pts.txt")
     msg = subprocess.check_output([demo, ck, str(tmp_path / "frame.f32"), str(h), str(w), out]).decode()
     got = np.loadtxt(out, ndmin=2)
-    e = engine(h, w)
+    e = engine(h, w, in_channels=1)       # ProcessFrame(gray) uploads the single plane
     e.load_state_dict(sd)
-    xy, conf, d, _ = e.detect(gray.transpose(2, 0, 1)[None])[0]
+    xy, conf, d, _ = e.detect(np.ascontiguousarray(gray[..., :1].transpose(2, 0, 1)[None]))[0]
     assert msg.startswith("%d feature points" % len(conf))
     np.testing.assert_array_equal(got[:, 0].astype(np.int32), xy[:, 0])
     np.testing.assert_array_equal(got[:, 1].astype(np.int32), xy[:, 1])
@@ -460,3 +460,28 @@ def test_alternative_plans_agree(torch_gpu, golden_dir, env):
         assert ncand == int(g["n_candidates"])
         np.testing.assert_array_equal(np.sort(xy[:, 1].astype(np.int64) * w + xy[:, 0]), np.sort(gy * w + gx))
     e.close()
+
+
+def test_gray_frames_equal_replicated_rgb(torch_gpu):
+    """in_channels = 1: a gray frame [n,1,H,W] gives what the reference computes after replicating the
+    plane over 3 channels (dataset_utils.py:19-20) -- the stem filters are summed over the input channels."""
+    h, w, n = 240, 320, 3
+    sd = synth.make_state_dict(21, dustbin_bias=7.0)
+    rgb = np.stack([synth.make_frame(300 + i, h, w, gray=True).transpose(2, 0, 1) for i in range(n)])
+    gray = np.ascontiguousarray(rgb[:, :1])
+    e3 = engine(h, w, n)
+    e1 = engine(h, w, n, in_channels=1)
+    e3.load_state_dict(sd)
+    e1.load_state_dict(sd)
+    p3, d3, l3 = e3.forward(rgb)
+    p1, d1, l1 = e1.forward(gray)
+    assert float((l3 - l1).abs().max()) < 2e-5 and float((d3 - d1).abs().max()) < 2e-5
+    o_prob, o_desc, o_logits = oracle_mod().forward(rgb[:1], sd, SPEC)
+    assert np.max(np.abs(l1[0].cpu().numpy() - o_logits[0])) < ATOL
+    r3, r1 = e3.detect(rgb), e1.detect(gray)
+    for a, b in zip(r3, r1):
+        np.testing.assert_array_equal(np.sort(a[0][:, 1] * w + a[0][:, 0]), np.sort(b[0][:, 1] * w + b[0][:, 0]))
+    with pytest.raises(ValueError):
+        e1.forward(rgb)
+    e3.close()
+    e1.close()
