@@ -28,6 +28,8 @@ from fpc_amd import arch, dist as fdist, synth  # noqa: E402
 from fpc_amd.engine import Engine  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (dense, f32 in / f32 acc)
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # ibid.: BF16 MFMA dense = 16x the FP32 matrix rate (~2.5 PF)
+PEAK_TFLOPS = PEAK_F32_MFMA_TFLOPS
 BATCH = 32
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/): filled in
 # once measured; null until then.
@@ -59,8 +61,8 @@ def cpu_baseline(state_dict, frames):
         kept += len(xs)
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d of the bench's 640x480 frames, full path (forward + get_points + get_descriptors), "
-                      "oracle/fpc_oracle.c with %d OpenMP threads, %.1f s" % (n, threads, dt)}
+            "sample": "%d of the bench's %dx%d frames, full path (forward + get_points + get_descriptors), "
+                      "oracle/fpc_oracle.c with %d OpenMP threads, %.1f s" % (n, W, H, threads, dt)}
 
 
 def symbol_stats(timings, steps):
@@ -82,12 +84,13 @@ def symbol_stats(timings, steps):
 def roofline_entry(sym, st, step_ms):
     ach = st["flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12
     frames = BATCH * st["layers"] / max(1, st["launches_per_step"])
-    return {"bound": "mfma", "kernel": sym, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": (round(TRAFFIC_BYTES_PER_FRAME[sym] * frames) if sym in TRAFFIC_BYTES_PER_FRAME else None),
+    return {"bound": "mfma", "kernel": sym, "achieved": round(ach, 3), "peak": PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
+            "traffic": (round(TRAFFIC_BYTES_PER_FRAME[sym] * frames)
+                        if sym in TRAFFIC_BYTES_PER_FRAME and (H, W) == (480, 640) else None),
             "avg_launch_ms": round(st["avg_launch_ms"], 4), "frames_per_launch": frames,
             "flops_per_launch": st["flops"], "mfma_issued_flops_per_launch": st["mfma_flops"],
-            "mfma_issued_frac": round(st["mfma_flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "mfma_issued_frac": round(st["mfma_flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
             "launches_per_step": st["launches_per_step"], "share_of_step": round(st["total_ms"] / step_ms, 3)}
 
 
@@ -105,7 +108,14 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra one-stream pass that gives clean per-kernel durations")
     ap.add_argument("--no-timing-events", action="store_true",
                     help="do not bracket launches with HIP events (roofline then comes from a separate pass)")
+    ap.add_argument("--workload", choices=["vga32", "hd64-bf16"], default="vga32",
+                    help="vga32 = BASELINE.json configs[1] (the headline; default); hd64-bf16 = configs[4]: 64 frames of "
+                         "1280x960 per step, bf16 activations / weights with fp32 accumulation")
     args = ap.parse_args()
+    global H, W, BATCH, PEAK_TFLOPS
+    dtype = "f32"
+    if args.workload == "hd64-bf16":
+        H, W, BATCH, dtype, PEAK_TFLOPS = 960, 1280, 64, "bf16", PEAK_BF16_MFMA_TFLOPS
 
     rank, world, local = fdist.init_from_env()
     if world != args.gpus:
@@ -117,11 +127,11 @@ def main():
     # synthetic checkpoint in the reference's layout; rank 0 packs and broadcasts it
     sd = synth.make_state_dict(0, dustbin_bias=7.0) if rank == 0 else None
     cin = 1 if args.gray else 3
-    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin)
+    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype)
     fdist.broadcast_packed_weights(eng, sd)
     engs = [eng]
     for _ in range(1, max(1, args.contexts)):
-        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin)
+        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype)
         e2.import_packed(eng.export_packed())
         engs.append(e2)
     # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
@@ -164,7 +174,7 @@ def main():
     if use_events and rank == 0 and world == 1 and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
         os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"] = "1", "0"
-        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin)
+        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
             e1.detect_async(frames, BATCH)
@@ -183,19 +193,21 @@ def main():
     if rank == 0:
         value = total_frames / dt
         flops_frame = 2.0 * arch.conv_macs(H, W)
+        wl = ("batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
+              "(BASELINE.json configs[1]; configs[2] when n_gpus=8)") if dtype == "f32" else (
+              "batch=64 1280x960 frames per GPU, super_point checkpoint layout, bf16 activations/weights, fp32 "
+              "accumulation, fp32 post-processing (BASELINE.json configs[4])")
         out = {
-            "metric": "frames/sec (VGA 640x480) SuperPoint fwd+NMS+descriptors",
+            "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("VGA 640x480" if dtype == "f32" else "HD 1280x960"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (seeded frames + seeded checkpoint in the reference's layout)",
-            "config": {"workload": "batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
-                                   "(BASELINE.json configs[1]; configs[2] when n_gpus=8)",
-                       "frames_per_step_per_gpu": BATCH, "height": H, "width": W, "input_channels": cin,
+            "config": {"workload": wl, "frames_per_step_per_gpu": BATCH, "height": H, "width": W, "input_channels": cin,
                        "parallelism": "frame-sharded x%d, no data-path collective" % world},
             "frames_per_sec_per_gpu": round(value / world, 2),
             "whole_path_tflops": round(value * flops_frame / 1e12, 3),
-            "whole_path_frac_of_f32_mfma_peak": round(value / world * flops_frame / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "whole_path_frac_of_%s_mfma_peak" % dtype: round(value / world * flops_frame / 1e12 / PEAK_TFLOPS, 4),
             "keypoints_per_frame": round(float(np.mean(cnt)), 1),
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
         }
@@ -224,7 +236,8 @@ def main():
                     lay.setdefault(name, []).append(ms)
                 out["layer_ms_serial"] = {k: round(float(np.mean(v)), 4) for k, v in lay.items()}
         if world == 1 and not args.no_cpu_baseline:
-            cb_frames = frames_np[:8] if not args.gray else np.repeat(frames_np[:8], 3, axis=1)
+            ncb = 8 if H * W <= 480 * 640 else 2
+            cb_frames = frames_np[:ncb] if not args.gray else np.repeat(frames_np[:ncb], 3, axis=1)
             out["cpu_baseline"] = cpu_baseline(sd, cb_frames)
         print(json.dumps(out))
     for e_ in engs:

@@ -1,0 +1,334 @@
+// block_bf16.h -- the ResNetBlock / convolution kernels of block_mfma.h and conv_mfma.h with bf16
+// activations and weights and fp32 accumulation (`dtype = FPC_BF16`; BASELINE.json configs[4]:
+// 1280x960 frames, the large-activation regime).  Same structure -- halo tile in LDS, weights
+// pre-packed in MFMA lane order and read straight from global memory, h never leaves LDS, fused
+// shortcut, vectorised epilogue -- on v_mfma_f32_32x32x16_bf16 (16 channels per instruction: lane
+// (row = l & 31, half = l >> 5) supplies channels 8*half .. 8*half+7 as one 16-byte fragment).
+// Tensors are bf16 NHWC with the channel count padded to a multiple of 16 where they feed a GEMM's K.
+// The first block of the net reads the (fp32) stem output, the last detector / descriptor blocks write
+// fp32 so that the post-processing kernels are the same as in the fp32 path.
+#pragma once
+#include "conv_mfma.h"
+
+namespace fpc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;  // storage type
+
+__device__ __forceinline__ bf16_t f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
+  uint4 r;
+  r.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+  r.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+  r.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
+  r.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
+  return r;
+}
+
+struct BlockBfArgs {
+  const void* x;         // input NHWC: bf16 (or fp32 when in_f32), offset to its first channel
+  int csx, nchunk;       // pixel stride in ELEMENTS, Cin_pad / KC
+  int H, W;
+  int in_f32;
+  const uint4* w1;       // 3x3 fragments: step = (chunk*ntaps + tap)*K16 + k16, [step][nb][64] uint4 (+2 steps)
+  const float* b1;
+  int ntaps;             // 9 for a block; 1..4 for a ConvTranspose phase (conv_only)
+  int tapoff16[9];       // halo offset of each tap in 16-byte units
+  const uint4* w2;       // 1x1 fragments: k16_h steps over h, then k16_x over x
+  const float* b2;
+  int k16_h, k16_x;      // k16_x == 0: identity shortcut
+  int conv_only;         // 1: stop after phase 1 (bias, ReLU, store): ConvTranspose phases
+  void* out;             // bf16 (or fp32 when out_f32), offset to its first channel
+  int cso, out_f32;
+  int Ho, Wo, tiles_x, tiles_y, frame0;
+  int OH, OW, oys, oxs, oy0, ox0;   // output pixel = (y*oys + oy0, x*oxs + ox0) in an OH x OW buffer
+  int pad;               // halo origin = tile origin * S - pad
+};
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+struct BlockBfCfg {
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int HW = (TW - 1) * S + EXT, HH = (TH - 1) * S + EXT;
+  static constexpr int ROW16 = KC / 8 + 1;            // 16-byte units per halo pixel (+1 skew)
+  static constexpr int ROWH16 = CMIDP / 8 + 1;        // per h row
+  static constexpr int ROWO4 = CMIDP / 4 + 1;         // float4 per row of the fp32 output tile
+  static constexpr int M = WM * MB * 32, N = WN * NB * 32;
+  static constexpr int HALO_BYTES = HH * HW * ROW16 * 16;
+  static constexpr int H_BYTES = M * ROWH16 * 16;
+  static constexpr int O_BYTES = M * ROWO4 * 16;
+  static constexpr int LDS_BYTES = (HALO_BYTES > H_BYTES ? HALO_BYTES : H_BYTES) > O_BYTES
+                                       ? (HALO_BYTES > H_BYTES ? HALO_BYTES : H_BYTES) : O_BYTES;
+  static_assert(KC % 16 == 0 && CMIDP % 16 == 0 && CMIDP <= N, "bf16 MFMA consumes 16 channels per step");
+};
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockBfArgs a) {
+  using C = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
+  constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
+  constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, ROWH16 = C::ROWH16, ROWO4 = C::ROWO4, NBT = WN * NB;
+  extern __shared__ uint4 lds16[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bl = blockIdx.x / tiles;
+  const int b = a.frame0 + bl;
+  const int t = blockIdx.x - bl * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+
+  int abase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int m = (wm * MB + mb) * 32 + l31;
+    m = m < TH * TW ? m : TH * TW - 1;
+    const int py = m / TW, px = m - py * TW;
+    abase[mb] = ((py * S) * HW + px * S) * ROW16 + half;
+  }
+  constexpr int stepstride = NBT * 64;
+  const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
+
+  const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
+  uint4 stage[ITER];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC8, c8 = e - pix * KC8;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c8 * 8 : 0;
+      uint4 v;
+      if (a.in_f32) {
+        const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + off);
+        v = pack8(p[0], p[1]);
+      } else {
+        v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + off);
+      }
+      if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+      stage[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC8, c8 = e - pix * KC8;
+      if (NV % NT == 0 || e < NV) lds16[pix * ROW16 + c8] = stage[i];
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  // ---------------------------------------------------------------- phase 1: KxK conv
+  load_chunk(0);
+  uint4 b0[NB], b1[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b0[nb] = wp[nb * 64];
+  wp += stepstride;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
+  wp += stepstride;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    if (chunk) FPC_LDS_BARRIER();
+    store_chunk();
+    FPC_LDS_BARRIER();
+    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    for (int tap = 0; tap < a.ntaps; ++tap) {
+      const int toff = a.tapoff16[tap];
+#pragma unroll
+      for (int k = 0; k < K16; ++k) {
+        uint4 b2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = wp[nb * 64];
+        wp += stepstride;
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 av[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = lds16[abase[mb] + toff + k * 2];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
+                                                                  __builtin_bit_cast(bf16x8, b0[nb]), acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          b0[nb] = b1[nb];
+          b1[nb] = b2[nb];
+        }
+      }
+    }
+  }
+
+  if (!a.conv_only) {
+    // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (bf16)
+    const uint4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b0[nb] = wq[nb * 64];
+    wq += stepstride;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b1[nb] = wq[nb * 64];
+    wq += stepstride;
+    FPC_LDS_BARRIER();
+    {
+      bf16_t* hl = reinterpret_cast<bf16_t*>(lds16);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = (wn * NB + nb) * 32 + l31;
+        const float bias = a.b1[n];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = acc[mb][nb][r] + bias;
+            if (n < CMIDP) hl[m * (ROWH16 * 8) + n] = f2bf(v > 0.f ? v : 0.f);
+            acc[mb][nb][r] = 0.f;
+          }
+      }
+    }
+    FPC_LDS_BARRIER();
+    // -------------------------------------------------------------- phase 2a: K over h (LDS)
+    int hbase[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH16 + half;
+    for (int k = 0; k < a.k16_h; ++k) {
+      uint4 b2[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
+      wq += stepstride;
+      __builtin_amdgcn_sched_barrier(0);
+      uint4 av[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[mb] = lds16[hbase[mb] + k * 2];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
+                                                                __builtin_bit_cast(bf16x8, b0[nb]), acc[mb][nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        b0[nb] = b1[nb];
+        b1[nb] = b2[nb];
+      }
+    }
+    // -------------------------------------------------------------- phase 2b: K over x (projection)
+    if (a.k16_x > 0) {
+      size_t xoff[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        int m = (wm * MB + mb) * 32 + l31;
+        m = m < TH * TW ? m : TH * TW - 1;
+        const int py = m / TW, px = m - py * TW;
+        int y = (ty * TH + py) * S, x = (tx * TW + px) * S;
+        y = y < a.H ? y : a.H - 1;
+        x = x < a.W ? x : a.W - 1;
+        xoff[mb] = ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 8;
+      }
+      auto load_a = [&](int mb, int k) {
+        if (a.in_f32) {
+          const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + xoff[mb] + k * 16);
+          return pack8(p[0], p[1]);
+        }
+        return *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + xoff[mb] + k * 16);
+      };
+      uint4 an[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) an[mb] = load_a(mb, 0);
+      for (int k = 0; k < a.k16_x; ++k) {
+        uint4 b2[NB], av[MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
+        wq += stepstride;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          av[mb] = an[mb];
+          an[mb] = load_a(mb, k + 1 < a.k16_x ? k + 1 : k);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
+                                                                  __builtin_bit_cast(bf16x8, b0[nb]), acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          b0[nb] = b1[nb];
+          b1[nb] = b2[nb];
+        }
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue: fp32 tile -> LDS -> 8-channel vectors
+  FPC_LDS_BARRIER();
+  {
+    float* ol = reinterpret_cast<float*>(lds16);
+    const float* bptr = a.conv_only ? a.b1 : a.b2;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 32 + l31;
+      const float bias = bptr[n];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (n < CMIDP) ol[m * (ROWO4 * 4) + n] = acc[mb][nb][r] + bias;
+        }
+    }
+  }
+  FPC_LDS_BARRIER();
+  {
+    constexpr int C8 = CMIDP / 8;
+    constexpr int NE = TH * TW * C8, EIT = (NE + NT - 1) / NT;
+    const float4* ol4 = reinterpret_cast<const float4*>(lds16);
+    const int oyb = ty * TH, oxb = tx * TW;
+    const bool ident = !a.conv_only && a.k16_x == 0;
+#pragma unroll
+    for (int i = 0; i < EIT; ++i) {
+      const int e = tid + i * NT;
+      const int m = e / C8, c8 = e - m * C8;
+      const int py = m / TW, px = m - py * TW;
+      const int y = oyb + py, x = oxb + px;
+      if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
+        float4 v0 = ol4[m * ROWO4 + c8 * 2], v1 = ol4[m * ROWO4 + c8 * 2 + 1];
+        if (ident) {  // identity shortcut: same geometry as the output (stride 1), bf16 or fp32 input
+          const size_t ioff = ((size_t)(b * a.H + y) * a.W + x) * a.csx + c8 * 8;
+          if (a.in_f32) {
+            const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + ioff);
+            v0.x += p[0].x; v0.y += p[0].y; v0.z += p[0].z; v0.w += p[0].w;
+            v1.x += p[1].x; v1.y += p[1].y; v1.z += p[1].z; v1.w += p[1].w;
+          } else {
+            const uint4 q = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + ioff);
+            v0.x += bf2f(q.x & 0xffff); v0.y += bf2f(q.x >> 16); v0.z += bf2f(q.y & 0xffff); v0.w += bf2f(q.y >> 16);
+            v1.x += bf2f(q.z & 0xffff); v1.y += bf2f(q.z >> 16); v1.z += bf2f(q.w & 0xffff); v1.w += bf2f(q.w >> 16);
+          }
+        }
+        v0.x = v0.x > 0.f ? v0.x : 0.f; v0.y = v0.y > 0.f ? v0.y : 0.f; v0.z = v0.z > 0.f ? v0.z : 0.f; v0.w = v0.w > 0.f ? v0.w : 0.f;
+        v1.x = v1.x > 0.f ? v1.x : 0.f; v1.y = v1.y > 0.f ? v1.y : 0.f; v1.z = v1.z > 0.f ? v1.z : 0.f; v1.w = v1.w > 0.f ? v1.w : 0.f;
+        const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
+        if (a.out_f32) {
+          float4* o = reinterpret_cast<float4*>(static_cast<float*>(a.out) + opix * a.cso + c8 * 8);
+          o[0] = v0;
+          o[1] = v1;
+        } else {
+          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(a.out) + opix * a.cso + c8 * 8) = pack8(v0, v1);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fpc

@@ -17,6 +17,7 @@
 
 #include "../../include/fpc.h"
 #include "block_mfma.h"
+#include "block_bf16.h"
 #include "wblock_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
@@ -167,10 +168,55 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 #undef X
 };
 
+// bf16 instances (dtype = FPC_BF16).  FKIND(name, TH,TW, S,EXT, KC, WM,WN, MB,NB, CMIDP)
+#define FPC_BF16_KINDS(X)                                      \
+  X(F816_s1_K64_C64, 8, 16, 1, 3, 64, 4, 1, 1, 2, 64)          \
+  X(F620_s2_K32_C128, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)        \
+  X(F620_s1_K64_C128, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)        \
+  X(F620_s1_K64_C80, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)          \
+  X(F620_s1_K80_C80, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)          \
+  X(F320_s2_K32_C256, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)        \
+  X(F320_s1_K64_C256, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)        \
+  X(F620_ct_K64_C128, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)
+
+enum FKind {
+#define X(name, ...) FK_##name,
+  FPC_BF16_KINDS(X)
+#undef X
+      FK_COUNT
+};
+
+struct FKindInfo {
+  const char* name;
+  const char* symbol;
+  int TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP;
+  int lds_bytes;
+  const void* fn;
+  void (*launch)(const BlockBfArgs&, dim3, hipStream_t);
+};
+
+#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP)                                                        \
+  static void launchf_##name(const BlockBfArgs& a, dim3 grid, hipStream_t st) {                                   \
+    constexpr int lds = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES;                         \
+    hipLaunchKernelGGL((block_bf16_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>), grid, dim3(WM* WN * 64),   \
+                       lds, st, a);                                                                               \
+  }
+FPC_BF16_KINDS(X)
+#undef X
+
+static const FKindInfo g_fkinds[FK_COUNT] = {
+#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP)                                                         \
+  {#name, "block_bf16_kernel<" #TH ", " #TW ", " #S ", " #EXT ", " #KC ", " #WM ", " #WN ", " #MB ", " #NB ", " #CMIDP ">", \
+   TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES,      \
+   (const void*)block_bf16_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>, launchf_##name},
+    FPC_BF16_KINDS(X)
+#undef X
+};
+
 // ------------------------------------------------------------------------------------
 // Launch plan
 // ------------------------------------------------------------------------------------
-enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_WBLOCK, OP_SOFTMAX, OP_NMS, OP_DESC };
+enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_WBLOCK, OP_BF16, OP_SOFTMAX, OP_NMS, OP_DESC };
 
 struct Op {
   OpType type;
@@ -181,6 +227,9 @@ struct Op {
   BlockArgs bargs{};
   WKind wkind = WK_COUNT;
   WBlockArgs wargs{};
+  FKind fkind = FK_COUNT;
+  BlockBfArgs fargs{};
+  int phase = -1;              // ConvTranspose output-parity phase of a bf16 conv-only op
   std::string prefix;          // checkpoint prefix of a fused block
   int cin = 0, cout = 0;       // real channel counts of a fused block
   int grid_y = 1, grid_z = 1;
@@ -202,6 +251,8 @@ using namespace fpc;
 struct fpc_ctx {
   fpc_config cfg{};
   int H = 0, W = 0, B = 0, Hc = 0, Wc = 0;
+  bool bf16 = false;                 // cfg.dtype == FPC_BF16
+  int lgcs = 72;                     // channel stride of the logits buffer (80 in bf16 mode)
   int cin = 3;                       // 3: [n,3,H,W] frames (the reference's layout); 1: gray [n,1,H,W]
   int cap = 0, sort_cap = 0;
   hipStream_t stream = nullptr;
@@ -468,6 +519,151 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   c->convw.push_back(cw);
 }
 
+// ---- bf16 plan (block_bf16.h) ---------------------------------------------------------------
+struct FBlockSpec {
+  std::string prefix;
+  FKind kind;
+  const void* x;
+  int csx, in_f32, cin, cin_pad, H, W;
+  void* out;
+  int cso, out_f32, cout;
+  bool proj, desc_branch;
+};
+
+static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
+  const FKindInfo& k = g_fkinds[s.kind];
+  Op op;
+  op.type = OP_BF16;
+  op.name = s.prefix + (s.proj ? " [bf16 conv1+bn1+relu+conv2+bn2+proj+relu]" : " [bf16 conv1+bn1+relu+conv2+bn2+identity+relu]");
+  op.prefix = s.prefix;
+  op.fkind = s.kind;
+  op.cin = s.cin;
+  op.cout = s.cout;
+  op.descriptor_branch = s.desc_branch;
+  BlockBfArgs& a = op.fargs;
+  const int nbt = k.WN * k.NB, K16 = k.KC / 16;
+  a.x = s.x;
+  a.csx = s.csx;
+  a.in_f32 = s.in_f32;
+  a.nchunk = s.cin_pad / k.KC;
+  a.H = s.H;
+  a.W = s.W;
+  a.ntaps = 9;
+  a.pad = 1;
+  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) a.tapoff16[ky * 3 + kx] = (ky * HWp + kx) * ROW16;
+  a.k16_h = k.CMIDP / 16;
+  a.k16_x = s.proj ? s.cin_pad / 16 : 0;
+  a.conv_only = 0;
+  a.out = s.out;
+  a.cso = s.cso;
+  a.out_f32 = s.out_f32;
+  a.Ho = a.OH = s.H / k.S;
+  a.Wo = a.OW = s.W / k.S;
+  a.oys = a.oxs = 1;
+  a.oy0 = a.ox0 = 0;
+  a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
+  a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
+  fpc_ctx::ConvW cw;
+  cw.w_off[0] = *blob_off;
+  *blob_off += ((size_t)a.nchunk * 9 * K16 + 2) * nbt * 64 * 4;
+  cw.b_off = *blob_off;
+  *blob_off += (size_t)nbt * 32;
+  cw.w_off[1] = *blob_off;
+  *blob_off += ((size_t)(a.k16_h + a.k16_x) + 2) * nbt * 64 * 4;
+  cw.b2_off = *blob_off;
+  *blob_off += (size_t)nbt * 32;
+  op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
+  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
+                            ((double)a.nchunk * k.KC * 9 + (a.k16_h + a.k16_x) * 16.0);
+  c->ops.push_back(op);
+  c->convw.push_back(cw);
+}
+
+// ConvTranspose2d(k3, s2, p1, op1) + bn + relu as four output-parity phases, one launch each
+static void add_fconvT(fpc_ctx* c, const void* x, int csx, int cin, int H, int W, void* out, int cso, int cout,
+                       size_t* blob_off) {
+  const FKindInfo& k = g_fkinds[FK_F620_ct_K64_C128];
+  const int nbt = k.WN * k.NB, K16 = k.KC / 16;
+  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
+  for (int ph = 0; ph < 4; ++ph) {
+    const int py = ph >> 1, px = ph & 1;
+    Op op;
+    op.type = OP_BF16;
+    op.name = "descriptor.up_sample+bn+relu [bf16 phase " + std::to_string(ph) + "]";
+    op.prefix = "descriptor.up_sample";
+    op.fkind = FK_F620_ct_K64_C128;
+    op.phase = ph;
+    op.cin = cin;
+    op.cout = cout;
+    op.descriptor_branch = true;
+    BlockBfArgs& a = op.fargs;
+    a.x = x;
+    a.csx = csx;
+    a.in_f32 = 0;
+    a.nchunk = cin / k.KC;
+    a.H = H;
+    a.W = W;
+    a.pad = 0;
+    a.ntaps = 0;
+    for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+      for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+        const int dy = py ? 1 - iy : 0, dx = px ? 1 - ix : 0;
+        a.tapoff16[a.ntaps++] = (dy * HWp + dx) * ROW16;
+      }
+    a.conv_only = 1;
+    a.out = out;
+    a.cso = cso;
+    a.out_f32 = 0;
+    a.Ho = H;
+    a.Wo = W;
+    a.OH = 2 * H;
+    a.OW = 2 * W;
+    a.oys = a.oxs = 2;
+    a.oy0 = py;
+    a.ox0 = px;
+    a.tiles_x = (W + k.TW - 1) / k.TW;
+    a.tiles_y = (H + k.TH - 1) / k.TH;
+    fpc_ctx::ConvW cw;
+    cw.w_off[0] = *blob_off;
+    *blob_off += ((size_t)a.nchunk * a.ntaps * K16 + 2) * nbt * 64 * 4;
+    cw.b_off = *blob_off;
+    *blob_off += (size_t)nbt * 32;
+    op.flops_per_frame = 2.0 * a.ntaps * H * W * cin * cout;
+    op.mfma_flops_per_frame = 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+    c->ops.push_back(op);
+    c->convw.push_back(cw);
+  }
+}
+
+static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
+  const int H = c->H, W = c->W;
+  const int H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
+  const bool de = c->cfg.descriptor_enabled != 0;
+  bf16_t* feat = reinterpret_cast<bf16_t*>(c->cat) + 128;
+  add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 1, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
+  add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K32_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
+  add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
+  add_fblock(c, {"detector.layer.1", FK_F620_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
+  {
+    Op op;
+    op.type = OP_SOFTMAX;
+    op.name = "exp-softmax+depth_to_space+threshold";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+  }
+  if (de) {
+    add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K32_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.1", FK_F320_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
+    add_fconvT(c, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
+    add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+  }
+}
+
 static int build_plan(fpc_ctx* c) {
   const int H = c->H, W = c->W, B = c->B;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
@@ -481,7 +677,7 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_h8 = cv.take<float>(npix8 * 128), o_x3 = cv.take<float>(npix8 * 128);
   const size_t o_cat = cv.take<float>(npix8 * 256);
   const size_t o_dh = cv.take<float>(npix8 * 72), o_dproj = cv.take<float>(npix8 * 72);
-  const size_t o_d0 = cv.take<float>(npix8 * 72), o_lg = cv.take<float>(npix8 * 72);
+  const size_t o_d0 = cv.take<float>(npix8 * 72), o_lg = cv.take<float>(npix8 * 80);
   const size_t o_h16 = cv.take<float>(npix16 * 256), o_y16a = cv.take<float>(npix16 * 256);
   const size_t o_y16b = cv.take<float>(npix16 * 256);
   const size_t o_loh = cv.take<float>(npix8 * 128), o_lo0 = cv.take<float>(npix8 * 128);
@@ -579,6 +775,11 @@ static int build_plan(fpc_ctx* c) {
     add_conv(c, t, &bo);
   };
   float* feat = c->cat + 128;  // encoder output lives in channels 128..255 of `cat`
+  if (c->bf16) {
+    build_bf16_ops(c, &bo);
+    goto postproc;
+  }
+  {
   const BKind l1kind = getenv("FPC_L1_T816") ? BK_B816_s1_K64_C64 : BK_B1616_s1_K32_C64;
   block("encoder.layer1.0", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x0, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
         c->x1, 64, true, false, l1kind);
@@ -640,6 +841,8 @@ static int build_plan(fpc_ctx* c) {
     block("descriptor.layer_out.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->lo0, 128, 128, 128, Hc, Wc,
           c->lo_h, 128, 128, 128, c->desc_map, 128, false, true, BK_B620_s1_K64_C128);
   }
+  }
+postproc:
   {
     Op op;
     op.type = OP_NMS;
@@ -664,6 +867,12 @@ static int build_plan(fpc_ctx* c) {
       op.wargs.b1 = c->blob + c->convw[i].b_off;
       op.wargs.w2 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[1]);
       op.wargs.b2 = c->blob + c->convw[i].b2_off;
+    }
+    if (op.type == OP_BF16) {
+      op.fargs.w1 = reinterpret_cast<const uint4*>(c->blob + c->convw[i].w_off[0]);
+      op.fargs.b1 = c->blob + c->convw[i].b_off;
+      op.fargs.w2 = reinterpret_cast<const uint4*>(c->blob + c->convw[i].w_off[1]);
+      op.fargs.b2 = c->blob + c->convw[i].b2_off;
     }
     if (op.type == OP_BLOCK) {
       op.bargs.w1 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
@@ -769,6 +978,53 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
         for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
       }
       std::vector<float> frag = pack_conv(srcs, co, nbt, 8);
+      memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
+      continue;
+    }
+    if (op.type == OP_BF16) {
+      const FKindInfo& k = g_fkinds[op.fkind];
+      const BlockBfArgs& a = op.fargs;
+      const fpc_ctx::ConvW& cw = c->convw[i];
+      const std::string& p = op.prefix;
+      const int ci = op.cin, co = op.cout, nbt = k.WN * k.NB;
+      if (op.phase >= 0) {  // ConvTranspose phase
+        const float* w = need("descriptor.up_sample.weight", {256, 128, 3, 3});
+        const float* bct = need("descriptor.up_sample.bias", {128});
+        Fold f;
+        if (!w || !bct || !fold_bn(m, "descriptor.bn", 128, &f, missing)) return FPC_E_MISSING_KEY;
+        const int py = op.phase >> 1, px = op.phase & 1;
+        std::vector<std::pair<int, int>> taps;  // (ky, kx) in the order add_fconvT laid the taps out
+        for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+          for (int ix = 0; ix < (px ? 2 : 1); ++ix) taps.push_back({py ? (iy == 0 ? 0 : 2) : 1, px ? (ix == 0 ? 0 : 2) : 1});
+        PackSource s{ci, a.nchunk * k.KC, (int)taps.size(),
+                     [&](int n, int cc, int t) { return (double)w[((cc * 128 + n) * 3 + taps[t].first) * 3 + taps[t].second]; },
+                     &f.s};
+        std::vector<float> frag = pack_conv_bf16({s}, co, nbt, k.KC);
+        memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+        for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)((double)bct[n] * f.s[n] + f.t[n]);
+        continue;
+      }
+      const float* w1 = need(p + ".conv1.weight", {co, ci, 3, 3});
+      const float* w2 = need(p + ".conv2.weight", {co, co, 1, 1});
+      Fold f1, f2, fp;
+      if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
+        return FPC_E_MISSING_KEY;
+      PackSource s1{ci, a.nchunk * k.KC, 9, [&](int n, int c_, int t) { return (double)w1[((size_t)(n * ci + c_)) * 9 + t]; }, &f1.s};
+      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC);
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
+      std::vector<PackSource> srcs;
+      srcs.push_back({co, a.k16_h * 16, 1, [&](int n, int c_, int) { return (double)w2[(size_t)n * co + c_]; }, &f2.s});
+      std::vector<double> bias(f2.t);
+      const float* wp = nullptr;
+      if (a.k16_x > 0) {
+        wp = need(p + ".identity_downsample.0.weight", {co, ci, 1, 1});
+        if (!wp || !fold_bn(m, p + ".identity_downsample.1", co, &fp, missing)) return FPC_E_MISSING_KEY;
+        srcs.push_back({ci, a.k16_x * 16, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
+        for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
+      }
+      frag = pack_conv_bf16(srcs, co, nbt, 16);
       memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
       continue;
@@ -957,7 +1213,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
     if (br != which) continue;
     switch (op.type) {
       case OP_STEM: {
-        if (c->fuse_stem_pool || c->cin == 1) {
+        if (c->fuse_stem_pool || c->cin == 1 || c->bf16) {
           float* x0 = c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
           hipMemsetAsync(x0, 0, (size_t)n * (H / 4) * (W / 4) * 64 * sizeof(float), sb.st);
           LaunchTimer t(c, (int)i, sb.st, n);
@@ -982,7 +1238,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         break;
       }
       case OP_POOL: {
-        if (c->fuse_stem_pool || c->cin == 1) break;
+        if (c->fuse_stem_pool || c->cin == 1 || c->bf16) break;
         LaunchTimer t(c, (int)i, sb.st, n);
         const size_t total = (size_t)n * (H / 4) * (W / 4) * 16;
         hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sb.st,
@@ -1029,6 +1285,13 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         g_bkinds[op.bkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
         break;
       }
+      case OP_BF16: {
+        LaunchTimer t(c, (int)i, sb.st, n);
+        BlockBfArgs a = op.fargs;
+        a.frame0 = f0;
+        g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
+        break;
+      }
       case OP_CONV: {
         LaunchTimer t(c, (int)i, sb.st, n);
         ConvArgs a = op.args;
@@ -1053,7 +1316,7 @@ static void run_softmax(fpc_ctx* c, const Sub& sb) {
   hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
   LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st, sb.n);
   hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)16 * c->W * sizeof(float), sb.st,
-                     c->lg + (size_t)sb.f0 * c->Hc * c->Wc * 72, 72, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
+                     c->lg + (size_t)sb.f0 * c->Hc * c->Wc * c->lgcs, c->lgcs, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
                      c->prob + sb.f0 * HW, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
 }
 
@@ -1191,6 +1454,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   // H/8 or W/8 breaks its concat, so frames must be multiples of 16 unless it is disabled
   const int mult = cfg->descriptor_enabled ? 16 : 8;
   if (cfg->in_channels != 0 && cfg->in_channels != 1 && cfg->in_channels != 3) return FPC_E_INVALID;
+  if (cfg->dtype != FPC_F32 && cfg->dtype != FPC_BF16) return FPC_E_INVALID;
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30))
@@ -1214,6 +1478,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->Hc = c->H / 8;
   c->Wc = c->W / 8;
   c->cin = cfg->in_channels == 1 ? 1 : 3;
+  c->bf16 = cfg->dtype == FPC_BF16;
+  c->lgcs = c->bf16 ? 80 : 72;
   // kept points are pairwise > nms_dist apart (infinity norm): at most one per (r+1)^2 cell
   const int r1 = cfg->nms_dist + 1;
   const int worst = ((c->H + r1 - 1) / r1) * ((c->W + r1 - 1) / r1);
@@ -1258,6 +1524,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     HIPCHECK(hipFuncSetAttribute(g_wkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_wkinds[k].lds_bytes));
   for (int k = 0; k < BK_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_bkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bkinds[k].lds_bytes));
+  for (int k = 0; k < FK_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_fkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_fkinds[k].lds_bytes));
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1391,7 +1659,7 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
   if (prob) HIPCHECK(hipMemcpyAsync(prob, c->prob, (size_t)n * c->H * c->W * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   if (logits) {
     const size_t tot = (size_t)n * 65 * HWc;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->lg, 72, 65,
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->lg, c->lgcs, 65,
                        HWc, n, logits);
   }
   if (desc) {
@@ -1546,6 +1814,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;
           case OP_WBLOCK: k = g_wkinds[op->wkind].symbol; break;
+          case OP_BF16: k = g_fkinds[op->fkind].symbol; break;
           case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
           case OP_NMS: k = "nms_rounds_kernel+nms_sort_kernel"; break;
           case OP_DESC: k = "descriptor_kernel"; break;

@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <unordered_map>
@@ -81,6 +82,41 @@ inline std::vector<float> pack_conv(const std::vector<PackSource>& srcs, int cou
               for (int j = 0; j < 4; ++j) {
                 const int c = chunk * KC + k8 * 8 + 4 * half + j;
                 dst[j] = (n < cout && c < s.cin) ? (float)(s.w(n, c, tap) * (*s.scale)[n]) : 0.f;
+              }
+            }
+  return out;
+}
+
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
+inline uint16_t host_f2bf(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// The same for block_bf16_kernel: 16 channels per step, 8 bf16 (16 bytes) per lane;
+//   frag[(step * nbt + nb) * 64 + lane] = { B[step*16 + 8*half + j][nb*32 + (lane&31)] }, j = 0..7
+// Returned as floats (4 per lane) so that it sits in the same blob.
+inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, int cout, int nbt, int KC) {
+  const int K16 = KC / 16;
+  size_t nsteps = 0;
+  for (auto& s : srcs) nsteps += (size_t)(s.cin_pad / KC) * s.ntaps * K16;
+  std::vector<float> out((nsteps + 2) * nbt * 64 * 4, 0.f);
+  uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+  size_t step = 0;
+  for (auto& s : srcs)
+    for (int chunk = 0; chunk < s.cin_pad / KC; ++chunk)
+      for (int tap = 0; tap < s.ntaps; ++tap)
+        for (int k16 = 0; k16 < K16; ++k16, ++step)
+          for (int nb = 0; nb < nbt; ++nb)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int n = nb * 32 + (lane & 31), half = lane >> 5;
+              uint16_t* dst = &o16[((step * nbt + nb) * 64 + lane) * 8];
+              for (int j = 0; j < 8; ++j) {
+                const int c = chunk * KC + k16 * 16 + 8 * half + j;
+                dst[j] = (n < cout && c < s.cin) ? host_f2bf((float)(s.w(n, c, tap) * (*s.scale)[n])) : 0;
               }
             }
   return out;

@@ -43,7 +43,7 @@ def _as_tensor_table(state_dict):
 
 class Engine:
     def __init__(self, height, width, max_batch=1, device=0, nms_dist=4, conf_thresh=0.015,
-                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3):
+                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3, dtype="f32"):
         self._l = _lib.load()          # raises if libfpc.so is not built: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("fpc_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -54,6 +54,10 @@ class Engine:
         cfg.nms_dist, cfg.conf_thresh, cfg.border_remove = nms_dist, conf_thresh, border_remove
         cfg.descriptor_enabled, cfg.max_keypoints = int(bool(descriptor_enabled)), max_keypoints
         cfg.in_channels = in_channels
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+        cfg.dtype = 1 if dtype == "bf16" else 0   # FPC_F32 / FPC_BF16 (include/fpc.h)
+        self.dtype = dtype
         self.in_channels = 1 if in_channels == 1 else 3
         self.cfg = cfg
         self.h, self.w, self.max_batch, self.device = height, width, max_batch, device

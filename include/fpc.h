@@ -42,6 +42,8 @@ enum {
   FPC_E_NOT_CONVERGED = -7 /* NMS round limit hit (never seen)     */
 };
 
+enum { FPC_F32 = 0, FPC_BF16 = 1 };
+
 /* Replaces SuperPointSettings (python/src/settings.py:2-8) / Settings
  * (cpp/src/settings.h:27-31) plus the geometry the reference takes from the frame. */
 typedef struct fpc_config {
@@ -57,7 +59,10 @@ typedef struct fpc_config {
   int in_channels;        /* 0 or 3: frames [n,3,H,W] (superpoint.py:12); 1: gray frames   */
                           /* [n,1,H,W] -- what the reference feeds after replicating the   */
                           /* plane x3 (dataset_utils.py:19-20, cpp/src/camera.cc:17-18)    */
-  int reserved[6];
+  int dtype;              /* FPC_F32 (0): fp32 activations and weights, the reference's    */
+                          /* arithmetic; FPC_BF16 (1): bf16 activations / weights with     */
+                          /* fp32 accumulation (BASELINE.json configs[4])                  */
+  int reserved[5];
 } fpc_config;
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']

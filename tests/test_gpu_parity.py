@@ -485,3 +485,80 @@ def test_gray_frames_equal_replicated_rgb(torch_gpu):
         e1.forward(rgb)
     e3.close()
     e1.close()
+
+
+# bf16 path (BASELINE.json configs[4]): bf16 activations / weights, fp32 accumulation.  The 1e-4 bound of
+# north_star is an fp32 statement; bf16 storage has 8 significant bits, so the dense maps are held to the
+# error that rounding predicts (about 2^-8 relative per tensor, a handful of tensors deep) and the sparse
+# outputs to agreement with the fp32 path.  Post-processing runs in fp32 on whatever dense maps it is given
+# and stays EXACT against the oracle on those maps.
+BF16_LOGIT_MAX, BF16_LOGIT_RMS, BF16_KP_OVERLAP, BF16_DESC_COS = 0.25, 0.02, 0.97, 0.999
+
+
+def _overlap_and_cosine(ra, rb):
+    (xa, _, fa, _), (xb, _, fb, _) = ra, rb
+    ia = {tuple(p): k for k, p in enumerate(xa.tolist())}
+    ib = {tuple(p): k for k, p in enumerate(xb.tolist())}
+    common = [p for p in ia if p in ib]
+    cos = [float(np.dot(fa[ia[p]], fb[ib[p]])) for p in common] if fa is not None else [1.0]
+    return len(common) / max(1, max(len(ia), len(ib))), min(cos) if cos else 1.0
+
+
+@pytest.mark.gpu
+def test_bf16_path_against_fp32_and_oracle(torch_gpu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "f5_e2e_vga.npz"))
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_batch(int(g["seed_frame"]), 1, h, w)
+    e32 = engine(h, w)
+    e32.load_state_dict(sd)
+    e16 = engine(h, w, dtype="bf16")
+    e16.load_state_dict(sd)
+    p32, d32, l32 = e32.forward(frame)
+    p16, d16, l16 = e16.forward(frame)
+    diff = (l32 - l16).float()
+    assert float(diff.abs().max()) < BF16_LOGIT_MAX and float(diff.pow(2).mean().sqrt()) < BF16_LOGIT_RMS
+    # against the reference's own probes of the dense maps (golden fixture), same bound
+    assert np.max(np.abs(l16.cpu().numpy().ravel()[::7] - g["logits_probe"])) < BF16_LOGIT_MAX
+    assert np.max(np.abs(d16.cpu().numpy().ravel()[::11] - g["desc_map_probe"])) < BF16_LOGIT_MAX
+    r32, r16 = e32.detect(frame)[0], e16.detect(frame)[0]
+    # post-processing is exact on the bf16 engine's own dense maps
+    _check_frame_against_oracle_postproc(oracle_mod(), p16[0].cpu().numpy(), d16[0].cpu().numpy(), r16, h, w)
+    ov, cos = _overlap_and_cosine(r32, r16)
+    assert ov >= BF16_KP_OVERLAP and cos >= BF16_DESC_COS
+    # and against the reference's keypoints
+    gset = set(zip(g["points_x"].astype(int).tolist(), g["points_y"].astype(int).tolist()))
+    kset = {tuple(p) for p in r16[0].tolist()}
+    assert len(gset & kset) / max(len(gset), len(kset)) >= BF16_KP_OVERLAP
+    e32.close()
+    e16.close()
+
+
+@pytest.mark.gpu
+def test_bf16_hd_batch_properties(torch_gpu):
+    """BASELINE.json configs[4] geometry and dtype (1280x960, bf16) on a batch that splits unevenly over the
+    sub-batch streams: batch == single frames, NMS / ordering / unit-norm properties, MagicPoint variant."""
+    h, w, n = 960, 1280, 5
+    sd = synth.make_state_dict(5, dustbin_bias=7.0)
+    frames = synth.make_batch(700, n, h, w)
+    e = engine(h, w, n, dtype="bf16")
+    e.load_state_dict(sd)
+    prob, desc, _ = e.forward(frames)
+    res = e.detect(frames)
+    oracle = oracle_mod()
+    for i in (0, n - 1):
+        _check_frame_against_oracle_postproc(oracle, prob[i].cpu().numpy(), desc[i].cpu().numpy(), res[i], h, w)
+    one = e.detect(frames[3:4])[0]
+    np.testing.assert_array_equal(one[0], res[3][0])
+    np.testing.assert_array_equal(one[1], res[3][1])
+    np.testing.assert_array_equal(one[2], res[3][2])
+    for xy, conf, d, ncand in res:
+        assert len(conf) > 1000 and np.all(np.diff(conf) <= 0)
+        np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
+    e.close()
+    m = engine(h, w, 1, dtype="bf16", descriptor_enabled=False)
+    m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("descriptor.")})
+    xy, conf, d, _ = m.detect(frames[:1])[0]
+    assert d is None
+    np.testing.assert_array_equal(xy, res[0][0])
+    m.close()
