@@ -29,7 +29,8 @@ from fpc_amd.engine import Engine  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (dense, f32 in / f32 acc)
 PEAK_BF16_MFMA_TFLOPS = 2516.8  # ibid.: BF16 MFMA dense = 16x the FP32 matrix rate (~2.5 PF)
-PEAK_TFLOPS = PEAK_F32_MFMA_TFLOPS
+PEAK_TFLOPS = PEAK_F32_MFMA_TFLOPS     # ceiling for ALGORITHMIC flops in the selected arithmetic mode
+PEAK_ISSUED_TFLOPS = PEAK_F32_MFMA_TFLOPS  # ceiling for the MFMA instructions really issued
 BATCH = 32
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/): filled in
 # once measured; null until then.
@@ -90,7 +91,7 @@ def roofline_entry(sym, st, step_ms):
                         if sym in TRAFFIC_BYTES_PER_FRAME and (H, W) == (480, 640) else None),
             "avg_launch_ms": round(st["avg_launch_ms"], 4), "frames_per_launch": frames,
             "flops_per_launch": st["flops"], "mfma_issued_flops_per_launch": st["mfma_flops"],
-            "mfma_issued_frac": round(st["mfma_flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
+            "mfma_issued_frac": round(st["mfma_flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_ISSUED_TFLOPS, 4),
             "launches_per_step": st["launches_per_step"], "share_of_step": round(st["total_ms"] / step_ms, 3)}
 
 
@@ -111,11 +112,20 @@ def main():
     ap.add_argument("--workload", choices=["vga32", "hd64-bf16"], default="vga32",
                     help="vga32 = BASELINE.json configs[1] (the headline; default); hd64-bf16 = configs[4]: 64 frames of "
                          "1280x960 per step, bf16 activations / weights with fp32 accumulation")
+    ap.add_argument("--dtype", choices=["f32", "f32_split"], default="f32",
+                    help="vga32 only. f32 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32, Winograd where it pays). "
+                         "f32_split: fp32 tensors, every product as six bf16 MFMAs on exactly split operands "
+                         "(block_x3.h) -- same 1e-4 parity bar, reported beside the headline as `split_operand_mode`")
+    ap.add_argument("--no-alt-pass", action="store_true", help="skip the extra pass in the other fp32 arithmetic mode")
     args = ap.parse_args()
-    global H, W, BATCH, PEAK_TFLOPS
-    dtype = "f32"
+    global H, W, BATCH, PEAK_TFLOPS, PEAK_ISSUED_TFLOPS
+    dtype = args.dtype
+    if dtype == "f32_split":
+        PEAK_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # six bf16 MFMAs per fp32 product
+        PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
     if args.workload == "hd64-bf16":
         H, W, BATCH, dtype, PEAK_TFLOPS = 960, 1280, 64, "bf16", PEAK_BF16_MFMA_TFLOPS
+        PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
 
     rank, world, local = fdist.init_from_env()
     if world != args.gpus:
@@ -188,26 +198,53 @@ def main():
         d1 = time.perf_counter() - t1
         serial = (symbol_stats(e1.timings(), ks), d1 / ks * 1e3, e1.timings(), ks)
         e1.close()
+    alt = None
+    if rank == 0 and world == 1 and not args.no_alt_pass and args.workload == "vga32":
+        # the other fp32 arithmetic mode on the same frames (not part of `value`)
+        os.environ.pop("FPC_STREAMS", None)
+        os.environ.pop("FPC_SPLIT_HEADS", None)
+        adt = "f32_split" if dtype == "f32" else "f32"
+        ea = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=adt)
+        ea.load_state_dict(sd)
+        for _ in range(3):
+            ea.detect_async(frames, BATCH)
+        ea.sync()
+        ks = min(20, max(5, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            ea.detect_async(frames, BATCH)
+        ea.sync()
+        d1 = time.perf_counter() - t1
+        acnt, _ = ea.counts(BATCH)
+        alt = {"dtype": adt, "value": round(BATCH * ks / d1, 2), "unit": "frames/s", "steps": ks,
+               "ms_per_step": round(d1 / ks * 1e3, 4), "keypoints_per_frame": round(float(np.mean(acnt)), 1),
+               "same_keypoint_counts_as_headline_mode": bool(np.array_equal(acnt, cnt))}
+        ea.close()
     total_frames = BATCH * args.steps * world
 
     if rank == 0:
         value = total_frames / dt
         flops_frame = 2.0 * arch.conv_macs(H, W)
         wl = ("batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
-              "(BASELINE.json configs[1]; configs[2] when n_gpus=8)") if dtype == "f32" else (
+              "(BASELINE.json configs[1]; configs[2] when n_gpus=8)" +
+              ("; products as six bf16 MFMAs on exactly split fp32 operands" if dtype == "f32_split" else "")
+              ) if dtype != "bf16" else (
               "batch=64 1280x960 frames per GPU, super_point checkpoint layout, bf16 activations/weights, fp32 "
               "accumulation, fp32 post-processing (BASELINE.json configs[4])")
         out = {
-            "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("VGA 640x480" if dtype == "f32" else "HD 1280x960"),
+            "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("VGA 640x480" if dtype != "bf16" else "HD 1280x960"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16": "bf16", "f32_split": "f32 (3 x bf16 split operands, 6 MFMA per product, f32 accumulate)"}[dtype],
             "data": "synthetic (seeded frames + seeded checkpoint in the reference's layout)",
             "config": {"workload": wl, "frames_per_step_per_gpu": BATCH, "height": H, "width": W, "input_channels": cin,
                        "parallelism": "frame-sharded x%d, no data-path collective" % world},
             "frames_per_sec_per_gpu": round(value / world, 2),
             "whole_path_tflops": round(value * flops_frame / 1e12, 3),
-            "whole_path_frac_of_%s_mfma_peak" % dtype: round(value / world * flops_frame / 1e12 / PEAK_TFLOPS, 4),
+            "whole_path_frac_of_%s_mfma_peak" % ("f32" if dtype == "f32" else "bf16"): round(
+                value / world * flops_frame * (6.0 if dtype == "f32_split" else 1.0) / 1e12 /
+                (PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
             "keypoints_per_frame": round(float(np.mean(cnt)), 1),
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
         }
@@ -221,7 +258,7 @@ def main():
             # concurrently, so a launch's duration includes the time it shares the GPU with others;
             # `roofline_serial` repeats the measurement with one stream (kernels alone on the GPU).
             stats = symbol_stats(timed_timings, args.steps)
-            sym = max(stats, key=lambda k: stats[k]["total_ms"])
+            sym = max((k for k in stats if stats[k]["flops"] > 0), key=lambda k: stats[k]["total_ms"])
             out["roofline"] = roofline_entry(sym, stats[sym], dt / args.steps * 1e3)
             sum_ms = {k: float(np.sum([m for m, _, _ in v])) / args.steps for k, v in per_kernel.items()}
             out["layer_ms_per_step_concurrent"] = {k: round(v, 4) for k, v in sum_ms.items()}
@@ -235,6 +272,8 @@ def main():
                 for name, kern, ms, fl, mf in stim:
                     lay.setdefault(name, []).append(ms)
                 out["layer_ms_serial"] = {k: round(float(np.mean(v)), 4) for k, v in lay.items()}
+        if alt is not None:
+            out["split_operand_mode" if alt["dtype"] == "f32_split" else "plain_f32_mfma_mode"] = alt
         if world == 1 and not args.no_cpu_baseline:
             ncb = 8 if H * W <= 480 * 640 else 2
             cb_frames = frames_np[:ncb] if not args.gray else np.repeat(frames_np[:ncb], 3, axis=1)

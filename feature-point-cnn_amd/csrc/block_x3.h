@@ -1,0 +1,332 @@
+// block_x3.h -- fp32 ResNetBlock / convolution kernels whose matrix products run on the bf16 MFMA pipe
+// with SPLIT OPERANDS (`dtype = FPC_F32_SPLIT`).
+//
+// Every fp32 operand x is split exactly into three bf16 terms x = x0 + x1 + x2 (8 significant bits each,
+// by truncation: x0 = top 16 bits of x, x1 = top 16 bits of x - x0, x2 = x - x0 - x1, which then has at most
+// 8 significant bits and is exact in bf16).  A product a*b is evaluated as the six cross terms of weight
+// >= 2^-16:  a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0, each exact in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16 (8 x 8 significant bits).  The three dropped terms (a1 b2, a2 b1, a2 b2) are
+// below 2^-23 of |a b| -- the size of one fp32 rounding -- so the result carries fp32 accuracy, at 6 bf16
+// MFMAs (6 x 32 cycles per 32x32x16) instead of 8 fp32 MFMAs (8 x 64 cycles) per 16 channels: 2.67x the
+// fp32 matrix rate.  Tensors in HBM stay fp32 NHWC exactly as in the default path; activations are split
+// while they are staged into LDS, weights are split on the host (weights.h: pack_conv_x3).
+//
+// Structure as block_mfma.h / block_bf16.h: halo tile in LDS (three bf16 planes), weights pre-packed in
+// MFMA lane order and read straight from global memory one step ahead, h = relu(bn1(conv1 x)) stays in LDS
+// (fp32, split when read), shortcut (projection as extra K, or identity) and ReLU in the epilogue.
+#pragma once
+#include "block_bf16.h"
+
+namespace fpc {
+
+struct Split3 {
+  uint4 p[3];
+};
+
+// 8 fp32 values -> three planes of 8 bf16 (16 bytes each)
+__device__ __forceinline__ Split3 split8(const float4& a, const float4& b) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned u = __float_as_uint(v[i]);
+    const unsigned hi = u & 0xffff0000u;
+    const float r = v[i] - __uint_as_float(hi);
+    const unsigned mi = __float_as_uint(r) & 0xffff0000u;
+    const float q = r - __uint_as_float(mi);
+    h[i] = hi;
+    m[i] = mi;
+    l[i] = __float_as_uint(q);  // <= 8 significant bits: its low 16 bits are zero
+  }
+  Split3 s;
+  // pack pairs: element 2j in the low half, 2j+1 in the high half
+  s.p[0] = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+  s.p[1] = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
+  s.p[2] = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u),
+                      (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u));
+  return s;
+}
+
+#define FPC_X3_MFMA(ACC, A, B)                                                                                          \
+  do {                                                                                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[2]), __builtin_bit_cast(bf16x8, (B)[0]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[0]), __builtin_bit_cast(bf16x8, (B)[2]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[1]), __builtin_bit_cast(bf16x8, (B)[1]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[1]), __builtin_bit_cast(bf16x8, (B)[0]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[0]), __builtin_bit_cast(bf16x8, (B)[1]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[0]), __builtin_bit_cast(bf16x8, (B)[0]), ACC, 0, 0, 0); \
+  } while (0)
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+struct BlockX3Cfg {
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int HW = (TW - 1) * S + EXT, HH = (TH - 1) * S + EXT;
+  static constexpr int ROW16 = KC / 8 + 1;            // 16-byte units per halo pixel and plane (+1 skew)
+  static constexpr int PLANE16 = HH * HW * ROW16;
+  static constexpr int ROWO4 = CMIDP / 4 + 1;         // float4 per row of the fp32 h / output tile
+  static constexpr int M = WM * MB * 32, N = WN * NB * 32;
+  static constexpr int HALO_BYTES = 3 * PLANE16 * 16;
+  static constexpr int O_BYTES = M * ROWO4 * 16;
+  static constexpr int LDS_BYTES = HALO_BYTES > O_BYTES ? HALO_BYTES : O_BYTES;
+  static_assert(KC % 16 == 0 && CMIDP % 16 == 0 && CMIDP <= N, "bf16 MFMA consumes 16 channels per step");
+};
+
+// BlockBfArgs as in block_bf16.h; x and out are fp32 (in_f32 / out_f32 are ignored), csx / cso in floats.
+// Weight fragments: [step][plane][nb][lane] uint4.
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfArgs a) {
+  using C = BlockX3Cfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
+  constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
+  constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, PLANE16 = C::PLANE16, ROWO4 = C::ROWO4, NBT = WN * NB;
+  extern __shared__ uint4 lds16[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bl = blockIdx.x / tiles;
+  const int b = a.frame0 + bl;
+  const int t = blockIdx.x - bl * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const float* __restrict__ xin = static_cast<const float*>(a.x);
+
+  int abase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int m = (wm * MB + mb) * 32 + l31;
+    m = m < TH * TW ? m : TH * TW - 1;
+    const int py = m / TW, px = m - py * TW;
+    abase[mb] = ((py * S) * HW + px * S) * ROW16 + half;
+  }
+  constexpr int planestride = NBT * 64, stepstride = 3 * NBT * 64;
+  const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
+
+  const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
+  float4 stage[ITER][2];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC8, c8 = e - pix * KC8;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c8 * 8 : 0;
+      const float4* p = reinterpret_cast<const float4*>(xin + off);
+      float4 v0 = p[0], v1 = p[1];
+      if (!ok) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      stage[i][0] = v0;
+      stage[i][1] = v1;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = tid + i * NT;
+      const int pix = e / KC8, c8 = e - pix * KC8;
+      if (NV % NT == 0 || e < NV) {
+        const Split3 s = split8(stage[i][0], stage[i][1]);
+        lds16[pix * ROW16 + c8] = s.p[0];
+        lds16[PLANE16 + pix * ROW16 + c8] = s.p[1];
+        lds16[2 * PLANE16 + pix * ROW16 + c8] = s.p[2];
+      }
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  // ---------------------------------------------------------------- phase 1: KxK conv
+  load_chunk(0);
+  uint4 bc[NB][3];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bc[nb][p] = wp[p * planestride + nb * 64];
+  wp += stepstride;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    if (chunk) FPC_LDS_BARRIER();
+    store_chunk();
+    FPC_LDS_BARRIER();
+    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    for (int tap = 0; tap < a.ntaps; ++tap) {
+      const int toff = a.tapoff16[tap];
+#pragma unroll
+      for (int k = 0; k < K16; ++k) {
+        uint4 bn[NB][3];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bn[nb][p] = wp[p * planestride + nb * 64];
+        wp += stepstride;
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 av[MB][3];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) av[mb][p] = lds16[p * PLANE16 + abase[mb] + toff + k * 2];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb], bc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+      }
+    }
+  }
+
+  if (!a.conv_only) {
+    // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (fp32)
+    const uint4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bc[nb][p] = wq[p * planestride + nb * 64];
+    wq += stepstride;
+    FPC_LDS_BARRIER();
+    {
+      float* hl = reinterpret_cast<float*>(lds16);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = (wn * NB + nb) * 32 + l31;
+        const float bias = a.b1[n];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = acc[mb][nb][r] + bias;
+            if (n < CMIDP) hl[m * (ROWO4 * 4) + n] = v > 0.f ? v : 0.f;
+            acc[mb][nb][r] = 0.f;
+          }
+      }
+    }
+    FPC_LDS_BARRIER();
+    // -------------------------------------------------------------- phase 2a: K over h (LDS, split on read)
+    const float4* hl4 = reinterpret_cast<const float4*>(lds16);
+    int hbase[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWO4 + half * 2;
+    for (int k = 0; k < a.k16_h; ++k) {
+      uint4 bn[NB][3];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bn[nb][p] = wq[p * planestride + nb * 64];
+      wq += stepstride;
+      __builtin_amdgcn_sched_barrier(0);
+      Split3 av[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[mb] = split8(hl4[hbase[mb] + k * 4], hl4[hbase[mb] + k * 4 + 1]);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb].p, bc[nb]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+    }
+    // -------------------------------------------------------------- phase 2b: K over x (projection)
+    if (a.k16_x > 0) {
+      size_t xoff[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        int m = (wm * MB + mb) * 32 + l31;
+        m = m < TH * TW ? m : TH * TW - 1;
+        const int py = m / TW, px = m - py * TW;
+        int y = (ty * TH + py) * S, x = (tx * TW + px) * S;
+        y = y < a.H ? y : a.H - 1;
+        x = x < a.W ? x : a.W - 1;
+        xoff[mb] = ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 8;
+      }
+      float4 an[MB][2];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float4* p = reinterpret_cast<const float4*>(xin + xoff[mb]);
+        an[mb][0] = p[0];
+        an[mb][1] = p[1];
+      }
+      for (int k = 0; k < a.k16_x; ++k) {
+        uint4 bn[NB][3];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bn[nb][p] = wq[p * planestride + nb * 64];
+        wq += stepstride;
+        Split3 av[MB];
+        const int kn = k + 1 < a.k16_x ? k + 1 : k;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          av[mb] = split8(an[mb][0], an[mb][1]);
+          const float4* p = reinterpret_cast<const float4*>(xin + xoff[mb] + kn * 16);
+          an[mb][0] = p[0];
+          an[mb][1] = p[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb].p, bc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue: fp32 tile -> LDS -> 8-channel vectors
+  FPC_LDS_BARRIER();
+  {
+    float* ol = reinterpret_cast<float*>(lds16);
+    const float* bptr = a.conv_only ? a.b1 : a.b2;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 32 + l31;
+      const float bias = bptr[n];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (n < CMIDP) ol[m * (ROWO4 * 4) + n] = acc[mb][nb][r] + bias;
+        }
+    }
+  }
+  FPC_LDS_BARRIER();
+  {
+    constexpr int C4 = CMIDP / 4;
+    constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
+    const float4* ol4 = reinterpret_cast<const float4*>(lds16);
+    const int oyb = ty * TH, oxb = tx * TW;
+    const bool ident = !a.conv_only && a.k16_x == 0;
+    float* __restrict__ outp = static_cast<float*>(a.out);
+#pragma unroll
+    for (int i = 0; i < EIT; ++i) {
+      const int e = tid + i * NT;
+      const int m = e / C4, c4 = e - m * C4;
+      const int py = m / TW, px = m - py * TW;
+      const int y = oyb + py, x = oxb + px;
+      if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
+        float4 v = ol4[m * ROWO4 + c4];
+        if (ident) {  // identity shortcut: same geometry as the output (stride 1)
+          const float4 q = *reinterpret_cast<const float4*>(xin + ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
+        *reinterpret_cast<float4*>(outp + opix * a.cso + c4 * 4) = v;
+      }
+    }
+  }
+}
+
+}  // namespace fpc

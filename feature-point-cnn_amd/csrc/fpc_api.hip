@@ -18,6 +18,7 @@
 #include "../../include/fpc.h"
 #include "block_mfma.h"
 #include "block_bf16.h"
+#include "block_x3.h"
 #include "wblock_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
@@ -168,16 +169,25 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 #undef X
 };
 
-// bf16 instances (dtype = FPC_BF16).  FKIND(name, TH,TW, S,EXT, KC, WM,WN, MB,NB, CMIDP)
-#define FPC_BF16_KINDS(X)                                      \
-  X(F816_s1_K64_C64, 8, 16, 1, 3, 64, 4, 1, 1, 2, 64)          \
-  X(F620_s2_K32_C128, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)        \
-  X(F620_s1_K64_C128, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)        \
-  X(F620_s1_K64_C80, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)          \
-  X(F620_s1_K80_C80, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)          \
-  X(F320_s2_K32_C256, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)        \
-  X(F320_s1_K64_C256, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)        \
-  X(F620_ct_K64_C128, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)
+// bf16 / split-operand instances.  FKIND(name, KERNEL, CFG, PLANES, TH,TW, S,EXT, KC, WM,WN, MB,NB, CMIDP)
+//   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
+#define FPC_BF16_KINDS(X)                                                                   \
+  X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 4, 1, 1, 2, 64)     \
+  X(F620_s2_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)   \
+  X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
+  X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
+  X(F620_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)     \
+  X(F320_s2_K32_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)   \
+  X(F320_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)   \
+  X(F620_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)   \
+  X(S816_s1_K64_C64, block_x3_kernel, BlockX3Cfg, 3, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)       \
+  X(S620_s2_K16_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)     \
+  X(S620_s1_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)     \
+  X(S620_s1_K64_C80, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)       \
+  X(S620_s1_K16_C80, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 3, 16, 4, 1, 1, 3, 80)       \
+  X(S320_s2_K16_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 2, 3, 16, 1, 4, 2, 2, 256)     \
+  X(S320_s1_K64_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)     \
+  X(S620_ct_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)
 
 enum FKind {
 #define X(name, ...) FK_##name,
@@ -189,26 +199,25 @@ enum FKind {
 struct FKindInfo {
   const char* name;
   const char* symbol;
-  int TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP;
+  int planes, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP;
   int lds_bytes;
   const void* fn;
   void (*launch)(const BlockBfArgs&, dim3, hipStream_t);
 };
 
-#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP)                                                        \
-  static void launchf_##name(const BlockBfArgs& a, dim3 grid, hipStream_t st) {                                   \
-    constexpr int lds = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES;                         \
-    hipLaunchKernelGGL((block_bf16_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>), grid, dim3(WM* WN * 64),   \
-                       lds, st, a);                                                                               \
+#define X(name, KERN, CFG, PL, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP)                                  \
+  static void launchf_##name(const BlockBfArgs& a, dim3 grid, hipStream_t st) {                            \
+    constexpr int lds = CFG<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES;                         \
+    hipLaunchKernelGGL((KERN<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>), grid, dim3(WM* WN * 64), lds, st, a); \
   }
 FPC_BF16_KINDS(X)
 #undef X
 
 static const FKindInfo g_fkinds[FK_COUNT] = {
-#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP)                                                         \
-  {#name, "block_bf16_kernel<" #TH ", " #TW ", " #S ", " #EXT ", " #KC ", " #WM ", " #WN ", " #MB ", " #NB ", " #CMIDP ">", \
-   TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES,      \
-   (const void*)block_bf16_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>, launchf_##name},
+#define X(name, KERN, CFG, PL, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP)                                   \
+  {#name, #KERN "<" #TH ", " #TW ", " #S ", " #EXT ", " #KC ", " #WM ", " #WN ", " #MB ", " #NB ", " #CMIDP ">", \
+   PL, TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, CFG<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>::LDS_BYTES,   \
+   (const void*)KERN<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>, launchf_##name},
     FPC_BF16_KINDS(X)
 #undef X
 };
@@ -252,6 +261,7 @@ struct fpc_ctx {
   fpc_config cfg{};
   int H = 0, W = 0, B = 0, Hc = 0, Wc = 0;
   bool bf16 = false;                 // cfg.dtype == FPC_BF16
+  bool split = false;                // cfg.dtype == FPC_F32_SPLIT
   int lgcs = 72;                     // channel stride of the logits buffer (80 in bf16 mode)
   int cin = 3;                       // 3: [n,3,H,W] frames (the reference's layout); 1: gray [n,1,H,W]
   int cap = 0, sort_cap = 0;
@@ -534,7 +544,8 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   const FKindInfo& k = g_fkinds[s.kind];
   Op op;
   op.type = OP_BF16;
-  op.name = s.prefix + (s.proj ? " [bf16 conv1+bn1+relu+conv2+bn2+proj+relu]" : " [bf16 conv1+bn1+relu+conv2+bn2+identity+relu]");
+  const std::string tag = k.planes == 3 ? " [3xbf16 " : " [bf16 ";
+  op.name = s.prefix + tag + (s.proj ? "conv1+bn1+relu+conv2+bn2+proj+relu]" : "conv1+bn1+relu+conv2+bn2+identity+relu]");
   op.prefix = s.prefix;
   op.fkind = s.kind;
   op.cin = s.cin;
@@ -567,33 +578,34 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
-  *blob_off += ((size_t)a.nchunk * 9 * K16 + 2) * nbt * 64 * 4;
+  *blob_off += ((size_t)a.nchunk * 9 * K16 + 2) * k.planes * nbt * 64 * 4;
   cw.b_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
   cw.w_off[1] = *blob_off;
-  *blob_off += ((size_t)(a.k16_h + a.k16_x) + 2) * nbt * 64 * 4;
+  *blob_off += ((size_t)(a.k16_h + a.k16_x) + 2) * k.planes * nbt * 64 * 4;
   cw.b2_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
   op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
-  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
+  // split operands: six bf16 MFMAs per product
+  op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : 1.0) * 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
                             ((double)a.nchunk * k.KC * 9 + (a.k16_h + a.k16_x) * 16.0);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
 
 // ConvTranspose2d(k3, s2, p1, op1) + bn + relu as four output-parity phases, one launch each
-static void add_fconvT(fpc_ctx* c, const void* x, int csx, int cin, int H, int W, void* out, int cso, int cout,
-                       size_t* blob_off) {
-  const FKindInfo& k = g_fkinds[FK_F620_ct_K64_C128];
+static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, int H, int W, void* out, int cso,
+                       int cout, size_t* blob_off) {
+  const FKindInfo& k = g_fkinds[kind];
   const int nbt = k.WN * k.NB, K16 = k.KC / 16;
   const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
   for (int ph = 0; ph < 4; ++ph) {
     const int py = ph >> 1, px = ph & 1;
     Op op;
     op.type = OP_BF16;
-    op.name = "descriptor.up_sample+bn+relu [bf16 phase " + std::to_string(ph) + "]";
+    op.name = std::string("descriptor.up_sample+bn+relu [") + (k.planes == 3 ? "3xbf16" : "bf16") + " phase " + std::to_string(ph) + "]";
     op.prefix = "descriptor.up_sample";
-    op.fkind = FK_F620_ct_K64_C128;
+    op.fkind = kind;
     op.phase = ph;
     op.cin = cin;
     op.cout = cout;
@@ -627,11 +639,11 @@ static void add_fconvT(fpc_ctx* c, const void* x, int csx, int cin, int H, int W
     a.tiles_y = (H + k.TH - 1) / k.TH;
     fpc_ctx::ConvW cw;
     cw.w_off[0] = *blob_off;
-    *blob_off += ((size_t)a.nchunk * a.ntaps * K16 + 2) * nbt * 64 * 4;
+    *blob_off += ((size_t)a.nchunk * a.ntaps * K16 + 2) * k.planes * nbt * 64 * 4;
     cw.b_off = *blob_off;
     *blob_off += (size_t)nbt * 32;
     op.flops_per_frame = 2.0 * a.ntaps * H * W * cin * cout;
-    op.mfma_flops_per_frame = 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+    op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : 1.0) * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
     c->ops.push_back(op);
     c->convw.push_back(cw);
   }
@@ -658,9 +670,37 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   if (de) {
     add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K32_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
     add_fblock(c, {"descriptor.layer_in.1", FK_F320_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
-    add_fconvT(c, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
+    add_fconvT(c, FK_F620_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
     add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
     add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+  }
+}
+
+// dtype = FPC_F32_SPLIT: the fp32 plan's buffers (all fp32), every ResNetBlock / ConvTranspose on block_x3_kernel
+static void build_x3_ops(fpc_ctx* c, size_t* bo) {
+  const int H = c->H, W = c->W;
+  const int H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
+  const bool de = c->cfg.descriptor_enabled != 0;
+  float* feat = c->cat + 128;
+  add_fblock(c, {"encoder.layer1.0", FK_S816_s1_K64_C64, c->x0, 64, 1, 64, 64, H4, W4, c->x1, 64, 1, 64, true, false}, bo);
+  add_fblock(c, {"encoder.layer1.1", FK_S816_s1_K64_C64, c->x1, 64, 1, 64, 64, H4, W4, c->x2, 64, 1, 64, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.0", FK_S620_s2_K16_C128, c->x2, 64, 1, 64, 64, H4, W4, c->x3, 128, 1, 128, true, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", FK_S620_s1_K64_C128, c->x3, 128, 1, 128, 128, Hc, Wc, feat, 256, 1, 128, false, false}, bo);
+  add_fblock(c, {"detector.layer.0", FK_S620_s1_K64_C80, feat, 256, 1, 128, 128, Hc, Wc, c->d0, 80, 1, 65, true, false}, bo);
+  add_fblock(c, {"detector.layer.1", FK_S620_s1_K16_C80, c->d0, 80, 1, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
+  {
+    Op op;
+    op.type = OP_SOFTMAX;
+    op.name = "exp-softmax+depth_to_space+threshold";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+  }
+  if (de) {
+    add_fblock(c, {"descriptor.layer_in.0", FK_S320_s2_K16_C256, feat, 256, 1, 128, 128, Hc, Wc, c->y16a, 256, 1, 256, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.1", FK_S320_s1_K64_C256, c->y16a, 256, 1, 256, 256, H16, W16, c->y16b, 256, 1, 256, false, true}, bo);
+    add_fconvT(c, FK_S620_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
+    add_fblock(c, {"descriptor.layer_out.0", FK_S620_s1_K64_C128, c->cat, 256, 1, 256, 256, Hc, Wc, c->lo0, 128, 1, 128, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", FK_S620_s1_K64_C128, c->lo0, 128, 1, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
   }
 }
 
@@ -677,7 +717,7 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_h8 = cv.take<float>(npix8 * 128), o_x3 = cv.take<float>(npix8 * 128);
   const size_t o_cat = cv.take<float>(npix8 * 256);
   const size_t o_dh = cv.take<float>(npix8 * 72), o_dproj = cv.take<float>(npix8 * 72);
-  const size_t o_d0 = cv.take<float>(npix8 * 72), o_lg = cv.take<float>(npix8 * 80);
+  const size_t o_d0 = cv.take<float>(npix8 * 80), o_lg = cv.take<float>(npix8 * 80);
   const size_t o_h16 = cv.take<float>(npix16 * 256), o_y16a = cv.take<float>(npix16 * 256);
   const size_t o_y16b = cv.take<float>(npix16 * 256);
   const size_t o_loh = cv.take<float>(npix8 * 128), o_lo0 = cv.take<float>(npix8 * 128);
@@ -775,8 +815,9 @@ static int build_plan(fpc_ctx* c) {
     add_conv(c, t, &bo);
   };
   float* feat = c->cat + 128;  // encoder output lives in channels 128..255 of `cat`
-  if (c->bf16) {
-    build_bf16_ops(c, &bo);
+  if (c->bf16 || c->split) {
+    if (c->bf16) build_bf16_ops(c, &bo);
+    else build_x3_ops(c, &bo);
     goto postproc;
   }
   {
@@ -1000,7 +1041,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
         PackSource s{ci, a.nchunk * k.KC, (int)taps.size(),
                      [&](int n, int cc, int t) { return (double)w[((cc * 128 + n) * 3 + taps[t].first) * 3 + taps[t].second]; },
                      &f.s};
-        std::vector<float> frag = pack_conv_bf16({s}, co, nbt, k.KC);
+        std::vector<float> frag = pack_conv_bf16({s}, co, nbt, k.KC, k.planes);
         memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
         for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)((double)bct[n] * f.s[n] + f.t[n]);
         continue;
@@ -1011,7 +1052,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
       if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
         return FPC_E_MISSING_KEY;
       PackSource s1{ci, a.nchunk * k.KC, 9, [&](int n, int c_, int t) { return (double)w1[((size_t)(n * ci + c_)) * 9 + t]; }, &f1.s};
-      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC);
+      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC, k.planes);
       memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
       std::vector<PackSource> srcs;
@@ -1024,7 +1065,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
         srcs.push_back({ci, a.k16_x * 16, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
         for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
       }
-      frag = pack_conv_bf16(srcs, co, nbt, 16);
+      frag = pack_conv_bf16(srcs, co, nbt, 16, k.planes);
       memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
       continue;
@@ -1454,7 +1495,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   // H/8 or W/8 breaks its concat, so frames must be multiples of 16 unless it is disabled
   const int mult = cfg->descriptor_enabled ? 16 : 8;
   if (cfg->in_channels != 0 && cfg->in_channels != 1 && cfg->in_channels != 3) return FPC_E_INVALID;
-  if (cfg->dtype != FPC_F32 && cfg->dtype != FPC_BF16) return FPC_E_INVALID;
+  if (cfg->dtype != FPC_F32 && cfg->dtype != FPC_BF16 && cfg->dtype != FPC_F32_SPLIT) return FPC_E_INVALID;
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30))
@@ -1479,7 +1520,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->Wc = c->W / 8;
   c->cin = cfg->in_channels == 1 ? 1 : 3;
   c->bf16 = cfg->dtype == FPC_BF16;
-  c->lgcs = c->bf16 ? 80 : 72;
+  c->split = cfg->dtype == FPC_F32_SPLIT;
+  c->lgcs = (c->bf16 || c->split) ? 80 : 72;
   // kept points are pairwise > nms_dist apart (infinity norm): at most one per (r+1)^2 cell
   const int r1 = cfg->nms_dist + 1;
   const int worst = ((c->H + r1 - 1) / r1) * ((c->W + r1 - 1) / r1);

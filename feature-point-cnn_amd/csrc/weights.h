@@ -96,14 +96,35 @@ inline uint16_t host_f2bf(float x) {
   return (uint16_t)(u >> 16);
 }
 
-// The same for block_bf16_kernel: 16 channels per step, 8 bf16 (16 bytes) per lane;
-//   frag[(step * nbt + nb) * 64 + lane] = { B[step*16 + 8*half + j][nb*32 + (lane&31)] }, j = 0..7
+// Exact three-way split of a float into bf16 terms by truncation (block_x3.h): x = t[0] + t[1] + t[2].
+inline void host_split3(float x, uint16_t t[3]) {
+  uint32_t u, v;
+  memcpy(&u, &x, 4);
+  u &= 0xffff0000u;
+  float hi;
+  memcpy(&hi, &u, 4);
+  const float r = x - hi;
+  memcpy(&v, &r, 4);
+  v &= 0xffff0000u;
+  float mid;
+  memcpy(&mid, &v, 4);
+  const float q = r - mid;
+  uint32_t w;
+  memcpy(&w, &q, 4);
+  t[0] = (uint16_t)(u >> 16);
+  t[1] = (uint16_t)(v >> 16);
+  t[2] = (uint16_t)(w >> 16);
+}
+
+// The same for block_bf16_kernel / block_x3_kernel: 16 channels per step, 8 bf16 (16 bytes) per lane;
+//   planes = 1: frag[(step * nbt + nb) * 64 + lane] = { bf16(B[step*16 + 8*half + j][nb*32 + (lane&31)]) }, j = 0..7
+//   planes = 3: frag[((step * 3 + p) * nbt + nb) * 64 + lane] = term p of the exact split of the same element
 // Returned as floats (4 per lane) so that it sits in the same blob.
-inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, int cout, int nbt, int KC) {
+inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, int cout, int nbt, int KC, int planes = 1) {
   const int K16 = KC / 16;
   size_t nsteps = 0;
   for (auto& s : srcs) nsteps += (size_t)(s.cin_pad / KC) * s.ntaps * K16;
-  std::vector<float> out((nsteps + 2) * nbt * 64 * 4, 0.f);
+  std::vector<float> out((nsteps + 2) * planes * nbt * 64 * 4, 0.f);
   uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
   size_t step = 0;
   for (auto& s : srcs)
@@ -113,10 +134,16 @@ inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, in
           for (int nb = 0; nb < nbt; ++nb)
             for (int lane = 0; lane < 64; ++lane) {
               const int n = nb * 32 + (lane & 31), half = lane >> 5;
-              uint16_t* dst = &o16[((step * nbt + nb) * 64 + lane) * 8];
               for (int j = 0; j < 8; ++j) {
                 const int c = chunk * KC + k16 * 16 + 8 * half + j;
-                dst[j] = (n < cout && c < s.cin) ? host_f2bf((float)(s.w(n, c, tap) * (*s.scale)[n])) : 0;
+                const float v = (n < cout && c < s.cin) ? (float)(s.w(n, c, tap) * (*s.scale)[n]) : 0.f;
+                if (planes == 1) {
+                  o16[((step * nbt + nb) * 64 + lane) * 8 + j] = host_f2bf(v);
+                } else {
+                  uint16_t t[3];
+                  host_split3(v, t);
+                  for (int p = 0; p < 3; ++p) o16[(((step * 3 + p) * nbt + nb) * 64 + lane) * 8 + j] = t[p];
+                }
               }
             }
   return out;

@@ -54,9 +54,9 @@ class Engine:
         cfg.nms_dist, cfg.conf_thresh, cfg.border_remove = nms_dist, conf_thresh, border_remove
         cfg.descriptor_enabled, cfg.max_keypoints = int(bool(descriptor_enabled)), max_keypoints
         cfg.in_channels = in_channels
-        if dtype not in ("f32", "bf16"):
-            raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (dtype,))
-        cfg.dtype = 1 if dtype == "bf16" else 0   # FPC_F32 / FPC_BF16 (include/fpc.h)
+        if dtype not in ("f32", "bf16", "f32_split"):
+            raise ValueError("dtype must be 'f32', 'bf16' or 'f32_split', got %r" % (dtype,))
+        cfg.dtype = {"f32": 0, "bf16": 1, "f32_split": 2}[dtype]   # FPC_F32 / FPC_BF16 / FPC_F32_SPLIT (include/fpc.h)
         self.dtype = dtype
         self.in_channels = 1 if in_channels == 1 else 3
         self.cfg = cfg

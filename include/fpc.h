@@ -42,7 +42,7 @@ enum {
   FPC_E_NOT_CONVERGED = -7 /* NMS round limit hit (never seen)     */
 };
 
-enum { FPC_F32 = 0, FPC_BF16 = 1 };
+enum { FPC_F32 = 0, FPC_BF16 = 1, FPC_F32_SPLIT = 2 };
 
 /* Replaces SuperPointSettings (python/src/settings.py:2-8) / Settings
  * (cpp/src/settings.h:27-31) plus the geometry the reference takes from the frame. */
@@ -61,7 +61,10 @@ typedef struct fpc_config {
                           /* plane x3 (dataset_utils.py:19-20, cpp/src/camera.cc:17-18)    */
   int dtype;              /* FPC_F32 (0): fp32 activations and weights, the reference's    */
                           /* arithmetic; FPC_BF16 (1): bf16 activations / weights with     */
-                          /* fp32 accumulation (BASELINE.json configs[4])                  */
+                          /* fp32 accumulation (BASELINE.json configs[4]); FPC_F32_SPLIT   */
+                          /* (2): fp32 tensors, matrix products on the bf16 pipe with each */
+                          /* operand split exactly into three bf16 terms (block_x3.h):     */
+                          /* fp32-level accuracy, same 1e-4 parity bar as FPC_F32          */
   int reserved[5];
 } fpc_config;
 

@@ -42,11 +42,12 @@ def test_native_library_is_loaded(torch_gpu):
     assert "libfpc.so" in maps
 
 
-def test_f1_small_frame_dense_maps(torch_gpu, golden_dir):
+@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+def test_f1_small_frame_dense_maps(torch_gpu, golden_dir, dtype):
     g = np.load(os.path.join(golden_dir, "f1_layers_32x48.npz"))
     sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
     frame = synth.make_batch(int(g["seed_frame"]), 1, 32, 48)
-    e = engine(32, 48)
+    e = engine(32, 48, dtype=dtype)
     e.load_state_dict(sd)
     prob, desc, logits = e.forward(frame)
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=ATOL)
@@ -73,14 +74,17 @@ def _check_frame_against_oracle_postproc(oracle, prob_b, desc_b, res, h, w):
         np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
 @pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
-def test_f5_end_to_end(torch_gpu, golden_dir, tag):
+def test_f5_end_to_end(torch_gpu, golden_dir, tag, dtype):
+    """The reference's own outputs (tests/golden/make_golden.py) at the north_star bar -- dense maps within
+    1e-4, keypoint set identical -- for the fp32 MFMA path and for the split-operand path (block_x3.h)."""
     g = np.load(os.path.join(golden_dir, "f5_e2e_%s.npz" % tag))
     h, w = int(g["h"]), int(g["w"])
     de = bool(int(g["descriptor_enabled"]))
     sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
     frame = synth.make_batch(int(g["seed_frame"]), 1, h, w)
-    e = engine(h, w, descriptor_enabled=de)
+    e = engine(h, w, descriptor_enabled=de, dtype=dtype)
     e.load_state_dict(sd)
     prob, desc, logits = e.forward(frame)
     prob, desc, logits = prob.cpu().numpy(), desc.cpu().numpy(), logits.cpu().numpy()
@@ -340,13 +344,14 @@ def test_cpp_entry_point(torch_gpu, tmp_path):
     e.close()
 
 
-def test_hd_frames_and_odd_batch(torch_gpu):
+@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+def test_hd_frames_and_odd_batch(torch_gpu, dtype):
     """BASELINE.json configs[4] geometry (1280x960) in fp32, and a batch that does not split evenly
     over the sub-batch streams: dense maps against the oracle, post-processing exact."""
     h, w, n = 960, 1280, 3
     sd = synth.make_state_dict(5, dustbin_bias=7.0)
     frames = synth.make_batch(700, n, h, w)
-    e = engine(h, w, n)
+    e = engine(h, w, n, dtype=dtype)
     e.load_state_dict(sd)
     prob, desc, logits = e.forward(frames)
     res = e.detect(frames)
@@ -562,3 +567,33 @@ def test_bf16_hd_batch_properties(torch_gpu):
     assert d is None
     np.testing.assert_array_equal(xy, res[0][0])
     m.close()
+
+
+def test_split_operand_path_equals_fp32_path_keypoints(torch_gpu):
+    """dtype="f32_split" (fp32 tensors, products as six bf16 MFMAs on exactly split operands) on a full
+    VGA batch: the same keypoints, in the same order, as the fp32 MFMA path on every frame, confidences and
+    descriptors within the 1e-4 bar, and an exact oracle check of its post-processing."""
+    h, w, n = 480, 640, 8
+    sd = synth.make_state_dict(0, dustbin_bias=7.0)
+    frames = synth.make_batch(100, n, h, w)
+    a = engine(h, w, n)
+    a.load_state_dict(sd)
+    b = engine(h, w, n, dtype="f32_split")
+    b.load_state_dict(sd)
+    ra, rb = a.detect(frames), b.detect(frames)
+    pb, db, lb = b.forward(frames)
+    pa, da, la = a.forward(frames)
+    assert float((la - lb).abs().max()) < ATOL and float((da - db).abs().max()) < ATOL
+    oracle = oracle_mod()
+    _check_frame_against_oracle_postproc(oracle, pb[5].cpu().numpy(), db[5].cpu().numpy(), rb[5], h, w)
+    for (xa, ca, fa, na), (xb, cb, fb, nb) in zip(ra, rb):
+        # identical keypoint set; the order may differ only between confidences closer than the bar
+        ka, kb = xa[:, 1].astype(np.int64) * w + xa[:, 0], xb[:, 1].astype(np.int64) * w + xb[:, 0]
+        oa, ob = np.argsort(ka), np.argsort(kb)
+        np.testing.assert_array_equal(ka[oa], kb[ob])
+        np.testing.assert_allclose(ca[oa], cb[ob], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(fa[oa], fb[ob], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(ca, cb, rtol=0, atol=ATOL)      # both descending
+        assert abs(na - nb) <= 2                                   # candidates within 1e-4 of the threshold
+    a.close()
+    b.close()
