@@ -16,6 +16,7 @@
 // (fp32, split when read), shortcut (projection as extra K, or identity) and ReLU in the epilogue.
 #pragma once
 #include "block_bf16.h"
+#include "kernels_misc.h"
 
 namespace fpc {
 
@@ -159,17 +160,31 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
 #pragma unroll
       for (int k = 0; k < K16; ++k) {
         uint4 bn[NB][3];
+#ifdef FPC_X3_NOB
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) { bn[nb][p] = bc[nb][p]; asm volatile("" : "+v"(bn[nb][p].x)); }
+#else
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
           for (int p = 0; p < 3; ++p) bn[nb][p] = wp[p * planestride + nb * 64];
+#endif
         wp += stepstride;
         __builtin_amdgcn_sched_barrier(0);
         uint4 av[MB][3];
+#ifdef FPC_X3_NOA
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) { av[mb][p] = make_uint4(toff + k, tid, p, mb); asm volatile("" : "+v"(av[mb][p].x)); }
+#else
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int p = 0; p < 3; ++p) av[mb][p] = lds16[p * PLANE16 + abase[mb] + toff + k * 2];
+#endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -325,6 +340,165 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
         const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
         *reinterpret_cast<float4*>(outp + opix * a.cso + c4 * 4) = v;
       }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Stem + max-pool on split operands (stem_pool_kernel of kernels_misc.h with the 7x7/2 convolution as six
+// bf16 MFMAs per product).  K is laid out as (input channel, filter row) x 8 filter columns (7 real + one
+// zero weight): a lane's 8 values of one K16 half are 8 consecutive pixels of one input row, read from the
+// LDS window (three bf16 planes) as four dwords.  K16 step s covers rows 2s (lanes 0-31) and 2s+1 (32-63).
+// ---------------------------------------------------------------------------------
+constexpr int STEMX_LW = 40;                                   // bf16 per LDS row (37 real + zero pad)
+constexpr int STEMX_PLANE = 3 * STEM_HALO * STEMX_LW;          // bf16 per plane (CIN = 3)
+constexpr int STEMX_LDS_BYTES = (3 * STEMX_PLANE * 2 > 256 * STEM_TROW * 4) ? 3 * STEMX_PLANE * 2 : 256 * STEM_TROW * 4;
+
+struct StemX3Args {
+  const float* in;      // [B,CIN,H,W]
+  const uint4* wfrag;   // [steps + 2][3 planes][2 nb][64] uint4
+  const float* bias;    // [64]
+  float* out;           // [B,Hp,Wp,64], zero-filled
+  int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
+  constexpr int ROWS = CIN * 7, STEPS = (ROWS + 1) / 2;  // 21 -> 11 steps; 7 -> 4
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STEMX_LDS_BYTES];
+  unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds_raw);
+  const unsigned* lds32 = reinterpret_cast<const unsigned*>(lds_raw);
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x / tiles;
+  const int t = blockIdx.x - b * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
+
+  const uint4* wp = a.wfrag + lane;
+  uint4 bc[2][3];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bc[nb][p] = wp[(p * 2 + nb) * 64];
+  wp += 6 * 64;
+
+  {  // input window -> three bf16 planes in LDS (pad columns zero): loads first, then split + write
+    constexpr int NE = CIN * STEM_HALO * STEMX_LW, IT = (NE + 255) / 256;
+    float v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / STEMX_LW, hx = e - row * STEMX_LW;
+      const int c = row / STEM_HALO, hy = row - c * STEM_HALO;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = e < NE && hx < STEM_HALO && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float x = a.in[ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0];
+      v[i] = ok ? x : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * 256;
+      if (e < NE) {
+        const unsigned u = __float_as_uint(v[i]);
+        const unsigned hi = u & 0xffff0000u;
+        const float r = v[i] - __uint_as_float(hi);
+        const unsigned mi = __float_as_uint(r) & 0xffff0000u;
+        const float q = r - __uint_as_float(mi);
+        lds16[e] = (unsigned short)(hi >> 16);
+        lds16[STEMX_PLANE + e] = (unsigned short)(mi >> 16);
+        lds16[2 * STEMX_PLANE + e] = (unsigned short)(__float_as_uint(q) >> 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  int abase[2];  // dword index of (row 0, 2*px) of this lane's output pixel
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = (wave * 2 + mb) * 32 + l31;
+    abase[mb] = ((2 * (m / STEM_T)) * STEMX_LW + 2 * (m % STEM_T)) / 2;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    uint4 bn[2][3];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bn[nb][p] = wp[(p * 2 + nb) * 64];
+    wp += 6 * 64;
+    __builtin_amdgcn_sched_barrier(0);
+    // this lane's filter row: (c, ky); a padded row (weights zero) re-reads the last real one
+    const int r0 = 2 * s < ROWS ? 2 * s : ROWS - 1, r1 = 2 * s + 1 < ROWS ? 2 * s + 1 : ROWS - 1;
+    const int off0 = ((r0 / 7) * STEM_HALO + (r0 % 7)) * (STEMX_LW / 2), off1 = ((r1 / 7) * STEM_HALO + (r1 % 7)) * (STEMX_LW / 2);
+    const int off = half ? off1 : off0;
+    uint4 av[2][3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned* q = lds32 + p * (STEMX_PLANE / 2) + abase[mb] + off;
+        av[mb][p] = make_uint4(q[0], q[1], q[2], q[3]);
+      }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb], bc[nb]);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+  }
+
+  // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool (as stem_pool_kernel)
+  const int gy0 = ty * STEM_T, gx0 = tx * STEM_T;
+  const int c = tid & 31;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    __syncthreads();
+    const float bias = a.bias[nb * 32 + l31];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wave * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v = acc[mb][nb][r] + bias;
+        lds[m * STEM_TROW + l31] = v > 0.f ? v : 0.f;
+      }
+    __syncthreads();
+    for (int p = tid >> 5; p < 81; p += 8) {
+      const int py = p / 9, px = p - py * 9;
+      const int gpy = ty * 8 + py, gpx = tx * 8 + px;
+      if (gpy >= a.Hp || gpx >= a.Wp) continue;
+      float mx = -1.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int rr = 2 * py - 1 + dy;
+        if (rr < 0 || rr > 15 || gy0 + rr >= a.Ho) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int cc = 2 * px - 1 + dx;
+          if (cc < 0 || cc > 15 || gx0 + cc >= a.Wo) continue;
+          mx = fmaxf(mx, lds[(rr * STEM_T + cc) * STEM_TROW + c]);
+        }
+      }
+      if (mx < 0.f) continue;
+      float* dst = a.out + ((size_t)(b * a.Hp + gpy) * a.Wp + gpx) * 64 + nb * 32 + c;
+      if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
+        *dst = mx;
+      else
+        atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
     }
   }
 }

@@ -763,10 +763,13 @@ static int build_plan(fpc_ctx* c) {
     op.name = "encoder.conv1+bn1+relu";
     op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;  // of the reference's 3-channel convolution, also for gray frames
     op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
+    if (c->split || c->bf16)  // stem_pool_x3_kernel: (rows + 1) / 2 K16 steps of six bf16 MFMAs
+      op.mfma_flops_per_frame = 6 * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
     c->ops.push_back(op);
     c->convw.push_back({});
     c->stem_w_off = bo;
-    bo += (size_t)(STEM_KG + 2) * 2 * 64 * 4;  // + two zero groups: the fused kernel prefetches ahead
+    // + two zero groups: the fused kernel prefetches ahead; the split-operand stem needs 13 steps x 3 planes
+    bo += std::max<size_t>((size_t)(STEM_KG + 2) * 2 * 64 * 4, (size_t)13 * 3 * 2 * 64 * 4);
     c->stem_b_off = bo;
     bo += 64;
     op = Op();
@@ -953,6 +956,25 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
     if (!w || !fold_bn(m, "encoder.bn1", 64, &f, missing)) return FPC_E_MISSING_KEY;
     float* dst = blob.data() + c->stem_w_off;
     const int kreal = c->cin * 49, kg = (kreal + 7) / 8;
+    if (c->split || c->bf16) {  // stem_pool_x3_kernel: [step][plane][nb][lane] x 8 bf16; k = (row = 2*step + half, kx = j)
+      uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+      const int rows = c->cin * 7, steps = (rows + 1) / 2;
+      for (int st = 0; st < steps; ++st)
+        for (int nb = 0; nb < 2; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int row = 2 * st + (lane >> 5), n = nb * 32 + (lane & 31);
+              double v = 0.0;
+              if (row < rows && j < 7) {
+                const int k = row * 7 + j;  // (c, ky, kx) flattened exactly as conv1.weight[n]
+                if (c->cin == 3) v = (double)w[n * 147 + k];
+                else v = (double)w[n * 147 + k] + (double)w[n * 147 + 49 + k] + (double)w[n * 147 + 98 + k];
+              }
+              uint16_t t3[3];
+              host_split3((float)(v * f.s[n]), t3);
+              for (int pl = 0; pl < 3; ++pl) d16[((((size_t)st * 3 + pl) * 2 + nb) * 64 + lane) * 8 + j] = t3[pl];
+            }
+    } else
     for (int g = 0; g < kg; ++g)
       for (int nb = 0; nb < 2; ++nb)
         for (int lane = 0; lane < 64; ++lane)
@@ -1265,7 +1287,15 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
           a.out = x0;
           a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Hp = H / 4; a.Wp = W / 4;
           a.tiles_x = c->stem.tiles_x; a.tiles_y = c->stem.tiles_y;
-          if (c->cin == 1)
+          if (c->split || c->bf16) {
+            StemX3Args x{};
+            x.in = a.in; x.wfrag = reinterpret_cast<const uint4*>(a.wfrag); x.bias = a.bias; x.out = a.out;
+            x.H = H; x.W = W; x.Ho = a.Ho; x.Wo = a.Wo; x.Hp = a.Hp; x.Wp = a.Wp; x.tiles_x = a.tiles_x; x.tiles_y = a.tiles_y;
+            if (c->cin == 1)
+              hipLaunchKernelGGL(stem_pool_x3_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, x);
+            else
+              hipLaunchKernelGGL(stem_pool_x3_kernel<3>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, x);
+          } else if (c->cin == 1)
             hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
           else
             hipLaunchKernelGGL(stem_pool_kernel<3>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
@@ -1851,7 +1881,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
     if (kernels) {
       const char* k = "?";
       if (op) switch (op->type) {
-          case OP_STEM: k = c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
+          case OP_STEM: k = (c->split || c->bf16) ? "stem_pool_x3_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;
