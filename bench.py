@@ -66,6 +66,49 @@ def cpu_baseline(state_dict, frames):
                       "oracle/fpc_oracle.c with %d OpenMP threads, %.1f s" % (n, W, H, threads, dt)}
 
 
+def host_fed_rates(sd, frames_np, local, dtype, steps=12):
+    """H2D-inclusive rates (the second figure, never `value`): every step uploads its batch from
+    pinned host memory and runs the path; two contexts on two streams so that batch k+1 uploads while batch k
+    computes.  (a) the reference's input, fp32 RGB [n,3,H,W]; (b) 8-bit RGB HWC frames converted on the device
+    (fpc_detect_u8)."""
+    dev = torch.device("cuda", local)
+    res = {}
+    u8 = np.clip(np.rint(frames_np.transpose(0, 2, 3, 1) * 255.0), 0, 255).astype(np.uint8)
+    for tag, host in (("f32_rgb_nchw", torch.from_numpy(frames_np).pin_memory()),
+                      ("u8_rgb_hwc", torch.from_numpy(np.ascontiguousarray(u8)).pin_memory())):
+        ctxs = []
+        for _ in range(2):
+            st = torch.cuda.Stream(device=dev)
+            e = Engine(H, W, max_batch=BATCH, device=local, dtype=dtype)
+            e.load_state_dict(sd)
+            with torch.cuda.stream(st):
+                e.use_torch_stream()
+            ctxs.append((st, e, torch.empty_like(host, device=dev)))
+
+        def step(i):
+            st, e, buf = ctxs[i % 2]
+            with torch.cuda.stream(st):
+                buf.copy_(host, non_blocking=True)
+                if tag == "u8_rgb_hwc":
+                    e.detect_u8_async(buf, BATCH, "rgb_hwc")
+                else:
+                    e.detect_async(buf, BATCH)
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        res[tag] = {"value": round(BATCH * steps / dt, 2), "unit": "frames/s", "steps": steps,
+                    "h2d_bytes_per_frame": int(host[0].numel() * host.element_size()),
+                    "h2d_gbytes_per_s": round(host.numel() * host.element_size() * steps / dt / 1e9, 2)}
+        for _, e, _b in ctxs:
+            e.close()
+    return res
+
+
 def symbol_stats(timings, steps):
     """kernel symbol -> dict(avg ms, algorithmic / MFMA-issued FLOPs per launch, launches per step, layers)."""
     by = {}
@@ -116,6 +159,7 @@ def main():
                     help="vga32 only. f32 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32, Winograd where it pays). "
                          "f32_split: fp32 tensors, every product as six bf16 MFMAs on exactly split operands "
                          "(block_x3.h) -- same 1e-4 parity bar, reported beside the headline as `split_operand_mode`")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (H2D-inclusive) passes")
     ap.add_argument("--no-alt-pass", action="store_true", help="skip the extra pass in the other fp32 arithmetic mode")
     args = ap.parse_args()
     global H, W, BATCH, PEAK_TFLOPS, PEAK_ISSUED_TFLOPS
@@ -220,6 +264,9 @@ def main():
                "ms_per_step": round(d1 / ks * 1e3, 4), "keypoints_per_frame": round(float(np.mean(acnt)), 1),
                "same_keypoint_counts_as_headline_mode": bool(np.array_equal(acnt, cnt))}
         ea.close()
+    host_fed = None
+    if rank == 0 and world == 1 and not args.no_host_fed and args.workload == "vga32" and not args.gray:
+        host_fed = host_fed_rates(sd, frames_np, local, dtype)
     total_frames = BATCH * args.steps * world
 
     if rank == 0:
@@ -272,6 +319,8 @@ def main():
                 for name, kern, ms, fl, mf in stim:
                     lay.setdefault(name, []).append(ms)
                 out["layer_ms_serial"] = {k: round(float(np.mean(v)), 4) for k, v in lay.items()}
+        if host_fed is not None:
+            out["host_fed"] = host_fed
         if alt is not None:
             out["split_operand_mode" if alt["dtype"] == "f32_split" else "plain_f32_mfma_mode"] = alt
         if world == 1 and not args.no_cpu_baseline:

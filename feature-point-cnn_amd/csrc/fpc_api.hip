@@ -299,6 +299,8 @@ struct fpc_ctx {
   unsigned long long* sort_scratch;
   unsigned long long *rowbest, *colbest;  // descriptor matching workspace, `cap` entries each
 
+  float* u8stage = nullptr;          // fpc_detect_u8: converted frames [B,cin,H,W], allocated on first use
+
   // packed weights
   float* blob = nullptr;
   size_t blob_floats = 0;
@@ -1640,6 +1642,7 @@ void fpc_destroy(fpc_ctx* c) {
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->slab) hipFree(c->slab);
   if (c->blob) hipFree(c->blob);
+  if (c->u8stage) hipFree(c->u8stage);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1754,6 +1757,22 @@ int fpc_detect(fpc_ctx* c, const float* frames, int n) {
   const bool de = c->cfg.descriptor_enabled != 0;
   return for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 1); });
 }
+
+int fpc_detect_u8(fpc_ctx* c, const uint8_t* frames, int n, int layout) {
+  if (!c || !frames || n < 1 || n > c->B || layout < FPC_U8_GRAY || layout > FPC_U8_BGR_HWC_GRAY) return FPC_E_INVALID;
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  const int cout = (layout == FPC_U8_GRAY || layout == FPC_U8_BGR_HWC_GRAY) ? 1 : 3;
+  if (cout != c->cin) return FPC_E_INVALID;  // gray layouts feed an in_channels = 1 ctx, colour layouts a 3-channel one
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  const int HW = c->H * c->W;  // multiple of 64 (H, W multiples of 8)
+  if (!c->u8stage) HIPCHECK(hipMalloc((void**)&c->u8stage, (size_t)c->B * c->cin * HW * sizeof(float)));
+  const size_t quads = (size_t)n * (HW / 4);
+  hipLaunchKernelGGL(u8_to_float_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c->stream, frames,
+                     c->u8stage, n, HW, layout);
+  return fpc_detect(c, c->u8stage, n);
+}
+
+const float* fpc_u8_staging(fpc_ctx* c) { return c ? c->u8stage : nullptr; }
 
 int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n) {
   if (!c || !prob || n < 1 || n > c->B) return FPC_E_INVALID;

@@ -675,4 +675,49 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, int 
   out[i] = in[((size_t)b * C + c) * HW + p];
 }
 
+// ---------------------------------------------------------------------------------
+// 8-bit camera frames -> planar float frames (fpc_detect_u8; python/src/camera.py:31,
+// inferencewrapper.py:70-81, inference.py:79, cpp/src/camera.cc:17-18).  HBM-bound:
+// 1 or 3 bytes in, 4 or 12 bytes out per pixel; four pixels per thread.
+// layout: 0 gray, 1 RGB HWC, 2 BGR HWC (swap), 3 BGR HWC -> gray (OpenCV 8-bit fixed point)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void u8_to_float_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                           int n, int HW, int layout) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;  // over n * HW / 4 pixel quads (HW % 4 == 0)
+  const size_t quads = (size_t)n * (HW / 4);
+  if (q >= quads) return;
+  const size_t f = q / (HW / 4), p = (q - f * (HW / 4)) * 4;
+  if (layout == 0) {
+    const uchar4 v = *reinterpret_cast<const uchar4*>(in + f * HW + p);
+    *reinterpret_cast<float4*>(out + f * HW + p) = make_float4((float)v.x / 255.0f, (float)v.y / 255.0f, (float)v.z / 255.0f, (float)v.w / 255.0f);
+    return;
+  }
+  const unsigned char* src = in + (f * HW + p) * 3;
+  const uint3 w = *reinterpret_cast<const uint3*>(src);  // 12 bytes = 4 pixels x 3 channels (12 | offset)
+  unsigned char b[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b[i] = (w.x >> (8 * i)) & 0xff;
+    b[4 + i] = (w.y >> (8 * i)) & 0xff;
+    b[8 + i] = (w.z >> (8 * i)) & 0xff;
+  }
+  if (layout == 3) {
+    const float k = (float)(1.0 / 255.0);
+    float g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned y = (b[3 * i] * 1868u + b[3 * i + 1] * 9617u + b[3 * i + 2] * 4899u + 8192u) >> 14;
+      g[i] = __fmul_rn((float)y, k);
+    }
+    *reinterpret_cast<float4*>(out + f * HW + p) = make_float4(g[0], g[1], g[2], g[3]);
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = layout == 2 ? 2 - c : c;
+    *reinterpret_cast<float4*>(out + (f * 3 + c) * HW + p) =
+        make_float4((float)b[sc] / 255.0f, (float)b[3 + sc] / 255.0f, (float)b[6 + sc] / 255.0f, (float)b[9 + sc] / 255.0f);
+  }
+}
+
 }  // namespace fpc

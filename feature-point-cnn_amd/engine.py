@@ -151,6 +151,32 @@ class Engine:
         self.detect_async(frames, frames.shape[0])
         return self.fetch(frames.shape[0])
 
+    U8_LAYOUTS = {"gray": 0, "rgb_hwc": 1, "bgr_hwc": 2, "bgr_hwc_gray": 3}   # FPC_U8_* (include/fpc.h)
+
+    def detect_u8_async(self, frames_u8_dev, n, layout):
+        """8-bit device frames (camera.py:31: float32(u8) / 255.0, converted on the device) -> the whole path."""
+        _lib.check(self._l.fpc_detect_u8(self._ctx, frames_u8_dev.data_ptr(), n, self.U8_LAYOUTS[layout]), "fpc_detect_u8")
+
+    def detect_u8(self, frames_u8, layout):
+        """frames_u8: uint8 [n,H,W] ("gray") or [n,H,W,3] ("rgb_hwc", "bgr_hwc", "bgr_hwc_gray")."""
+        if not isinstance(frames_u8, torch.Tensor):
+            frames_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8, dtype=np.uint8))
+        f = frames_u8.to(self.torch_device, torch.uint8).contiguous()
+        want = (self.h, self.w) if layout == "gray" else (self.h, self.w, 3)
+        if tuple(f.shape[1:]) != want or f.shape[0] > self.max_batch:
+            raise ValueError("u8 frames must be [n<=%d,%s], got %s" % (self.max_batch, want, tuple(f.shape)))
+        torch.cuda.synchronize(self.torch_device)
+        self.detect_u8_async(f, f.shape[0], layout)
+        return self.fetch(f.shape[0])
+
+    def u8_staging(self, n):
+        """The float frames [n,C,H,W] the last detect_u8 call fed to the network (a copy)."""
+        self.sync()
+        ptr = self._l.fpc_u8_staging(self._ctx)
+        nbytes = n * self.in_channels * self.h * self.w * 4
+        raw = torch.as_tensor(_DevArray(ptr, nbytes), device=self.torch_device)   # uint8 view of the library's buffer
+        return raw.view(torch.float32).reshape(n, self.in_channels, self.h, self.w).clone()
+
     def get_points(self, prob_map, desc_map=None):
         """Post-processing only, on caller-provided dense maps (netutils.py:78-121)."""
         prob_map = prob_map.to(self.torch_device, torch.float32).contiguous()

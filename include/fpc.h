@@ -139,6 +139,23 @@ int fpc_forward(fpc_ctx* ctx, const float* frames_dev, int n, float* prob_map_de
  * Asynchronous; results stay on the device until fetched. */
 int fpc_detect(fpc_ctx* ctx, const float* frames_dev, int n);
 
+/* The step in front of the path, on the device: 8-bit camera frames -> the float frames
+ * fpc_detect takes, then fpc_detect.  Uploading u8 instead of fp32 RGB cuts the host-to-device bytes 4x
+ * (12x for gray).  Conversion is `float32(u8) / 255.0f` (python/src/camera.py:31, dataset_utils.py:23,
+ * preprocess_coco.py:25), written as planar [n,C,H,W] into a staging buffer the ctx allocates on first use.
+ *   FPC_U8_GRAY         [n,H,W]    -> [n,1,H,W]  (ctx with in_channels = 1)
+ *   FPC_U8_RGB_HWC      [n,H,W,3]  -> [n,3,H,W]  (ctx with in_channels = 3; inferencewrapper.py:70-81)
+ *   FPC_U8_BGR_HWC      [n,H,W,3]  -> [n,3,H,W] with the channel swap of cv2.COLOR_BGR2RGB (inference.py:79)
+ *   FPC_U8_BGR_HWC_GRAY [n,H,W,3]  -> [n,1,H,W]  cv::COLOR_BGR2GRAY on 8-bit data then convertTo(CV_32FC1,
+ *                       1/255) (cpp/src/camera.cc:17-18): OpenCV's documented 14-bit fixed-point weights
+ *                       (B 1868, G 9617, R 4899, +8192 >> 14) and a float multiply by (float)(1.0/255.0).
+ *                       OpenCV is not available to this build: parity for THIS layout is unpinned.
+ * Resizing (cv2.resize, inference.py:72-85) is not done here. */
+enum { FPC_U8_GRAY = 0, FPC_U8_RGB_HWC = 1, FPC_U8_BGR_HWC = 2, FPC_U8_BGR_HWC_GRAY = 3 };
+int fpc_detect_u8(fpc_ctx* ctx, const uint8_t* frames_dev, int n, int layout);
+/* The converted float frames of the last fpc_detect_u8 call ([n,C,H,W], device) -- for tests. */
+const float* fpc_u8_staging(fpc_ctx* ctx);
+
 /* Runs only the post-processing of fpc_detect on a caller-provided probability map
  * [n,H,W] (device) -- get_points on its own (netutils.py:78-100). Descriptors are
  * sampled from desc_nchw_dev [n,128,H/8,W/8] when it is not NULL. */

@@ -522,3 +522,31 @@ void oracle_first_within(const float* key, int nk, const float* cur, int nc, int
       }
   }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * 8-bit frames -> the float frames the network takes (the step in front of the path; the checker of
+ * fpc_detect_u8).  layout 0: gray [n,HW] -> [n,1,HW];  1: RGB HWC -> planar [n,3,HW]
+ * (python/src/inferencewrapper.py:70-81 transposes, python/src/camera.py:31 divides: float32(u8) / 255.0);
+ * 2: BGR HWC with the swap of cv2.COLOR_BGR2RGB (python/src/inference.py:79);  3: BGR HWC -> gray as
+ * cv::cvtColor(COLOR_BGR2GRAY) on 8-bit data followed by convertTo(CV_32FC1, 1.0/255.0)
+ * (cpp/src/camera.cc:17-18).  OpenCV is absent from /root/reference and from this image: layout 3 restates
+ * OpenCV 4.x's published 8-bit algorithm (color_yuv: B2Y 1868, G2Y 9617, R2Y 4899, shift 14 with rounding;
+ * convertScale 8u->32f: float multiply by (float)alpha) -- PARITY UNPINNED for layout 3.
+ * Layouts 0-2 are pinned by fixture F6 (tests/golden/f6_u8_to_float.npz: numpy's own evaluation of the
+ * reference's expression for all 256 byte values).
+ * ------------------------------------------------------------------------------------------- */
+void oracle_u8_to_float(const uint8_t* in, int n, int hw, int layout, float* out) {
+  for (int f = 0; f < n; ++f)
+    for (int p = 0; p < hw; ++p) {
+      if (layout == 0) {
+        out[(size_t)f * hw + p] = (float)in[(size_t)f * hw + p] / 255.0f;
+      } else if (layout == 3) {
+        const uint8_t* s = in + ((size_t)f * hw + p) * 3;
+        const unsigned y = (s[0] * 1868u + s[1] * 9617u + s[2] * 4899u + 8192u) >> 14;
+        out[(size_t)f * hw + p] = (float)y * (float)(1.0 / 255.0);
+      } else {
+        const uint8_t* s = in + ((size_t)f * hw + p) * 3;
+        for (int c = 0; c < 3; ++c) out[((size_t)f * 3 + c) * hw + p] = (float)s[layout == 2 ? 2 - c : c] / 255.0f;
+      }
+    }
+}

@@ -147,3 +147,14 @@ def first_within(key, cur, tolerance=0.8):
         lib().oracle_first_within(_p(k), len(k), _p(c), len(c), k.shape[1], ctypes.c_double(tolerance),
                                   out.ctypes.data_as(_i32p))
     return out
+
+
+def u8_to_float(frames_u8, layout):
+    """8-bit frames -> float frames [n,C,H,W] (camera.py:31, inferencewrapper.py:70-81, inference.py:79,
+    cpp/src/camera.cc:17-18).  layout: 0 gray [n,H,W], 1 RGB HWC, 2 BGR HWC (swap), 3 BGR HWC -> gray."""
+    a = np.ascontiguousarray(frames_u8, np.uint8)
+    n, h, w = a.shape[0], a.shape[1], a.shape[2]
+    cout = 1 if layout in (0, 3) else 3
+    out = np.empty((n, cout, h, w), np.float32)
+    lib().oracle_u8_to_float(a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n, h * w, int(layout), _p(out))
+    return out

@@ -222,11 +222,34 @@ def golden_end_to_end():
               "thresh margin %.3g" % thr_margin, "NaN desc:", int(np.isnan(desc).sum()))
 
 
+def golden_u8():
+    """F6: the reference's 8-bit -> float conversion, evaluated by the libraries the reference calls, for all
+    256 byte values: `frame.astype('float32') / 255.0` (python/src/camera.py:31; dataset_utils.py:23 is the
+    same expression) and `img.float().div(255)` (python/src/preprocess_coco.py:25); and the HWC -> CHW
+    transpose of inferencewrapper.py:70-81 / the BGR->RGB swap of inference.py:79 on a small random image
+    (numpy slicing stands in for cv2.cvtColor, which is a pure channel permutation)."""
+    b = np.arange(256, dtype=np.uint8)
+    t_np = b.astype('float32') / 255.0
+    t_np2 = b.astype(np.float32) / 255.
+    t_torch = torch.from_numpy(b).float().div(255).numpy()
+    assert t_np.dtype == np.float32 and np.array_equal(t_np, t_np2) and np.array_equal(t_np, t_torch)
+    rng = np.random.Generator(np.random.PCG64(66))
+    img = rng.integers(0, 256, size=(2, 16, 24, 3), dtype=np.uint8)       # [n,H,W,3]
+    rgb = (img.astype('float32') / 255.0).transpose(0, 3, 1, 2).copy()    # prepare_input per frame
+    bgr_swapped = (img[..., ::-1].astype('float32') / 255.0).transpose(0, 3, 1, 2).copy()
+    np.savez(os.path.join(HERE, "f6_u8_to_float.npz"), table=t_np, img=img, rgb=rgb, bgr_swapped=bgr_swapped)
+    print("F6 u8 table", t_np[:3], t_np[-1])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "u8":
+        golden_u8()
+        sys.exit(0)
     golden_layers()
     golden_restore()
     golden_get_points()
     golden_get_descriptors()
     golden_end_to_end()
+    golden_u8()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

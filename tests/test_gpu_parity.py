@@ -597,3 +597,45 @@ def test_split_operand_path_equals_fp32_path_keypoints(torch_gpu):
         assert abs(na - nb) <= 2                                   # candidates within 1e-4 of the threshold
     a.close()
     b.close()
+
+
+def test_u8_frames_on_device(torch_gpu, golden_dir):
+    """fpc_detect_u8: the conversion kernel is bit-exact against the oracle (itself pinned by F6 for the
+    layouts the Python reference uses) on every byte value and on random frames, and the keypoints equal
+    those of fpc_detect on the converted float frames."""
+    oracle = oracle_mod()
+    h, w, n = 64, 96, 3
+    rng = np.random.Generator(np.random.PCG64(9))
+    sd = synth.make_state_dict(3, dustbin_bias=2.0)
+    col = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+    col[0].reshape(-1)[:256 * 3] = np.repeat(np.arange(256, dtype=np.uint8), 3)   # every byte value in every channel
+    e3 = engine(h, w, n)
+    e3.load_state_dict(sd)
+    for layout, code in (("rgb_hwc", 1), ("bgr_hwc", 2)):
+        res = e3.detect_u8(col, layout)
+        want = oracle.u8_to_float(col, code)
+        np.testing.assert_array_equal(e3.u8_staging(n).cpu().numpy(), want)
+        ref = e3.detect(want)
+        for a, b in zip(res, ref):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(a[2], b[2])
+    g = np.load(os.path.join(golden_dir, "f6_u8_to_float.npz"))
+    e3.detect_u8(np.broadcast_to(np.arange(256, dtype=np.uint8).repeat(3 * 24).reshape(1, 64, 96, 3), (1, 64, 96, 3)), "rgb_hwc")
+    got = e3.u8_staging(1).cpu().numpy()[0, 0].ravel()[::24]
+    np.testing.assert_array_equal(got[:256], g["table"])           # the reference's own table
+    e3.close()
+    e1 = engine(h, w, n, in_channels=1)
+    e1.load_state_dict(sd)
+    gray = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    res = e1.detect_u8(gray, "gray")
+    want = oracle.u8_to_float(gray, 0)
+    np.testing.assert_array_equal(e1.u8_staging(n).cpu().numpy(), want)
+    ref = e1.detect(want)
+    for a, b in zip(res, ref):
+        np.testing.assert_array_equal(a[0], b[0])
+    e1.detect_u8(col, "bgr_hwc_gray")                               # cpp/src/camera.cc:17-18 (unpinned restatement)
+    np.testing.assert_array_equal(e1.u8_staging(n).cpu().numpy(), oracle.u8_to_float(col, 3))
+    with pytest.raises(Exception):
+        e1.detect_u8(col, "rgb_hwc")                                # colour layout into a gray ctx
+    e1.close()

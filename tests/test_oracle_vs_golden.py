@@ -122,3 +122,17 @@ def test_f5_end_to_end(golden_dir, tag):
         np.testing.assert_allclose(d[inv[g["desc_subset_idx"]]], g["desc_subset"], rtol=0, atol=2e-5)
     else:
         assert not desc.any()
+
+
+def test_f6_u8_to_float(golden_dir):
+    """8-bit frames -> float frames (camera.py:31, preprocess_coco.py:25, inferencewrapper.py:70-81,
+    inference.py:79): the oracle against numpy's / torch's own evaluation of the reference's expressions."""
+    g = np.load(os.path.join(golden_dir, "f6_u8_to_float.npz"))
+    table = oracle.u8_to_float(np.arange(256, dtype=np.uint8).reshape(1, 16, 16), 0)
+    np.testing.assert_array_equal(table.ravel(), g["table"])
+    np.testing.assert_array_equal(oracle.u8_to_float(g["img"], 1), g["rgb"])
+    np.testing.assert_array_equal(oracle.u8_to_float(g["img"], 2), g["bgr_swapped"])
+    gray = oracle.u8_to_float(g["img"], 3)                 # OpenCV's 8-bit BGR2GRAY, restated (unpinned)
+    assert gray.shape == (2, 1, 16, 24) and gray.min() >= 0.0 and gray.max() <= 1.0
+    b, gch, r = (g["img"][..., i].astype(np.float64) for i in range(3))
+    assert np.max(np.abs(gray[:, 0] * 255.0 - (0.114 * b + 0.587 * gch + 0.299 * r))) <= 0.51
