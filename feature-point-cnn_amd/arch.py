@@ -82,3 +82,33 @@ def conv_macs(h, w, descriptor=True):
         m += h16 * w16 * 256 * 128 * 9           # ConvTranspose2d: 9 taps per INPUT pixel
         m += blk(256, 128, h8, w8, True) + blk(128, 128, h8, w8, False)
     return m
+
+
+# ---- the reference's C++ network: superpoint::SPModel (cpp/src/model.cc:4-94, cpp/src/settings.h:19-25) ----
+VGG_ENCODER_DIMS = [(1, 64), (64, 64), (64, 128), (128, 128)]   # settings.h:19-22
+VGG_DESC_DIM = 256                                               # settings.h:25
+
+
+def vgg_state_dict_spec():
+    """Ordered {name: shape} of SPModel's 24 parameters, as its named_parameters() lists them (the keys of the
+    flat dict cpp/src/superpoint.cc:27-55 loads; printed by oracle/_ref/ref_vgg_forward)."""
+    e = []
+    for i, (cin, cout) in enumerate(VGG_ENCODER_DIMS):
+        e += [("encoder_conv%d_a.weight" % i, (cout, cin, 3, 3)), ("encoder_conv%d_a.bias" % i, (cout,)),
+              ("encoder_conv%d_b.weight" % i, (cout, cout, 3, 3)), ("encoder_conv%d_b.bias" % i, (cout,))]
+    e += [("detector_conv_a.weight", (256, 128, 3, 3)), ("detector_conv_a.bias", (256,)),
+          ("detector_conv_b.weight", (65, 256, 1, 1)), ("detector_conv_b.bias", (65,)),
+          ("descriptor_conv_a.weight", (256, 128, 3, 3)), ("descriptor_conv_a.bias", (256,)),
+          ("descriptor_conv_b.weight", (256, 256, 1, 1)), ("descriptor_conv_b.bias", (256,))]
+    return OrderedDict(e)
+
+
+def vgg_conv_macs(h, w):
+    """Algorithmic MACs per frame of SPModel::forward (26.0 G at 640x480)."""
+    m, hh, ww = 0, h, w
+    for i, (cin, cout) in enumerate(VGG_ENCODER_DIMS):
+        m += hh * ww * cout * 9 * (cin + cout)
+        if i != 3:
+            hh, ww = hh // 2, ww // 2
+    m += hh * ww * (256 * 128 * 9 + 65 * 256) + hh * ww * (256 * 128 * 9 + 256 * 256)
+    return m

@@ -53,6 +53,22 @@ def make_state_dict(seed=0, dustbin_bias=2.0, gain=1.0):
     return sd
 
 
+def make_vgg_state_dict(seed=0, dustbin_bias=3.0):
+    """Seeded parameters of the reference's C++ network (superpoint::SPModel, cpp/src/model.cc) as the flat
+    {name: float32 array} dict cpp/src/superpoint.cc:27-55 loads: He-uniform weights (every layer keeps the
+    activation scale), small biases, and the dustbin knob on detector_conv_b.bias[64]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for name, shape in arch.vgg_state_dict_spec().items():
+        if len(shape) == 4:
+            b = np.sqrt(6.0 / (shape[1] * shape[2] * shape[3]))
+            sd[name] = rng.uniform(-b, b, shape).astype(np.float32)
+        else:
+            sd[name] = rng.normal(0.0, 0.05, shape).astype(np.float32)
+    sd["detector_conv_b.bias"][64] += np.float32(dustbin_bias)
+    return sd
+
+
 def make_frame(seed, h=480, w=640, gray=False):
     """HxWx3 float32 image in [0,1]: 40 random filled rectangles / triangles on a
     flat background, 5x5 box-blurred.

@@ -550,3 +550,115 @@ void oracle_u8_to_float(const uint8_t* in, int n, int hw, int layout, float* out
       }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * The reference's OTHER network: superpoint::SPModelImpl (cpp/src/model.cc:4-94, dims
+ * cpp/src/settings.h:19-25) -- the VGG-style SuperPoint its cpp/ frontend runs: 1-channel input, four
+ * pairs of 3x3 convolutions (bias, ReLU) with 2x2 max-pools between them, two heads of 3x3 + 1x1
+ * convolutions, 256-D descriptors L2-normalised over channels (model.cc:61-93).  The probability map is
+ * SuperPoint::GetPoints' exp / (sum + 1e-5), dustbin dropped, depth-to-space (cpp/src/superpoint.cc:154-172)
+ * -- the same arithmetic as python/src/superpoint.py:111-114.
+ * PINNED against the reference itself: oracle/_ref/ref_vgg_forward is cpp/src/model.cc compiled unmodified
+ * (oracle/Makefile.ref); tests/golden/f7_vgg_*.npz hold its outputs (tests/golden/make_golden_vgg.py).
+ * weights: 12 convolutions x (weight, bias) in named_parameters() order: encoder_conv{0..3}_{a,b},
+ * detector_conv_{a,b}, descriptor_conv_{a,b}.
+ * ------------------------------------------------------------------------------------------- */
+static void bias_act(float* x, const float* bias, int relu, int B, int C, size_t hw) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      float* p = x + ((size_t)b * C + c) * hw;
+      const float bv = bias[c];
+      for (size_t i = 0; i < hw; ++i) {
+        const float v = p[i] + bv;
+        p[i] = (relu && v < 0.0f) ? 0.0f : v;
+      }
+    }
+}
+
+/* torch::max_pool2d(x, 2, 2) -- model.cc:74 */
+static void maxpool2(const float* in, float* out, int B, int C, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2;
+#pragma omp parallel for schedule(static)
+  for (int bc = 0; bc < B * C; ++bc)
+    for (int y = 0; y < Ho; ++y)
+      for (int x = 0; x < Wo; ++x) {
+        const float* p = in + ((size_t)bc * H + 2 * y) * W + 2 * x;
+        float m = p[0];
+        if (p[1] > m) m = p[1];
+        if (p[W] > m) m = p[W];
+        if (p[W + 1] > m) m = p[W + 1];
+        out[((size_t)bc * Ho + y) * Wo + x] = m;
+      }
+}
+
+static float* vgg_conv(const float* x, const float* w, const float* b, int B, int cin, int H, int W, int cout, int k,
+                       int relu) {
+  float* y = (float*)malloc((size_t)B * cout * H * W * sizeof(float));
+  oracle_conv2d(x, w, y, B, cin, H, W, cout, k, 1, k / 2);
+  bias_act(y, b, relu, B, cout, (size_t)H * W);
+  return y;
+}
+
+int oracle_vgg_forward(const float* image, const float* const* weights, int B, int H, int W, float* prob_map,
+                       float* desc, float* logits) {
+  if (H % 8 || W % 8) return -1;
+  static const int dims[4][2] = {{1, 64}, {64, 64}, {64, 128}, {128, 128}}; /* settings.h:19-22 */
+  int h = H, w = W, wi = 0;
+  float* x = (float*)malloc((size_t)B * H * W * sizeof(float));
+  memcpy(x, image, (size_t)B * H * W * sizeof(float));
+  for (int i = 0; i < 4; ++i) { /* model.cc:66-76 */
+    float* a = vgg_conv(x, weights[wi], weights[wi + 1], B, dims[i][0], h, w, dims[i][1], 3, 1);
+    free(x);
+    float* b2 = vgg_conv(a, weights[wi + 2], weights[wi + 3], B, dims[i][1], h, w, dims[i][1], 3, 1);
+    free(a);
+    wi += 4;
+    if (i != 3) {
+      float* p = (float*)malloc((size_t)B * dims[i][1] * (h / 2) * (w / 2) * sizeof(float));
+      maxpool2(b2, p, B, dims[i][1], h, w);
+      free(b2);
+      h /= 2;
+      w /= 2;
+      x = p;
+    } else {
+      x = b2;
+    }
+  }
+  const int Hc = h, Wc = w;
+  const size_t hw = (size_t)Hc * Wc;
+  float* pa = vgg_conv(x, weights[16], weights[17], B, 128, Hc, Wc, 256, 3, 1); /* model.cc:79-82 */
+  float* lg = vgg_conv(pa, weights[18], weights[19], B, 256, Hc, Wc, 65, 1, 0);
+  free(pa);
+  memcpy(logits, lg, (size_t)B * 65 * hw * sizeof(float));
+  float* da = vgg_conv(x, weights[20], weights[21], B, 128, Hc, Wc, 256, 3, 1); /* model.cc:85-88 */
+  free(x);
+  float* dd = vgg_conv(da, weights[22], weights[23], B, 256, Hc, Wc, 256, 1, 0);
+  free(da);
+  for (int b = 0; b < B; ++b) /* model.cc:90-91: desc / norm(desc, 2, dim=1), no epsilon */
+    for (size_t i = 0; i < hw; ++i) {
+      double s = 0.0;
+      for (int c = 0; c < 256; ++c) {
+        const double v = dd[((size_t)b * 256 + c) * hw + i];
+        s += v * v;
+      }
+      const float nrm = (float)sqrt(s);
+      for (int c = 0; c < 256; ++c) desc[((size_t)b * 256 + c) * hw + i] = dd[((size_t)b * 256 + c) * hw + i] / nrm;
+    }
+  free(dd);
+  float* sm = (float*)malloc((size_t)B * 65 * hw * sizeof(float)); /* superpoint.cc:157-172 */
+  for (int b = 0; b < B; ++b)
+    for (size_t i = 0; i < hw; ++i) {
+      float sum = 0.0f;
+      for (int c = 0; c < 65; ++c) {
+        const float e = expf(lg[((size_t)b * 65 + c) * hw + i]);
+        sm[((size_t)b * 65 + c) * hw + i] = e;
+        sum += e;
+      }
+      const float den = sum + .00001f;
+      for (int c = 0; c < 65; ++c) sm[((size_t)b * 65 + c) * hw + i] /= den;
+    }
+  oracle_restore_prob_map(sm, prob_map, B, Hc, Wc, 8);
+  free(sm);
+  free(lg);
+  return 0;
+}

@@ -158,3 +158,20 @@ def u8_to_float(frames_u8, layout):
     out = np.empty((n, cout, h, w), np.float32)
     lib().oracle_u8_to_float(a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n, h * w, int(layout), _p(out))
     return out
+
+
+def vgg_forward(image, state_dict, spec):
+    """The reference's C++ network (cpp/src/model.cc:61-93) restated: image float32 [B,1,H,W] ->
+    (prob_map [B,H,W], desc [B,256,H/8,W/8] unit-norm over channels, logits [B,65,H/8,W/8])."""
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    b, c, h, w = image.shape
+    assert c == 1
+    prob = np.empty((b, h, w), np.float32)
+    desc = np.empty((b, 256, h // 8, w // 8), np.float32)
+    logits = np.empty((b, 65, h // 8, w // 8), np.float32)
+    wp, keep = weight_ptrs(state_dict, spec)
+    rc = lib().oracle_vgg_forward(_p(image), wp, b, h, w, _p(prob), _p(desc), _p(logits))
+    if rc != 0:
+        raise ValueError("oracle_vgg_forward: H and W must be multiples of 8")
+    del keep
+    return prob, desc, logits

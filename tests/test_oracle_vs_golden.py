@@ -136,3 +136,49 @@ def test_f6_u8_to_float(golden_dir):
     assert gray.shape == (2, 1, 16, 24) and gray.min() >= 0.0 and gray.max() <= 1.0
     b, gch, r = (g["img"][..., i].astype(np.float64) for i in range(3))
     assert np.max(np.abs(gray[:, 0] * 255.0 - (0.114 * b + 0.587 * gch + 0.299 * r))) <= 0.51
+
+
+def _gray(seed, h, w):
+    return synth.make_batch(seed, 1, h, w, gray=True)[:, :1].copy()
+
+
+def test_f7_vgg_network_against_the_reference_binary_outputs(golden_dir):
+    """The reference's C++ network (superpoint::SPModel, cpp/src/model.cc) -- fixtures written by the
+    reference's own source compiled unmodified (oracle/_ref/ref_vgg_forward, tests/golden/make_golden_vgg.py)."""
+    spec = arch.vgg_state_dict_spec()
+    names = [ln.split()[0] for ln in open(os.path.join(golden_dir, "f7_vgg_names.txt")).read().strip().splitlines()]
+    assert names == list(spec.keys())
+    g = np.load(os.path.join(golden_dir, "f7_vgg_32x48.npz"))
+    sd = synth.make_vgg_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    prob, desc, logits = oracle.vgg_forward(_gray(int(g["seed_frame"]), 32, 48), sd, spec)
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(desc, g["desc"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(desc, axis=1), 1.0, rtol=1e-5)
+    assert prob.shape == (1, 32, 48) and 0.0 <= prob.min() and prob.max() <= 1.0
+    g = np.load(os.path.join(golden_dir, "f7_vgg_qvga.npz"))
+    sd = synth.make_vgg_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    prob, desc, logits = oracle.vgg_forward(_gray(int(g["seed_frame"]), int(g["h"]), int(g["w"])), sd, spec)
+    np.testing.assert_allclose(logits.ravel()[::7], g["logits_probe"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(desc.ravel()[::11], g["desc_probe"], rtol=0, atol=5e-6)
+    assert abs(float(logits.astype(np.float64).sum()) - float(g["logits_sum"])) < 0.05
+
+
+def test_vgg_oracle_against_live_reference_binary(golden_dir):
+    """Where oracle/_ref/ref_vgg_forward exists (built from /root/reference by oracle/Makefile.ref), run the
+    reference itself on a fresh seed and compare."""
+    import importlib.util
+    binpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_vgg_forward")
+    if not os.path.exists(binpath):
+        pytest.skip("oracle/_ref/ref_vgg_forward not built")
+    specm = importlib.util.spec_from_file_location("make_golden_vgg", os.path.join(golden_dir, "make_golden_vgg.py"))
+    mg = importlib.util.module_from_spec(specm)
+    specm.loader.exec_module(mg)
+    sd = synth.make_vgg_state_dict(77, 2.5)
+    fr = _gray(505, 48, 64)
+    try:
+        point, dref, _ = mg.run_reference(sd, fr)
+    except Exception as exc:  # e.g. libtorch missing on the machine running the tests
+        pytest.skip("reference binary did not run: %r" % (exc,))
+    prob, desc, logits = oracle.vgg_forward(fr, sd, arch.vgg_state_dict_spec())
+    np.testing.assert_allclose(logits, point, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(desc, dref, rtol=0, atol=2e-6)
