@@ -34,8 +34,8 @@ class FpcConfig(ctypes.Structure):
                 ("max_batch", ctypes.c_int), ("cell", ctypes.c_int), ("nms_dist", ctypes.c_int),
                 ("conf_thresh", ctypes.c_float), ("border_remove", ctypes.c_int),
                 ("descriptor_enabled", ctypes.c_int), ("max_keypoints", ctypes.c_int),
-                ("in_channels", ctypes.c_int), ("dtype", ctypes.c_int),
-                ("reserved", ctypes.c_int * 5)]
+                ("in_channels", ctypes.c_int), ("dtype", ctypes.c_int), ("arch", ctypes.c_int),
+                ("reserved", ctypes.c_int * 4)]
 
 
 class FpcTensor(ctypes.Structure):

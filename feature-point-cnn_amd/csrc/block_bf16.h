@@ -44,6 +44,7 @@ struct BlockBfArgs {
   int Ho, Wo, tiles_x, tiles_y, frame0;
   int OH, OW, oys, oxs, oy0, ox0;   // output pixel = (y*oys + oy0, x*oxs + ox0) in an OH x OW buffer
   int pad;               // halo origin = tile origin * S - pad
+  int norelu;            // conv_only: 1 = no ReLU (the last 1x1 of a head of the C++ network)
 };
 
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
@@ -316,8 +317,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
             v1.x += bf2f(q.z & 0xffff); v1.y += bf2f(q.z >> 16); v1.z += bf2f(q.w & 0xffff); v1.w += bf2f(q.w >> 16);
           }
         }
-        v0.x = v0.x > 0.f ? v0.x : 0.f; v0.y = v0.y > 0.f ? v0.y : 0.f; v0.z = v0.z > 0.f ? v0.z : 0.f; v0.w = v0.w > 0.f ? v0.w : 0.f;
-        v1.x = v1.x > 0.f ? v1.x : 0.f; v1.y = v1.y > 0.f ? v1.y : 0.f; v1.z = v1.z > 0.f ? v1.z : 0.f; v1.w = v1.w > 0.f ? v1.w : 0.f;
+        if (!a.norelu) {
+          v0.x = v0.x > 0.f ? v0.x : 0.f; v0.y = v0.y > 0.f ? v0.y : 0.f; v0.z = v0.z > 0.f ? v0.z : 0.f; v0.w = v0.w > 0.f ? v0.w : 0.f;
+          v1.x = v1.x > 0.f ? v1.x : 0.f; v1.y = v1.y > 0.f ? v1.y : 0.f; v1.z = v1.z > 0.f ? v1.z : 0.f; v1.w = v1.w > 0.f ? v1.w : 0.f;
+        }
         const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
         if (a.out_f32) {
           float4* o = reinterpret_cast<float4*>(static_cast<float*>(a.out) + opix * a.cso + c8 * 8);

@@ -336,7 +336,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
           const float4 q = *reinterpret_cast<const float4*>(xin + ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
-        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        if (!a.norelu) {
+          v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        }
         const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
         *reinterpret_cast<float4*>(outp + opix * a.cso + c4 * 4) = v;
       }

@@ -187,7 +187,9 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
   X(S620_s1_K16_C80, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 3, 16, 4, 1, 1, 3, 80)       \
   X(S320_s2_K16_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 2, 3, 16, 1, 4, 2, 2, 256)     \
   X(S320_s1_K64_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)     \
-  X(S620_ct_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)
+  X(S620_ct_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)     \
+  X(S620_1x1_K64_C80, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 1, 64, 4, 1, 1, 3, 80)      \
+  X(S320_1x1_K64_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 1, 1, 64, 1, 4, 2, 2, 256)
 
 enum FKind {
 #define X(name, ...) FK_##name,
@@ -225,7 +227,8 @@ static const FKindInfo g_fkinds[FK_COUNT] = {
 // ------------------------------------------------------------------------------------
 // Launch plan
 // ------------------------------------------------------------------------------------
-enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_WBLOCK, OP_BF16, OP_SOFTMAX, OP_NMS, OP_DESC };
+enum OpType { OP_STEM, OP_POOL, OP_CONV, OP_BLOCK, OP_WBLOCK, OP_BF16, OP_SOFTMAX, OP_NMS, OP_DESC,
+              OP_VCONV0, OP_POOL2, OP_L2NORM };
 
 struct Op {
   OpType type;
@@ -239,6 +242,11 @@ struct Op {
   FKind fkind = FK_COUNT;
   BlockBfArgs fargs{};
   int phase = -1;              // ConvTranspose output-parity phase of a bf16 conv-only op
+  bool plain_conv = false;     // a Conv2d + bias (+ ReLU) of the C++ network: weights `prefix`.weight / .bias, no BN
+  int ksize = 0;
+  const float* pin = nullptr;  // OP_POOL2 / OP_L2NORM / OP_VCONV0 operands
+  float* pout = nullptr;
+  int pH = 0, pW = 0, pC = 0;
   std::string prefix;          // checkpoint prefix of a fused block
   int cin = 0, cout = 0;       // real channel counts of a fused block
   int grid_y = 1, grid_z = 1;
@@ -260,6 +268,10 @@ using namespace fpc;
 struct fpc_ctx {
   fpc_config cfg{};
   int H = 0, W = 0, B = 0, Hc = 0, Wc = 0;
+  bool vgg = false;                  // cfg.arch == FPC_ARCH_VGG: superpoint::SPModel (cpp/src/model.cc)
+  int D = 128;                       // descriptor length: 128 (python net) / 256 (C++ net, settings.h:25)
+  std::vector<float*> vbuf;          // VGG activation buffers
+  size_t vconv0_off = 0;
   bool bf16 = false;                 // cfg.dtype == FPC_BF16
   bool split = false;                // cfg.dtype == FPC_F32_SPLIT
   int lgcs = 72;                     // channel stride of the logits buffer (80 in bf16 mode)
@@ -706,7 +718,213 @@ static void build_x3_ops(fpc_ctx* c, size_t* bo) {
   }
 }
 
+// ---- the reference's C++ network (superpoint::SPModel, cpp/src/model.cc) -----------------------------
+// A plain Conv2d + bias (+ ReLU) on the split-operand kernel (conv_only) -- dtype FPC_F32_SPLIT
+static void add_fconv(fpc_ctx* c, FKind kind, const std::string& prefix, const float* x, int csx, int cin, int cin_pad,
+                      int H, int W, float* out, int cso, int cout, int ksize, bool relu, bool desc_branch,
+                      size_t* blob_off) {
+  const FKindInfo& k = g_fkinds[kind];
+  const int nbt = k.WN * k.NB, K16 = k.KC / 16;
+  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
+  Op op;
+  op.type = OP_BF16;
+  op.name = prefix + (relu ? " [3xbf16 conv+bias+relu]" : " [3xbf16 conv+bias]");
+  op.prefix = prefix;
+  op.fkind = kind;
+  op.plain_conv = true;
+  op.ksize = ksize;
+  op.cin = cin;
+  op.cout = cout;
+  op.descriptor_branch = desc_branch;
+  BlockBfArgs& a = op.fargs;
+  a.x = x;
+  a.csx = csx;
+  a.in_f32 = 1;
+  a.nchunk = cin_pad / k.KC;
+  a.H = H;
+  a.W = W;
+  a.pad = ksize / 2;
+  a.ntaps = ksize * ksize;
+  for (int ky = 0; ky < ksize; ++ky)
+    for (int kx = 0; kx < ksize; ++kx) a.tapoff16[ky * ksize + kx] = (ky * HWp + kx) * ROW16;
+  a.conv_only = 1;
+  a.norelu = relu ? 0 : 1;
+  a.out = out;
+  a.cso = cso;
+  a.out_f32 = 1;
+  a.Ho = a.OH = H;
+  a.Wo = a.OW = W;
+  a.oys = a.oxs = 1;
+  a.tiles_x = (W + k.TW - 1) / k.TW;
+  a.tiles_y = (H + k.TH - 1) / k.TH;
+  fpc_ctx::ConvW cw;
+  cw.w_off[0] = *blob_off;
+  *blob_off += ((size_t)a.nchunk * a.ntaps * K16 + 2) * k.planes * nbt * 64 * 4;
+  cw.b_off = *blob_off;
+  *blob_off += (size_t)nbt * 32;
+  op.flops_per_frame = 2.0 * a.ntaps * H * W * (double)cin * cout;
+  op.mfma_flops_per_frame = 6.0 * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+  c->ops.push_back(op);
+  c->convw.push_back(cw);
+}
+
+static int build_vgg_plan(fpc_ctx* c) {
+  const int H = c->H, W = c->W, B = c->B, Hc = H / 8, Wc = W / 8;
+  const size_t npix8 = (size_t)B * Hc * Wc;
+  Carver cv;
+  // activations: one buffer per tensor (sub-batches of one call run different layers at the same time)
+  const int ah[4] = {H, H / 2, H / 4, Hc}, aw[4] = {W, W / 2, W / 4, Wc}, ac[4] = {64, 64, 128, 128};
+  size_t o_a[4], o_b[4], o_p[3];
+  for (int i = 0; i < 4; ++i) {
+    o_a[i] = cv.take<float>((size_t)B * ah[i] * aw[i] * ac[i]);
+    o_b[i] = cv.take<float>((size_t)B * ah[i] * aw[i] * ac[i]);
+    if (i < 3) o_p[i] = cv.take<float>((size_t)B * ah[i + 1] * aw[i + 1] * ac[i]);
+  }
+  const size_t o_pa = cv.take<float>(npix8 * 256), o_da = cv.take<float>(npix8 * 256);
+  const size_t o_lg = cv.take<float>(npix8 * 80), o_desc = cv.take<float>(npix8 * 256), o_descin = cv.take<float>(npix8 * 256);
+  const size_t o_prob = cv.take<float>((size_t)B * H * W);
+  const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
+  const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4);
+  const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
+  const size_t o_dout = cv.take<float>((size_t)B * c->cap * 256);
+  const size_t o_sort = cv.take<unsigned long long>(c->sort_cap > NMS_LDS_KEYS ? (size_t)B * c->sort_cap : 64);
+  const size_t o_rowbest = cv.take<unsigned long long>(c->cap), o_colbest = cv.take<unsigned long long>(c->cap);
+  c->slab_bytes = cv.off;
+  if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
+    g_hip_err = "hipMalloc(workspace " + std::to_string(c->slab_bytes >> 20) + " MiB) failed";
+    return FPC_E_HIP;
+  }
+  HIPCHECK(hipMemset(c->slab, 0, c->slab_bytes));
+  auto F = [&](size_t o) { return reinterpret_cast<float*>(c->slab + o); };
+  c->lg = F(o_lg); c->desc_map = F(o_desc); c->desc_in_nhwc = F(o_descin); c->prob = F(o_prob);
+  c->nmsmap = reinterpret_cast<uint32_t*>(c->slab + o_map);
+  c->cand = reinterpret_cast<uint32_t*>(c->slab + o_cand);
+  c->ncand = reinterpret_cast<int32_t*>(c->slab + o_ncand);
+  c->count = reinterpret_cast<int32_t*>(c->slab + o_count);
+  c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
+  c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
+  c->conf = F(o_conf);
+  c->desc_out = F(o_dout);
+  c->sort_scratch = reinterpret_cast<unsigned long long*>(c->slab + o_sort);
+  c->rowbest = reinterpret_cast<unsigned long long*>(c->slab + o_rowbest);
+  c->colbest = reinterpret_cast<unsigned long long*>(c->slab + o_colbest);
+
+  size_t bo = 0;
+  c->ops.clear();
+  c->convw.clear();
+  auto conv = [&](const std::string& prefix, const float* x, int cin, int Hx, int Wx, float* out, int cso, int cout,
+                  int ksize, bool relu, bool desc) {
+    if (c->split) {
+      FKind fk;
+      if (ksize == 3) fk = cout == 64 ? FK_S816_s1_K64_C64 : cout == 128 ? FK_S620_s1_K64_C128 : FK_S320_s1_K64_C256;
+      else fk = cout == 65 ? FK_S620_1x1_K64_C80 : FK_S320_1x1_K64_C256;
+      add_fconv(c, fk, prefix, x, cin, cin, cin, Hx, Wx, out, cso, cout, ksize, relu, desc, &bo);
+      return;
+    }
+    ConvSpec s{};
+    s.name = prefix + (relu ? " [conv+bias+relu]" : " [conv+bias]");
+    if (ksize == 3) s.kind = cout == 64 ? K_T816_3x3_K64_N64 : K_T620_3x3_K64_N128;
+    else s.kind = cout == 65 ? K_T620_1x1_K64_N96 : K_T620_1x1_K64_N128;
+    s.ksize = ksize; s.stride = 1;
+    s.in0 = x; s.cs0 = cin; s.cin0 = cin; s.cin0_pad = cin; s.H0 = Hx; s.W0 = Wx;
+    s.out = out; s.cso = cso; s.cout = cout; s.nstore = cout == 65 ? cso : cout; s.Ho = Hx; s.Wo = Wx; s.relu = relu ? 1 : 0;
+    s.desc_branch = desc;
+    add_conv(c, s, &bo);
+    c->ops.back().prefix = prefix;
+    c->ops.back().plain_conv = true;
+    c->ops.back().ksize = ksize;
+    c->ops.back().cin = cin;
+    c->ops.back().cout = cout;
+  };
+  const float* x = nullptr;
+  for (int i = 0; i < 4; ++i) {
+    const std::string pa = "encoder_conv" + std::to_string(i) + "_a", pb = "encoder_conv" + std::to_string(i) + "_b";
+    float* a = F(o_a[i]);
+    float* b = F(o_b[i]);
+    if (i == 0) {  // Conv2d(1, 64): K = 9, plain FMAs
+      Op op;
+      op.type = OP_VCONV0;
+      op.name = pa + " [conv+bias+relu, 1 input channel]";
+      op.prefix = pa;
+      op.pout = a;
+      op.pH = H; op.pW = W;
+      op.flops_per_frame = 2.0 * H * W * 64 * 9;
+      c->ops.push_back(op);
+      c->convw.push_back({});
+      c->vconv0_off = bo;
+      bo += 640;
+    } else {
+      conv(pa, x, ac[i - 1], ah[i], aw[i], a, ac[i], ac[i], 3, true, false);
+    }
+    conv(pb, a, ac[i], ah[i], aw[i], b, ac[i], ac[i], 3, true, false);
+    if (i < 3) {
+      Op op;
+      op.type = OP_POOL2;
+      op.name = "max_pool2d(2,2) after " + pb;
+      op.pin = b;
+      op.pout = F(o_p[i]);
+      op.pH = ah[i]; op.pW = aw[i]; op.pC = ac[i];
+      c->ops.push_back(op);
+      c->convw.push_back({});
+      x = op.pout;
+    } else {
+      x = b;
+    }
+  }
+  const int lgcs = c->lgcs;
+  conv("detector_conv_a", x, 128, Hc, Wc, F(o_pa), 256, 256, 3, true, false);
+  conv("detector_conv_b", F(o_pa), 256, Hc, Wc, c->lg, lgcs, 65, 1, false, false);
+  {
+    Op op;
+    op.type = OP_SOFTMAX;
+    op.name = "exp-softmax+depth_to_space+threshold";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+  }
+  const bool de = c->cfg.descriptor_enabled != 0;
+  if (de) {
+    conv("descriptor_conv_a", x, 128, Hc, Wc, F(o_da), 256, 256, 3, true, true);
+    conv("descriptor_conv_b", F(o_da), 256, Hc, Wc, c->desc_map, 256, 256, 1, false, true);
+    Op op;
+    op.type = OP_L2NORM;
+    op.name = "descriptor L2 normalisation over channels";
+    op.descriptor_branch = true;
+    op.pout = c->desc_map;
+    c->ops.push_back(op);
+    c->convw.push_back({});
+  }
+  {
+    Op op;
+    op.type = OP_NMS;
+    op.name = "nms+sort+border_crop";
+    c->ops.push_back(op);
+    c->convw.push_back({});
+    if (de) {
+      op.type = OP_DESC;
+      op.name = "descriptor_sample+l2norm";
+      c->ops.push_back(op);
+      c->convw.push_back({});
+    }
+  }
+  c->blob_floats = bo;
+  HIPCHECK(hipMalloc((void**)&c->blob, c->blob_floats * sizeof(float)));
+  HIPCHECK(hipMemset(c->blob, 0, c->blob_floats * sizeof(float)));
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    Op& op = c->ops[i];
+    if (op.type == OP_BF16) {
+      op.fargs.w1 = reinterpret_cast<const uint4*>(c->blob + c->convw[i].w_off[0]);
+      op.fargs.b1 = c->blob + c->convw[i].b_off;
+    }
+    if (op.type == OP_CONV) {
+      op.args.sub[0].wfrag = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
+      op.args.bias = c->blob + c->convw[i].b_off;
+    }
+  }
+  return FPC_OK;
+}
+
 static int build_plan(fpc_ctx* c) {
+  if (c->vgg) return build_vgg_plan(c);
   const int H = c->H, W = c->W, B = c->B;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
   const bool de = c->cfg.descriptor_enabled != 0;
@@ -951,6 +1169,39 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
     }
     return m.at(k).data;
   };
+  if (c->vgg) {  // superpoint::SPModel: Conv2d weights + biases, no BatchNorm (cpp/src/model.cc:4-58)
+    static const std::vector<double> ones(256, 1.0);
+    for (size_t i = 0; i < c->ops.size(); ++i) {
+      const Op& op = c->ops[i];
+      if (op.type == OP_VCONV0) {
+        const float* w = need(op.prefix + ".weight", {64, 1, 3, 3});
+        const float* bv = need(op.prefix + ".bias", {64});
+        if (!w || !bv) return FPC_E_MISSING_KEY;
+        float* dst = blob.data() + c->vconv0_off;
+        for (int t = 0; t < 9; ++t)
+          for (int n = 0; n < 64; ++n) dst[t * 64 + n] = w[n * 9 + t];
+        for (int n = 0; n < 64; ++n) dst[576 + n] = bv[n];
+        continue;
+      }
+      if (!op.plain_conv) continue;
+      const int ci = op.cin, co = op.cout, kk = op.ksize * op.ksize;
+      const float* w = need(op.prefix + ".weight", {co, ci, op.ksize, op.ksize});
+      const float* bv = need(op.prefix + ".bias", {co});
+      if (!w || !bv) return FPC_E_MISSING_KEY;
+      const fpc_ctx::ConvW& cw = c->convw[i];
+      PackSource src{ci, ci, kk, [&](int n, int cc, int t) { return (double)w[((size_t)n * ci + cc) * kk + t]; }, &ones};
+      std::vector<float> frag;
+      if (op.type == OP_BF16) {
+        const FKindInfo& k = g_fkinds[op.fkind];
+        frag = pack_conv_bf16({src}, co, k.WN * k.NB, k.KC, k.planes);
+      } else {
+        frag = pack_conv({src}, co, op.args.nbt, g_kinds[op.kind].KC);
+      }
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = bv[n];
+    }
+    return FPC_OK;
+  }
   // stem
   {
     const float* w = need("encoder.conv1.weight", {64, 3, 7, 7});
@@ -1274,7 +1525,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
   const int H = c->H, W = c->W, n = sb.n, f0 = sb.f0;
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
-    const int br = op.descriptor_branch ? 2 : (op.name.compare(0, 9, "detector.") == 0 ? 1 : 0);
+    const int br = op.descriptor_branch ? 2 : (op.name.compare(0, 8, "detector") == 0 ? 1 : 0);
     if (br != which) continue;
     switch (op.type) {
       case OP_STEM: {
@@ -1365,6 +1616,31 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
         break;
       }
+      case OP_VCONV0: {
+        LaunchTimer t(c, (int)i, sb.st, n);
+        VggConv0Args a{};
+        a.in = frames;
+        a.w = c->blob + c->vconv0_off;
+        a.out = op.pout;
+        a.H = H; a.W = W; a.frame0 = f0;
+        hipLaunchKernelGGL(vgg_conv0_kernel, dim3((unsigned)((size_t)n * H * W / 64)), dim3(256), 0, sb.st, a);
+        break;
+      }
+      case OP_POOL2: {
+        LaunchTimer t(c, (int)i, sb.st, n);
+        const size_t tot = (size_t)n * (op.pH / 2) * (op.pW / 2) * (op.pC / 4);
+        hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, sb.st,
+                           reinterpret_cast<const float4*>(op.pin), reinterpret_cast<float4*>(op.pout), n, op.pH, op.pW,
+                           op.pC / 4, f0);
+        break;
+      }
+      case OP_L2NORM: {
+        LaunchTimer t(c, (int)i, sb.st, n);
+        const size_t npix = (size_t)n * c->Hc * c->Wc;
+        hipLaunchKernelGGL(l2norm256_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, sb.st,
+                           op.pout + (size_t)f0 * c->Hc * c->Wc * 256, npix);
+        break;
+      }
       case OP_CONV: {
         LaunchTimer t(c, (int)i, sb.st, n);
         ConvArgs a = op.args;
@@ -1420,9 +1696,14 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
 
 static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
   LaunchTimer t(c, op_index(c, OP_DESC), sb.st, sb.n);
-  hipLaunchKernelGGL(descriptor_kernel, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
-                     dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
-                     c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128);
+  if (c->D == 256)
+    hipLaunchKernelGGL(descriptor_kernel<4>, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
+                       dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 256, 256, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
+                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 256);
+  else
+    hipLaunchKernelGGL(descriptor_kernel<2>, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
+                       dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
+                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128);
 }
 
 // Splits [0,n) over the ctx's streams; aux streams fork from / join into the main stream.
@@ -1525,9 +1806,12 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   *out = nullptr;
   // the descriptor head halves the 1/8 map and doubles it again (superpoint.py:43-59): odd
   // H/8 or W/8 breaks its concat, so frames must be multiples of 16 unless it is disabled
-  const int mult = cfg->descriptor_enabled ? 16 : 8;
+  const int mult = (cfg->descriptor_enabled && cfg->arch != FPC_ARCH_VGG) ? 16 : 8;
   if (cfg->in_channels != 0 && cfg->in_channels != 1 && cfg->in_channels != 3) return FPC_E_INVALID;
   if (cfg->dtype != FPC_F32 && cfg->dtype != FPC_BF16 && cfg->dtype != FPC_F32_SPLIT) return FPC_E_INVALID;
+  if (cfg->arch != FPC_ARCH_RESNET && cfg->arch != FPC_ARCH_VGG) return FPC_E_INVALID;
+  // the C++ network takes one gray plane (cpp/src/settings.h:19) and has no bf16 plan
+  if (cfg->arch == FPC_ARCH_VGG && (cfg->in_channels != 1 || cfg->dtype == FPC_BF16)) return FPC_E_INVALID;
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30))
@@ -1551,6 +1835,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->Hc = c->H / 8;
   c->Wc = c->W / 8;
   c->cin = cfg->in_channels == 1 ? 1 : 3;
+  c->vgg = cfg->arch == FPC_ARCH_VGG;
+  c->D = c->vgg ? 256 : 128;
   c->bf16 = cfg->dtype == FPC_BF16;
   c->split = cfg->dtype == FPC_F32_SPLIT;
   c->lgcs = (c->bf16 || c->split) ? 80 : 72;
@@ -1738,10 +2024,10 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
                        HWc, n, logits);
   }
   if (desc) {
-    const size_t tot = (size_t)n * 128 * HWc;
+    const size_t tot = (size_t)n * c->D * HWc;
     if (de)
       hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                         c->desc_map, 128, 128, HWc, n, desc);
+                         c->desc_map, c->D, c->D, HWc, n, desc);
     else  // superpoint.py:106-109: zeros when the descriptor head is disabled
       HIPCHECK(hipMemsetAsync(desc, 0, tot * sizeof(float), c->stream));
   }
@@ -1788,9 +2074,9 @@ int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n)
   all.st = c->stream;
   run_nms(c, all);
   if (desc_nchw && c->cfg.descriptor_enabled) {
-    const size_t tot = (size_t)n * 128 * c->Hc * c->Wc;
+    const size_t tot = (size_t)n * c->D * c->Hc * c->Wc;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, desc_nchw,
-                       128, c->Hc * c->Wc, n, c->desc_in_nhwc);
+                       c->D, c->Hc * c->Wc, n, c->desc_in_nhwc);
     run_desc(c, all, c->desc_in_nhwc);
   }
   HIPCHECK(hipGetLastError());
@@ -1810,7 +2096,7 @@ int fpc_match(fpc_ctx* c, const float* q, int nq, const float* t, int nt, int cr
   HIPCHECK(hipMemsetAsync(c->rowbest, 0xff, sizeof(unsigned long long) * nq, c->stream));
   HIPCHECK(hipMemsetAsync(c->colbest, 0xff, sizeof(unsigned long long) * nt, c->stream));
   MatchArgs a{};
-  a.q = q; a.t = t; a.nq = nq; a.nt = nt; a.rowbest = c->rowbest; a.colbest = c->colbest; a.first = nullptr; a.tol2 = -1.f;
+  a.q = q; a.t = t; a.nq = nq; a.nt = nt; a.D = c->D; a.rowbest = c->rowbest; a.colbest = c->colbest; a.first = nullptr; a.tol2 = -1.f;
   hipLaunchKernelGGL(match_gemm_kernel, dim3((nq + 127) / 128, (nt + 127) / 128), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(match_finalize_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->rowbest, c->colbest, nq,
                      cross_check, max_dist, match, dist);
@@ -1831,7 +2117,7 @@ int fpc_first_within(fpc_ctx* c, const float* key, int nk, const float* cur, int
   unsigned int* ws = reinterpret_cast<unsigned int*>(c->rowbest);
   HIPCHECK(hipMemsetAsync(ws, 0xff, sizeof(unsigned int) * nk, c->stream));
   MatchArgs a{};
-  a.q = key; a.t = cur; a.nq = nk; a.nt = nc; a.rowbest = nullptr; a.colbest = nullptr; a.first = ws; a.tol2 = tolerance * tolerance;
+  a.q = key; a.t = cur; a.nq = nk; a.nt = nc; a.D = c->D; a.rowbest = nullptr; a.colbest = nullptr; a.first = ws; a.tol2 = tolerance * tolerance;
   hipLaunchKernelGGL(match_gemm_kernel, dim3((nk + 127) / 128, (nc + 127) / 128), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(first_finalize_kernel, dim3((nk + 255) / 256), dim3(256), 0, c->stream, ws, nk, first);
   HIPCHECK(hipGetLastError());
@@ -1846,7 +2132,7 @@ int fpc_results(fpc_ctx* c, fpc_device_results* out) {
   out->conf = c->conf;
   out->desc = c->cfg.descriptor_enabled ? c->desc_out : nullptr;
   out->capacity = c->cap;
-  out->desc_dim = 128;
+  out->desc_dim = c->D;
   return FPC_OK;
 }
 
@@ -1874,7 +2160,7 @@ int fpc_get_keypoints(fpc_ctx* c, int frame, int cap, int32_t* xy, float* conf, 
   if (conf) HIPCHECK(hipMemcpy(conf, c->conf + (size_t)frame * c->cap, sizeof(float) * k, hipMemcpyDeviceToHost));
   if (desc) {
     if (!c->cfg.descriptor_enabled) return FPC_E_INVALID;
-    HIPCHECK(hipMemcpy(desc, c->desc_out + (size_t)frame * c->cap * 128, sizeof(float) * 128 * k, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(desc, c->desc_out + (size_t)frame * c->cap * c->D, sizeof(float) * c->D * k, hipMemcpyDeviceToHost));
   }
   return k;
 }
@@ -1909,6 +2195,9 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
           case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
           case OP_NMS: k = "nms_rounds_kernel+nms_sort_kernel"; break;
           case OP_DESC: k = "descriptor_kernel"; break;
+          case OP_VCONV0: k = "vgg_conv0_kernel"; break;
+          case OP_POOL2: k = "maxpool2_kernel"; break;
+          case OP_L2NORM: k = "l2norm256_kernel"; break;
         }
       kernels[i] = k;
     }

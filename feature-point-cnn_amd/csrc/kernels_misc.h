@@ -609,6 +609,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
 // division by the L2 norm (no epsilon).  One wave per keypoint, lane = 2 channels of
 // the NHWC descriptor map (D = 128): each corner is one 512-byte coalesced read.
 // ---------------------------------------------------------------------------------
+template <int VPL>  // values per lane: 2 (D = 128, python net) or 4 (D = 256, cpp/src/settings.h:25)
 __global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
                                                          const int32_t* count, const int32_t* xy, int cap,
                                                          float* out) {
@@ -626,34 +627,40 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int 
   const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
   const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
   const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc, vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
-  const float* base = dmap + (size_t)b * Hc * Wc * cs + 2 * lane;
-  float2 v = make_float2(0.f, 0.f);
-  if (vy0 && vx0) {
-    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y0 * Wc + x0) * cs);
-    v.x += t.x * wnw;
-    v.y += t.y * wnw;
-  }
-  if (vy0 && vx1) {
-    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y0 * Wc + x1) * cs);
-    v.x += t.x * wne;
-    v.y += t.y * wne;
-  }
-  if (vy1 && vx0) {
-    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y1 * Wc + x0) * cs);
-    v.x += t.x * wsw;
-    v.y += t.y * wsw;
-  }
-  if (vy1 && vx1) {
-    const float2 t = *reinterpret_cast<const float2*>(base + (size_t)(y1 * Wc + x1) * cs);
-    v.x += t.x * wse;
-    v.y += t.y * wse;
-  }
-  float ss = v.x * v.x + v.y * v.y;
+  const float* base = dmap + (size_t)b * Hc * Wc * cs + VPL * lane;
+  float v[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) v[i] = 0.f;
+  auto corner = [&](bool ok, int yy, int xx, float wgt) {
+    if (!ok) return;
+    const float* q = base + (size_t)(yy * Wc + xx) * cs;
+    if (VPL == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(q);
+      v[0] += t.x * wgt;
+      v[1] += t.y * wgt;
+    } else {
+      const float4 t = *reinterpret_cast<const float4*>(q);
+      v[0] += t.x * wgt;
+      v[1] += t.y * wgt;
+      v[VPL - 2] += t.z * wgt;
+      v[VPL - 1] += t.w * wgt;
+    }
+  };
+  corner(vy0 && vx0, y0, x0, wnw);
+  corner(vy0 && vx1, y0, x1, wne);
+  corner(vy1 && vx0, y1, x0, wsw);
+  corner(vy1 && vx1, y1, x1, wse);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) ss += v[i] * v[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float nrm = sqrtf(ss);
-  float2 o2 = make_float2(v.x / nrm, v.y / nrm);
-  *reinterpret_cast<float2*>(out + ((size_t)b * cap + k) * 128 + 2 * lane) = o2;
+  float* dst = out + ((size_t)b * cap + k) * (64 * VPL) + VPL * lane;
+  if (VPL == 2)
+    *reinterpret_cast<float2*>(dst) = make_float2(v[0] / nrm, v[1] / nrm);
+  else
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0] / nrm, v[1] / nrm, v[VPL - 2] / nrm, v[VPL - 1] / nrm);
 }
 
 // NHWC (pixel stride cs, first C channels) -> NCHW, for the reference-layout dense outputs.
@@ -718,6 +725,92 @@ __global__ __launch_bounds__(256) void u8_to_float_kernel(const unsigned char* _
     *reinterpret_cast<float4*>(out + (f * 3 + c) * HW + p) =
         make_float4((float)b[sc] / 255.0f, (float)b[3 + sc] / 255.0f, (float)b[6 + sc] / 255.0f, (float)b[9 + sc] / 255.0f);
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernels only the reference's C++ network needs (superpoint::SPModel, cpp/src/model.cc).
+// ---------------------------------------------------------------------------------
+// encoder_conv0_a: Conv2d(1, 64, 3, padding 1) + bias + ReLU on a gray frame (model.cc:66-68).  K = 9 is no
+// GEMM: plain fp32 FMAs, one thread = one pixel x 16 output channels; HBM-bound on its 256 B/pixel output.
+struct VggConv0Args {
+  const float* in;   // [B,1,H,W]
+  const float* w;    // [9][64] (tap-major), bias [64] behind it
+  float* out;        // [B,H,W,64]
+  int H, W, frame0;
+};
+__global__ __launch_bounds__(256) void vgg_conv0_kernel(const VggConv0Args a) {
+  __shared__ float wl[10 * 64];
+  for (int i = threadIdx.x; i < 640; i += 256) wl[i] = a.w[i];
+  __syncthreads();
+  const int cg = threadIdx.x & 3;                                   // 16-channel group
+  const size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);  // over n*H*W of this launch
+  const size_t HW = (size_t)a.H * a.W;
+  const int bl = pix / HW;
+  const int r = pix - bl * HW;
+  const int y = r / a.W, x = r - y * a.W;
+  const float* src = a.in + (size_t)(a.frame0 + bl) * HW;
+  float v[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = y + ky - 1, ix = x + kx - 1;
+      const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float t = src[ok ? (size_t)iy * a.W + ix : 0];
+      v[ky * 3 + kx] = ok ? t : 0.f;
+    }
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[t], wl[t * 64 + cg * 16 + j], acc[j]);
+  float* dst = a.out + ((size_t)(a.frame0 + bl) * HW + r) * 64 + cg * 16;
+#pragma unroll
+  for (int j = 0; j < 16; j += 4) {
+    float4 o;
+    o.x = fmaxf(acc[j] + wl[576 + cg * 16 + j], 0.f);
+    o.y = fmaxf(acc[j + 1] + wl[576 + cg * 16 + j + 1], 0.f);
+    o.z = fmaxf(acc[j + 2] + wl[576 + cg * 16 + j + 2], 0.f);
+    o.w = fmaxf(acc[j + 3] + wl[576 + cg * 16 + j + 3], 0.f);
+    *reinterpret_cast<float4*>(dst + j) = o;
+  }
+}
+
+// torch::max_pool2d(x, 2, 2) on NHWC (model.cc:74); C4 = channels / 4
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float4* in, float4* out, int n, int H, int W, int C4,
+                                                       int frame0) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int Ho = H / 2, Wo = W / 2;
+  if (i >= (size_t)n * Ho * Wo * C4) return;
+  const int c = i % C4;
+  size_t p = i / C4;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int b = frame0 + (int)(p / Ho);
+  const float4* s = in + (((size_t)b * H + 2 * y) * W + 2 * x) * C4 + c;
+  const float4 q0 = s[0], q1 = s[C4], q2 = s[(size_t)W * C4], q3 = s[(size_t)W * C4 + C4];
+  float4 m;
+  m.x = fmaxf(fmaxf(q0.x, q1.x), fmaxf(q2.x, q3.x));
+  m.y = fmaxf(fmaxf(q0.y, q1.y), fmaxf(q2.y, q3.y));
+  m.z = fmaxf(fmaxf(q0.z, q1.z), fmaxf(q2.z, q3.z));
+  m.w = fmaxf(fmaxf(q0.w, q1.w), fmaxf(q2.w, q3.w));
+  out[(((size_t)b * Ho + y) * Wo + x) * C4 + c] = m;
+}
+
+// desc / norm(desc, 2, dim = 1) (model.cc:90-91): one wave per pixel of the 256-channel NHWC map, in place
+__global__ __launch_bounds__(256) void l2norm256_kernel(float* d, size_t npix) {
+  const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  float4* p = reinterpret_cast<float4*>(d + pix * 256) + (threadIdx.x & 63);
+  float4 v = *p;
+  float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float nrm = sqrtf(ss);
+  *p = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
 }
 
 }  // namespace fpc

@@ -16,9 +16,10 @@
 namespace fpc {
 
 struct MatchArgs {
-  const float* q;   // [nq][128]
-  const float* t;   // [nt][128]
+  const float* q;   // [nq][D]
+  const float* t;   // [nt][D]
   int nq, nt;
+  int D;            // descriptor length, a multiple of 8: 128 (python net) / 256 (C++ net)
   unsigned long long* rowbest;  // [nq]  (d^2 bits << 32 | t index), pre-filled with ~0
   unsigned long long* colbest;  // [nt]  (d^2 bits << 32 | q index), pre-filled with ~0
   unsigned int* first;          // [nq]  lowest t index with d < tol (first-within mode), pre-filled with ~0
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(const MatchArgs a) {
   const float* trow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    qrow[i] = a.q + (size_t)min(q0 + i * 32 + l31, a.nq - 1) * 128 + half * 4;
-    trow[i] = a.t + (size_t)min(t0 + i * 32 + l31, a.nt - 1) * 128 + half * 4;
+    qrow[i] = a.q + (size_t)min(q0 + i * 32 + l31, a.nq - 1) * a.D + half * 4;
+    trow[i] = a.t + (size_t)min(t0 + i * 32 + l31, a.nt - 1) * a.D + half * 4;
   }
   f32x16 acc[2][2];
   float qn[2] = {0.f, 0.f}, tn[2] = {0.f, 0.f};  // partial squared norms of this lane's rows (its half of each k8)
@@ -51,14 +52,14 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(const MatchArgs a) {
     qa[i] = *reinterpret_cast<const float4*>(qrow[i]);
     ta[i] = *reinterpret_cast<const float4*>(trow[i]);
   }
-#pragma unroll 4
-  for (int k8 = 0; k8 < 16; ++k8) {
+  const int K8 = a.D / 8;
+  for (int k8 = 0; k8 < K8; ++k8) {
     float4 qc[2], tc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       qc[i] = qa[i];
       tc[i] = ta[i];
-      const int kn = k8 + 1 < 16 ? k8 + 1 : k8;
+      const int kn = k8 + 1 < K8 ? k8 + 1 : k8;
       qa[i] = *reinterpret_cast<const float4*>(qrow[i] + kn * 8);
       ta[i] = *reinterpret_cast<const float4*>(trow[i] + kn * 8);
       qn[i] += qc[i].x * qc[i].x + qc[i].y * qc[i].y + qc[i].z * qc[i].z + qc[i].w * qc[i].w;

@@ -43,7 +43,7 @@ def _as_tensor_table(state_dict):
 
 class Engine:
     def __init__(self, height, width, max_batch=1, device=0, nms_dist=4, conf_thresh=0.015,
-                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3, dtype="f32"):
+                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3, dtype="f32", arch="resnet"):
         self._l = _lib.load()          # raises if libfpc.so is not built: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("fpc_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -58,6 +58,10 @@ class Engine:
             raise ValueError("dtype must be 'f32', 'bf16' or 'f32_split', got %r" % (dtype,))
         cfg.dtype = {"f32": 0, "bf16": 1, "f32_split": 2}[dtype]   # FPC_F32 / FPC_BF16 / FPC_F32_SPLIT (include/fpc.h)
         self.dtype = dtype
+        if arch not in ("resnet", "vgg"):
+            raise ValueError("arch must be 'resnet' (python/src/superpoint.py) or 'vgg' (cpp/src/model.cc), got %r" % (arch,))
+        cfg.arch = 1 if arch == "vgg" else 0     # FPC_ARCH_RESNET / FPC_ARCH_VGG
+        self.arch = arch
         self.in_channels = 1 if in_channels == 1 else 3
         self.cfg = cfg
         self.h, self.w, self.max_batch, self.device = height, width, max_batch, device
@@ -133,7 +137,7 @@ class Engine:
         n = frames.shape[0]
         dev = self.torch_device
         prob = torch.empty((n, self.h, self.w), device=dev)
-        desc = torch.empty((n, 128, self.h // 8, self.w // 8), device=dev)
+        desc = torch.empty((n, self.desc_dim, self.h // 8, self.w // 8), device=dev)
         logits = torch.empty((n, 65, self.h // 8, self.w // 8), device=dev)
         torch.cuda.synchronize(dev)
         _lib.check(self._l.fpc_forward(self._ctx, frames.data_ptr(), n, prob.data_ptr(), desc.data_ptr(),
@@ -208,7 +212,7 @@ class Engine:
             k = int(cnt[f])
             xy = np.empty((k, 2), np.int32)
             conf = np.empty(k, np.float32)
-            desc = np.empty((k, 128), np.float32) if with_desc else None
+            desc = np.empty((k, self.desc_dim), np.float32) if with_desc else None
             got = self._l.fpc_get_keypoints(self._ctx, f, k, xy.ctypes.data, conf.ctypes.data,
                                             desc.ctypes.data if with_desc else None)
             _lib.check(got, "fpc_get_keypoints")
@@ -221,8 +225,8 @@ class Engine:
         if not isinstance(d, torch.Tensor):
             d = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32))
         d = d.to(self.torch_device, torch.float32).contiguous()
-        if d.dim() != 2 or d.shape[1] != 128:
-            raise ValueError("descriptors must be [n,128]")
+        if d.dim() != 2 or d.shape[1] != self.desc_dim:
+            raise ValueError("descriptors must be [n,%d]" % self.desc_dim)
         return d
 
     def match(self, query, train, cross_check=True, max_dist=0.0):

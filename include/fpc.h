@@ -43,6 +43,7 @@ enum {
 };
 
 enum { FPC_F32 = 0, FPC_BF16 = 1, FPC_F32_SPLIT = 2 };
+enum { FPC_ARCH_RESNET = 0, FPC_ARCH_VGG = 1 };
 
 /* Replaces SuperPointSettings (python/src/settings.py:2-8) / Settings
  * (cpp/src/settings.h:27-31) plus the geometry the reference takes from the frame. */
@@ -65,7 +66,11 @@ typedef struct fpc_config {
                           /* (2): fp32 tensors, matrix products on the bf16 pipe with each */
                           /* operand split exactly into three bf16 terms (block_x3.h):     */
                           /* fp32-level accuracy, same 1e-4 parity bar as FPC_F32          */
-  int reserved[5];
+  int arch;               /* FPC_ARCH_RESNET (0): the Python network (superpoint.py), 128-D; */
+                          /* FPC_ARCH_VGG (1): the C++ frontend's superpoint::SPModel        */
+                          /* (cpp/src/model.cc, settings.h:19-25): gray input                */
+                          /* (in_channels = 1), 256-D descriptors, fp32 or split mode        */
+  int reserved[4];
 } fpc_config;
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']
@@ -85,7 +90,7 @@ typedef struct fpc_device_results {
   const float* conf;          /* [n][cap]       descending (ties: row-major index ascending)*/
   const float* desc;          /* [n][cap][D]    unit L2 norm; NULL when descriptors are off */
   int capacity;               /* cap                                                       */
-  int desc_dim;               /* D = 128                                                   */
+  int desc_dim;               /* D = 128 (256 for FPC_ARCH_VGG)                            */
 } fpc_device_results;
 
 typedef struct fpc_ctx fpc_ctx;

@@ -639,3 +639,68 @@ def test_u8_frames_on_device(torch_gpu, golden_dir):
     with pytest.raises(Exception):
         e1.detect_u8(col, "rgb_hwc")                                # colour layout into a gray ctx
     e1.close()
+
+
+# ---- the reference's C++ network (superpoint::SPModel, cpp/src/model.cc): arch="vgg" -------------------------
+def _gray(seed, n, h, w):
+    return synth.make_batch(seed, n, h, w, gray=True)[:, :1].copy()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+def test_vgg_network_against_reference_binary_fixtures(torch_gpu, golden_dir, dtype):
+    """Dense maps of the HIP path vs the outputs of the reference's own cpp/src/model.cc (fixtures F7, written by
+    oracle/_ref/ref_vgg_forward) at the 1e-4 bar, and vs the oracle; post-processing exact on those maps."""
+    vspec = arch.vgg_state_dict_spec()
+    g = np.load(os.path.join(golden_dir, "f7_vgg_32x48.npz"))
+    sd = synth.make_vgg_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    fr = _gray(int(g["seed_frame"]), 1, 32, 48)
+    e = engine(32, 48, in_channels=1, arch="vgg", dtype=dtype)
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(fr)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(desc.cpu().numpy(), g["desc"], rtol=0, atol=ATOL)
+    e.close()
+    g = np.load(os.path.join(golden_dir, "f7_vgg_qvga.npz"))
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_vgg_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    fr = _gray(int(g["seed_frame"]), 1, h, w)
+    e = engine(h, w, in_channels=1, arch="vgg", dtype=dtype)
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(fr)
+    prob, desc, logits = prob.cpu().numpy(), desc.cpu().numpy(), logits.cpu().numpy()
+    np.testing.assert_allclose(logits.ravel()[::7], g["logits_probe"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(desc.ravel()[::11], g["desc_probe"], rtol=0, atol=ATOL)
+    oracle = oracle_mod()
+    o_prob, o_desc, o_logits = oracle.vgg_forward(fr, sd, vspec)
+    assert np.max(np.abs(logits - o_logits)) < 5e-5 and np.max(np.abs(desc - o_desc)) < 5e-6
+    assert np.max(np.abs(prob - o_prob)) < 1e-5
+    res = e.detect(fr)[0]
+    assert res[2].shape[1] == 256 and len(res[1]) > 50
+    _check_frame_against_oracle_postproc(oracle, prob[0], desc[0], res, h, w)
+    e.close()
+
+
+def test_vgg_batch_and_matching(torch_gpu):
+    """C++ network on a VGA batch that splits over the sub-batch streams: batch == single frames, NMS / order /
+    unit-norm properties, 256-D descriptor matching against the oracle."""
+    h, w, n = 480, 640, 5
+    sd = synth.make_vgg_state_dict(8, 3.0)
+    fr = _gray(900, n, h, w)
+    e = engine(h, w, n, in_channels=1, arch="vgg")
+    e.load_state_dict(sd)
+    res = e.detect(fr)
+    one = e.detect(fr[2:3])[0]
+    np.testing.assert_array_equal(one[0], res[2][0])
+    np.testing.assert_array_equal(one[1], res[2][1])
+    np.testing.assert_array_equal(one[2], res[2][2])
+    for xy, conf, d, ncand in res:
+        assert len(conf) > 100 and np.all(np.diff(conf) <= 0) and d.shape[1] == 256
+        np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
+    oracle = oracle_mod()
+    q, t = res[0][2][:300], res[1][2][:400]
+    m, dist = e.match(q, t, cross_check=True)
+    om, od = oracle.match(q, t, True)
+    np.testing.assert_array_equal(m, om)
+    e.close()
+    with pytest.raises(Exception):
+        engine(h, w, 1, in_channels=3, arch="vgg")        # the C++ network takes one gray plane
