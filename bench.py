@@ -159,6 +159,9 @@ def main():
                     help="vga32 only. f32 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32, Winograd where it pays). "
                          "f32_split: fp32 tensors, every product as six bf16 MFMAs on exactly split operands "
                          "(block_x3.h) -- same 1e-4 parity bar, reported beside the headline as `split_operand_mode`")
+    ap.add_argument("--arch", choices=["resnet", "vgg"], default="resnet",
+                    help="resnet (default): the Python network of BASELINE.json's configs. vgg: the cpp/ frontend's "
+                         "superpoint::SPModel (SURVEY 8f rank 4), gray frames, 52 GFLOP per VGA frame")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (H2D-inclusive) passes")
     ap.add_argument("--no-alt-pass", action="store_true", help="skip the extra pass in the other fp32 arithmetic mode")
     args = ap.parse_args()
@@ -179,13 +182,16 @@ def main():
     dev = torch.device("cuda", local)
 
     # synthetic checkpoint in the reference's layout; rank 0 packs and broadcasts it
-    sd = synth.make_state_dict(0, dustbin_bias=7.0) if rank == 0 else None
+    vgg = args.arch == "vgg"
+    if vgg:
+        args.gray, args.no_host_fed, args.no_alt_pass, args.no_cpu_baseline = True, True, True, True
+    sd = (synth.make_vgg_state_dict(0, dustbin_bias=5.5) if vgg else synth.make_state_dict(0, dustbin_bias=7.0)) if rank == 0 else None
     cin = 1 if args.gray else 3
-    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype)
+    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
     fdist.broadcast_packed_weights(eng, sd)
     engs = [eng]
     for _ in range(1, max(1, args.contexts)):
-        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype)
+        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
         e2.import_packed(eng.export_packed())
         engs.append(e2)
     # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
@@ -228,7 +234,7 @@ def main():
     if use_events and rank == 0 and world == 1 and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
         os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"] = "1", "0"
-        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype)
+        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
             e1.detect_async(frames, BATCH)
@@ -271,13 +277,15 @@ def main():
 
     if rank == 0:
         value = total_frames / dt
-        flops_frame = 2.0 * arch.conv_macs(H, W)
+        flops_frame = 2.0 * (arch.vgg_conv_macs(H, W) if vgg else arch.conv_macs(H, W))
         wl = ("batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
               "(BASELINE.json configs[1]; configs[2] when n_gpus=8)" +
               ("; products as six bf16 MFMAs on exactly split fp32 operands" if dtype == "f32_split" else "")
               ) if dtype != "bf16" else (
               "batch=64 1280x960 frames per GPU, super_point checkpoint layout, bf16 activations/weights, fp32 "
               "accumulation, fp32 post-processing (BASELINE.json configs[4])")
+        if vgg:
+            wl = "batch=32 640x480 gray frames per GPU, the cpp/ frontend's network (superpoint::SPModel, 256-D), " + dtype
         out = {
             "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("VGA 640x480" if dtype != "bf16" else "HD 1280x960"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

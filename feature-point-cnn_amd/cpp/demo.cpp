@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
       out.precision(9);
       for (auto& p : pts)
         out << p.x << ' ' << p.y << ' ' << p.confidence << ' ' << p.descriptor[0] << ' ' << p.descriptor[1] << ' '
-            << p.descriptor[2] << ' ' << p.descriptor[127] << '\n';
+            << p.descriptor[2] << ' ' << p.descriptor[127] << ' ' << p.descriptor[255] << '\n';
     }
     return 0;
   } catch (const std::exception& e) {  // cpp/src/main.cc:146-149

@@ -32,7 +32,7 @@
 
 namespace superpoint {
 
-using DescriptorType = std::array<float, 256>;  // torchutis.h:11; the snapshot net fills the first 128
+using DescriptorType = std::array<float, 256>;  // torchutis.h:11; the snapshot net fills the first 128, the C++ net all 256
 
 struct FeaturePoint {  // torchutis.h:13-18
   int x = 0;
@@ -56,12 +56,17 @@ class SuperPoint {
       throw std::runtime_error("SuperPoint: TorchScript/TRTorch loading is not part of this build; pass the "
                                "checkpoint file with load_script=false");
     ckpt_ = fpc_pt::load_checkpoint(file_name);
+    // the flat dict of the reference's own C++ network (cpp/src/model.cc, names as cpp/src/superpoint.cc:27-55
+    // copies them) selects that architecture; the trainer's snapshot selects the Python network
+    for (auto& kv : ckpt_.tensors)
+      if (kv.first == "encoder_conv0_a.weight") vgg_ = true;
   }
   SuperPoint(const SuperPoint&) = delete;
   SuperPoint& operator=(const SuperPoint&) = delete;
   ~SuperPoint() { release(); }
 
-  int descriptor_len() const { return 128; }
+  int descriptor_len() const { return vgg_ ? 256 : 128; }
+  bool is_cpp_network() const { return vgg_; }
   Settings& settings() { return settings_; }   // changes take effect at the next frame-size change
 
   // frame: rows x cols floats (gray)
@@ -72,6 +77,7 @@ class SuperPoint {
   }
   // frame: 3 x rows x cols planar RGB
   std::vector<FeaturePoint> ProcessFrameRGB(const float* chw, int rows, int cols) {
+    if (vgg_) throw std::runtime_error("SuperPoint: the C++ network (cpp/src/model.cc) takes one gray plane");
     ensure(rows, cols, 3);
     hip(hipMemcpy(frame_dev_, chw, (size_t)3 * rows * cols * sizeof(float), hipMemcpyHostToDevice), "upload");
     return run();
@@ -105,6 +111,7 @@ class SuperPoint {
     cfg.width = cols;
     cfg.max_batch = 1;
     cfg.in_channels = channels;
+    cfg.arch = vgg_ ? FPC_ARCH_VGG : FPC_ARCH_RESNET;
     cfg.nms_dist = settings_.nms_dist;
     cfg.conf_thresh = settings_.confidence_thresh;
     cfg.border_remove = settings_.border_remove;
@@ -132,7 +139,8 @@ class SuperPoint {
     chk(fpc_get_counts(ctx_, 1, &k, nullptr), "fpc_get_counts");
     xy_.resize((size_t)2 * k);
     conf_.resize(k);
-    desc_.resize((size_t)128 * k);
+    const int D = descriptor_len();
+    desc_.resize((size_t)D * k);
     chk(fpc_get_keypoints(ctx_, 0, k, xy_.data(), conf_.data(), desc_.data()), "fpc_get_keypoints");
     feature_points_.resize(k);
     for (int i = 0; i < k; ++i) {
@@ -141,13 +149,14 @@ class SuperPoint {
       fp.y = xy_[2 * i + 1];
       fp.confidence = conf_[i];
       fp.descriptor.fill(0.f);
-      std::copy(desc_.begin() + (size_t)128 * i, desc_.begin() + (size_t)128 * (i + 1), fp.descriptor.begin());
+      std::copy(desc_.begin() + (size_t)D * i, desc_.begin() + (size_t)D * (i + 1), fp.descriptor.begin());
     }
     return feature_points_;  // by-value copy, as cpp/src/superpoint.cc:95
   }
 
   Settings settings_;
   int device_ = 0, rows_ = 0, cols_ = 0, channels_ = 0;
+  bool vgg_ = false;
   fpc_pt::Checkpoint ckpt_;
   fpc_ctx* ctx_ = nullptr;
   float* frame_dev_ = nullptr;

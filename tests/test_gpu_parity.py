@@ -704,3 +704,33 @@ def test_vgg_batch_and_matching(torch_gpu):
     e.close()
     with pytest.raises(Exception):
         engine(h, w, 1, in_channels=3, arch="vgg")        # the C++ network takes one gray plane
+
+
+def test_cpp_entry_point_with_the_cpp_network(torch_gpu, tmp_path):
+    """The reference's C++ frontend end to end on ITS network: superpoint::SuperPoint(file, false) with the flat
+    {name: tensor} dict cpp/src/superpoint.cc:27-55 loads (torch.save of a dict, read by pt_reader.hpp without
+    libtorch), ProcessFrame(gray) -> FeaturePoints with 256-float descriptors (torchutis.h:11-18)."""
+    import subprocess
+    torch = torch_gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "feature-point-cnn_amd", "lib", "fpc_demo")
+    assert os.path.exists(demo), "run __graft_entry__.build()"
+    h, w = 240, 320
+    sd = synth.make_vgg_state_dict(32, 3.0)
+    ck = str(tmp_path / "sp_vgg_flat.pt")
+    torch.save({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, ck)
+    gray = _gray(401, 1, h, w)
+    gray[0, 0].tofile(str(tmp_path / "frame.f32"))
+    out = str(tmp_path / "pts.txt")
+    msg = subprocess.check_output([demo, ck, str(tmp_path / "frame.f32"), str(h), str(w), out]).decode()
+    got = np.loadtxt(out, ndmin=2)
+    e = engine(h, w, in_channels=1, arch="vgg")
+    e.load_state_dict(sd)
+    xy, conf, d, _ = e.detect(gray)[0]
+    assert msg.startswith("%d feature points" % len(conf)) and len(conf) > 50
+    np.testing.assert_array_equal(got[:, 0].astype(np.int32), xy[:, 0])
+    np.testing.assert_array_equal(got[:, 1].astype(np.int32), xy[:, 1])
+    np.testing.assert_allclose(got[:, 2], conf, rtol=1e-6)
+    np.testing.assert_allclose(got[:, 3:6], d[:, 0:3], atol=1e-6)
+    np.testing.assert_allclose(got[:, 7], d[:, 255], atol=1e-6)
+    e.close()
