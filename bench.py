@@ -66,6 +66,25 @@ def cpu_baseline(state_dict, frames):
                       "oracle/fpc_oracle.c with %d OpenMP threads, %.1f s" % (n, W, H, threads, dt)}
 
 
+def cpu_baseline_vgg_reference(sd, frames):
+    """kind "reference": the reference's own cpp/src/model.cc (oracle/_ref/ref_vgg_forward, built by
+    oracle/Makefile.ref) timed on this host's cores -- the forward pass only, which is all of cpp/ that can be built."""
+    import importlib.util
+    path = os.path.join(ROOT, "tests", "golden", "make_golden_vgg.py")
+    spec = importlib.util.spec_from_file_location("make_golden_vgg", path)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    if not os.path.exists(mg.BIN):
+        return None
+    n, reps = frames.shape[0], 3
+    _, _, err = mg.run_reference(sd, frames, repeats=reps)
+    kv = dict(ln.split() for ln in err.strip().splitlines() if len(ln.split()) == 2)
+    sec = float(kv["forward_seconds"])
+    return {"value": round(n / sec, 3), "unit": "frames/s", "cores": int(kv.get("threads", 0)), "kind": "reference",
+            "sample": "%d of the bench's %dx%d gray frames, SPModel::forward only (cpp/src/model.cc compiled unmodified "
+                      "with libtorch CPU, %d runs of %.2f s); the rest of cpp/ needs TRTorch/OpenCV" % (n, W, H, reps, sec)}
+
+
 def host_fed_rates(sd, frames_np, local, dtype, steps=12):
     """H2D-inclusive rates (the second figure, never `value`): every step uploads its batch from
     pinned host memory and runs the path; two contexts on two streams so that batch k+1 uploads while batch k
@@ -184,7 +203,7 @@ def main():
     # synthetic checkpoint in the reference's layout; rank 0 packs and broadcasts it
     vgg = args.arch == "vgg"
     if vgg:
-        args.gray, args.no_host_fed, args.no_alt_pass, args.no_cpu_baseline = True, True, True, True
+        args.gray, args.no_host_fed, args.no_alt_pass = True, True, True
     sd = (synth.make_vgg_state_dict(0, dustbin_bias=5.5) if vgg else synth.make_state_dict(0, dustbin_bias=7.0)) if rank == 0 else None
     cin = 1 if args.gray else 3
     eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
@@ -331,7 +350,11 @@ def main():
             out["host_fed"] = host_fed
         if alt is not None:
             out["split_operand_mode" if alt["dtype"] == "f32_split" else "plain_f32_mfma_mode"] = alt
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and vgg:
+            cb = cpu_baseline_vgg_reference(sd, frames_np[:4])
+            if cb is not None:
+                out["cpu_baseline"] = cb
+        elif world == 1 and not args.no_cpu_baseline:
             ncb = 8 if H * W <= 480 * 640 else 2
             cb_frames = frames_np[:ncb] if not args.gray else np.repeat(frames_np[:ncb], 3, axis=1)
             out["cpu_baseline"] = cpu_baseline(sd, cb_frames)

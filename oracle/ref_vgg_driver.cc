@@ -3,13 +3,17 @@
 // into oracle/_ref/), on inputs and parameters read from flat binary files, and writes its outputs.
 // Only this driver is ours; the network code is the reference's, unmodified, linked against the image's libtorch.
 //
-//   ref_vgg_forward <params.bin> <input.bin> <output.bin>
+//   ref_vgg_forward <params.bin> <input.bin> <output.bin> [repeats]
+// With `repeats` the forward pass is run that many more times and "forward_seconds <mean>" and "threads <n>" go to
+// stderr (bench.py's cpu_baseline of kind "reference" for --arch vgg).
 // params.bin : int32 count, then per entry: int32 name_len, name bytes, int32 ndim, int64 shape[ndim], float data
 //              (names as named_parameters() of SPModel gives them -- cpp/src/superpoint.cc:27-55 copies a flat
 //              {name: tensor} dict into exactly those)
 // input.bin  : int32 n, h, w, then float [n,1,h,w]
 // output.bin : int32 n, hc, wc, then float point [n,65,hc,wc], float desc [n,256,hc,wc]   (model.cc:61-93)
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -22,7 +26,7 @@
 static bool read_exact(std::ifstream& f, void* p, size_t n) { return (bool)f.read(reinterpret_cast<char*>(p), (std::streamsize)n); }
 
 int main(int argc, char** argv) {
-  if (argc != 4) {
+  if (argc != 4 && argc != 5) {
     std::cerr << "usage: ref_vgg_forward params.bin input.bin output.bin\n";
     return 2;
   }
@@ -68,6 +72,13 @@ int main(int argc, char** argv) {
   at::Tensor x = torch::empty({dims[0], 1, dims[1], dims[2]}, torch::kFloat32);
   if (!read_exact(fi, x.data_ptr<float>(), sizeof(float) * x.numel())) return 5;
   auto out = model->forward(x);
+  if (argc == 5) {
+    const int reps = std::atoi(argv[4]);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) out = model->forward(x);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cerr << "forward_seconds " << (reps > 0 ? dt / reps : 0.0) << "\nthreads " << at::get_num_threads() << "\n";
+  }
   at::Tensor point = out.first.contiguous(), desc = out.second.contiguous();
   std::ofstream fo(argv[3], std::ios::binary);
   int32_t od[3] = {(int32_t)point.size(0), (int32_t)point.size(2), (int32_t)point.size(3)};

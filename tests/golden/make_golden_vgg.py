@@ -27,8 +27,9 @@ from fpc_amd import arch, synth  # noqa: E402
 BIN = os.path.join(ROOT, "oracle", "_ref", "ref_vgg_forward")
 
 
-def run_reference(sd, frames):
-    """frames float32 [n,1,h,w] -> (point [n,65,hc,wc], desc [n,256,hc,wc], names text)"""
+def run_reference(sd, frames, repeats=None):
+    """frames float32 [n,1,h,w] -> (point [n,65,hc,wc], desc [n,256,hc,wc], names text); with `repeats` the names
+    text is replaced by the binary's stderr (mean forward seconds and thread count)."""
     with tempfile.TemporaryDirectory() as td:
         pf, inf, outf = (os.path.join(td, x) for x in ("params.bin", "input.bin", "output.bin"))
         with open(pf, "wb") as f:
@@ -41,7 +42,9 @@ def run_reference(sd, frames):
         n, _, h, w = frames.shape
         with open(inf, "wb") as f:
             f.write(struct.pack("<iii", n, h, w) + np.ascontiguousarray(frames, np.float32).tobytes())
-        names = subprocess.run([BIN, pf, inf, outf], check=True, capture_output=True, text=True).stdout
+        cp = subprocess.run([BIN, pf, inf, outf] + ([str(repeats)] if repeats is not None else []), check=True,
+                            capture_output=True, text=True)
+        names = cp.stdout if repeats is None else cp.stderr
         raw = open(outf, "rb").read()
     n2, hc, wc = struct.unpack("<iii", raw[:12])
     a = np.frombuffer(raw[12:], np.float32)
