@@ -242,6 +242,8 @@ struct Op {
   FKind fkind = FK_COUNT;
   BlockBfArgs fargs{};
   int phase = -1;              // ConvTranspose output-parity phase of a bf16 conv-only op
+  bool wconv = false;          // conv-only Winograd launch: 3x3 conv + (BN or bias) + ReLU, output channels n0 .. n0+127
+  int n0 = 0;
   bool plain_conv = false;     // a Conv2d + bias (+ ReLU) of the C++ network: weights `prefix`.weight / .bias, no BN
   int ksize = 0;
   const float* pin = nullptr;  // OP_POOL2 / OP_L2NORM / OP_VCONV0 operands
@@ -294,6 +296,7 @@ struct fpc_ctx {
   unsigned long long* diag_stamps = nullptr;
   int diag_n = 0;
 #endif
+  bool winograd_in1 = true;          // descriptor.layer_in.1 (256 ch): conv-only Winograd x2 + 1x1 (FPC_WINOGRAD_IN1=0: fused direct block)
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
@@ -539,6 +542,48 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   // 16 GEMMs of 32 rows per 128-pixel tile instead of 9 taps x 128 rows; then the 1x1 on 128 rows
   op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) *
                             (16.0 * 32 * a.nchunk * k.KC + 128.0 * (a.k8_h + a.k8_x) * 8.0);
+  c->ops.push_back(op);
+  c->convw.push_back(cw);
+}
+
+// A 3x3 stride-1 convolution + (folded BN | bias) + ReLU on the Winograd kernel in conv-only form.  Output channels
+// n0 .. n0 + CMID - 1 of the layer (a 256-wide layer takes two launches).  `bn`: weights are `prefix`.conv1.weight +
+// `prefix`.bn1.* (a ResNetBlock's first half); otherwise `prefix`.weight + `prefix`.bias (the C++ network).
+static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, const float* x, int csx, int cin, int H,
+                      int W, float* out, int cso, int cout, int n0, bool desc_branch, size_t* blob_off) {
+  const WKindInfo& k = g_wkinds[wk];
+  Op op;
+  op.type = OP_WBLOCK;
+  op.name = prefix + (bn ? ".conv1+bn1+relu [winograd" : " [winograd conv+bias+relu") +
+            (cout > k.CMID ? ", channels " + std::to_string(n0) + ".." + std::to_string(n0 + k.CMID - 1) : std::string()) + "]";
+  op.prefix = prefix;
+  op.wkind = wk;
+  op.wconv = true;
+  op.plain_conv = !bn;
+  op.n0 = n0;
+  op.cin = cin;
+  op.cout = cout;
+  op.descriptor_branch = desc_branch;
+  WBlockArgs& a = op.wargs;
+  const int K8 = k.KC / 8;
+  a.x = x;
+  a.csx = csx;
+  a.nchunk = cin / k.KC;
+  a.H = H;
+  a.W = W;
+  a.k8_h = a.k8_x = 0;
+  a.conv_only = 1;
+  a.out = out + n0;
+  a.cso = cso;
+  a.tiles_x = (W + 15) / 16;
+  a.tiles_y = (H + 7) / 8;
+  fpc_ctx::ConvW cw;
+  cw.w_off[0] = *blob_off;
+  *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
+  cw.b_off = *blob_off;
+  *blob_off += (size_t)k.NBT * 32;
+  op.flops_per_frame = 2.0 * H * W * (double)k.CMID * cin * 9;
+  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) * (16.0 * 32 * a.nchunk * k.KC);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -821,6 +866,12 @@ static int build_vgg_plan(fpc_ctx* c) {
       add_fconv(c, fk, prefix, x, cin, cin, cin, Hx, Wx, out, cso, cout, ksize, relu, desc, &bo);
       return;
     }
+    if (ksize == 3 && relu && c->winograd) {  // Winograd F(2x2,3x3), conv-only; 256 outputs = two 128-channel launches
+      const WKind wk = cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128;
+      for (int n0 = 0; n0 < cout; n0 += g_wkinds[wk].CMID)
+        add_wconv(c, prefix, false, wk, x, cin, cin, Hx, Wx, out, cso, cout, n0, desc, &bo);
+      return;
+    }
     ConvSpec s{};
     s.name = prefix + (relu ? " [conv+bias+relu]" : " [conv+bias]");
     if (ksize == 3) s.kind = cout == 64 ? K_T816_3x3_K64_N64 : K_T620_3x3_K64_N128;
@@ -918,6 +969,10 @@ static int build_vgg_plan(fpc_ctx* c) {
     if (op.type == OP_CONV) {
       op.args.sub[0].wfrag = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
       op.args.bias = c->blob + c->convw[i].b_off;
+    }
+    if (op.type == OP_WBLOCK) {
+      op.wargs.w1 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[0]);
+      op.wargs.b1 = c->blob + c->convw[i].b_off;
     }
   }
   return FPC_OK;
@@ -1091,6 +1146,21 @@ static int build_plan(fpc_ctx* c) {
   if (de) {
     block("descriptor.layer_in.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, feat, 256, 128, 128, Hc, Wc, c->h16,
           256, 256, 256, c->y16a, 256, true, true, BK_B320_s2_K32_C256);
+    if (c->fuse_blocks && c->winograd && c->winograd_in1) {
+      // 256 channels are too wide for the fused Winograd block (accumulators): conv1 as two conv-only Winograd
+      // launches of 128 output channels each, then conv2 + identity + ReLU as a 1x1 launch (h makes one round trip)
+      const std::string p = "descriptor.layer_in.1";
+      for (int n0 = 0; n0 < 256; n0 += 128)
+        add_wconv(c, p, true, WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+      ConvSpec t{};
+      t.name = p + ".conv2+bn2+identity+relu";
+      t.kind = K_T620_1x1_K64_N128; t.ksize = 1; t.stride = 1;
+      t.in0 = c->h16; t.cs0 = 256; t.cin0 = 256; t.cin0_pad = 256; t.H0 = H16; t.W0 = W16;
+      t.res = c->y16a; t.csr = 256;
+      t.out = c->y16b; t.cso = 256; t.cout = 256; t.nstore = 256; t.Ho = H16; t.Wo = W16; t.relu = 1;
+      t.desc_branch = true;
+      add_conv(c, t, &bo);
+    } else
     block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
           c->h16, 256, 256, 256, c->y16b, 256, false, true, BK_B320_s1_K64_C256);
     ConvSpec u{};
@@ -1183,7 +1253,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
         for (int n = 0; n < 64; ++n) dst[576 + n] = bv[n];
         continue;
       }
-      if (!op.plain_conv) continue;
+      if (!op.plain_conv || op.type == OP_WBLOCK) continue;   // Winograd conv-only launches: generic loop below
       const int ci = op.cin, co = op.cout, kk = op.ksize * op.ksize;
       const float* w = need(op.prefix + ".weight", {co, ci, op.ksize, op.ksize});
       const float* bv = need(op.prefix + ".bias", {co});
@@ -1200,10 +1270,9 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
       memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b_off + n] = bv[n];
     }
-    return FPC_OK;
   }
   // stem
-  {
+  if (!c->vgg) {
     const float* w = need("encoder.conv1.weight", {64, 3, 7, 7});
     Fold f;
     if (!w || !fold_bn(m, "encoder.bn1", 64, &f, missing)) return FPC_E_MISSING_KEY;
@@ -1245,12 +1314,54 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
   }
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
+    if (c->vgg && op.type != OP_WBLOCK) continue;  // packed above
     if (op.type == OP_WBLOCK) {
       const WKindInfo& k = g_wkinds[op.wkind];
       const WBlockArgs& a = op.wargs;
       const fpc_ctx::ConvW& cw = c->convw[i];
       const std::string& p = op.prefix;
       const int ci = op.cin, co = op.cout, nbt = k.NBT, K8 = k.KC / 8;
+      if (op.wconv) {  // conv-only launch: U = G g G^T of output channels n0 .. n0 + CMID - 1
+        const float* w1 = need(p + (op.plain_conv ? ".weight" : ".conv1.weight"), {co, ci, 3, 3});
+        Fold f1;
+        if (!w1) return FPC_E_MISSING_KEY;
+        if (op.plain_conv) {
+          const float* bv = need(p + ".bias", {co});
+          if (!bv) return FPC_E_MISSING_KEY;
+          f1.s.assign(co, 1.0);
+          f1.t.assign(bv, bv + co);
+        } else if (!fold_bn(m, p + ".bn1", co, &f1, missing)) {
+          return FPC_E_MISSING_KEY;
+        }
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        float* dst = blob.data() + cw.w_off[0];
+        const int nn = std::min(k.CMID, co - op.n0);
+        std::vector<double> U((size_t)nn * ci * 16);
+        for (int n = 0; n < nn; ++n)
+          for (int cc = 0; cc < ci; ++cc) {
+            const float* g = w1 + ((size_t)(op.n0 + n) * ci + cc) * 9;
+            double t[4][3];
+            for (int i = 0; i < 4; ++i)
+              for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+            for (int i = 0; i < 4; ++i)
+              for (int j = 0; j < 4; ++j)
+                U[((size_t)n * ci + cc) * 16 + i * 4 + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * f1.s[op.n0 + n];
+          }
+        for (int ch = 0; ch < a.nchunk; ++ch)
+          for (int xi = 0; xi < 16; ++xi)
+            for (int k8 = 0; k8 < K8; ++k8)
+              for (int nb = 0; nb < nbt; ++nb)
+                for (int lane = 0; lane < 64; ++lane) {
+                  const int n = nb * 32 + (lane & 31), half = lane >> 5;
+                  float* d4 = dst + (((((size_t)ch * 16 + xi) * K8 + k8) * nbt + nb) * 64 + lane) * 4;
+                  for (int j = 0; j < 4; ++j) {
+                    const int cc = ch * k.KC + k8 * 8 + 4 * half + j;
+                    d4[j] = (n < nn && cc < ci) ? (float)U[((size_t)n * ci + cc) * 16 + xi] : 0.f;
+                  }
+                }
+        for (int n = 0; n < nn; ++n) blob[cw.b_off + n] = (float)f1.t[op.n0 + n];
+        continue;
+      }
       const float* w1 = need(p + ".conv1.weight", {co, ci, 3, 3});
       const float* w2 = need(p + ".conv2.weight", {co, co, 1, 1});
       Fold f1, f2, fp;
@@ -1855,6 +1966,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
     if (const char* e = getenv("FPC_PERSIST_MIN")) c->persist_min_tiles = atoi(e);
     if (const char* e = getenv("FPC_WINOGRAD_DET")) c->winograd_det = atoi(e) != 0;
+    if (const char* e = getenv("FPC_WINOGRAD_IN1")) c->winograd_in1 = atoi(e) != 0;
     if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

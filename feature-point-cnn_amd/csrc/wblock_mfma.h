@@ -30,6 +30,8 @@ struct WBlockArgs {
   float* out;
   int cso, tiles_x, tiles_y, frame0;
   int total;             // tiles_x * tiles_y * frames of this launch; the grid is persistent
+  int conv_only;         // 1: stop after h = relu(conv3x3(x) + b1) and store it (a plain Conv2d + bias/BN + ReLU:
+                         // the layers of the C++ network, conv1 of a block too wide to fuse); w2 / b2 unused
 #ifdef FPC_DIAG
   unsigned long long* stamps;
 #endif
@@ -282,6 +284,21 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
   }
   FPC_LDS_BARRIER();
   if (wg == (int)blockIdx.x) { FPC_STAMP(3) }
+  if (a.conv_only) {  // h is the result: [128 px][CMID] in LDS -> 16-byte stores
+    constexpr int C4S = CMID / 4;
+    constexpr int NES = TH * TW * C4S, EITS = (NES + NT - 1) / NT;
+    const float4* h4r = lds4 + C::M_BYTES / 16;
+#pragma unroll
+    for (int i = 0; i < EITS; ++i) {
+      const int e = tid_t + i * NT;
+      const int m = e / C4S, c4 = e - m * C4S;
+      const int py = m / TW, px = m - py * TW;
+      const int y = ty * TH + py, x = tx * TW + px;
+      if ((NES % NT == 0 || e < NES) && y < a.H && x < a.W)
+        *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) = h4r[m * ROWH4 + c4];
+    }
+    continue;  // next tile: its first barrier orders these LDS reads before the V region is rewritten
+  }
 
   // ---------------------------------------------------------------- phase 2: 1x1 over h (+ projection over x)
   // 4 M blocks (128 pixels) x NBT channel blocks over 8 waves
