@@ -32,15 +32,19 @@ PEAK_BF16_MFMA_TFLOPS = 2516.8  # ibid.: BF16 MFMA dense = 16x the FP32 matrix r
 PEAK_TFLOPS = PEAK_F32_MFMA_TFLOPS     # ceiling for ALGORITHMIC flops in the selected arithmetic mode
 PEAK_ISSUED_TFLOPS = PEAK_F32_MFMA_TFLOPS  # ceiling for the MFMA instructions really issued
 BATCH = 32
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/): filled in
-# once measured; null until then.
 # HBM bytes per FRAME of each kernel symbol from the rocprofv3 PMC passes in
-# profiles/r01c_pmc_summary_serial.csv: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch / 32 frames
-# (the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md for 16 B/lane reads).
+# profiles/r01f_pmc_summary_serial.csv (one stream, default plan): (2*FETCH_SIZE + WRITE_SIZE) KiB per
+# dispatch / 32 frames, averaged over the layers that share the symbol (the x2 on FETCH_SIZE is the gfx950
+# correction of MI355X_MICROARCH.md for 16 B/lane reads; FETCH_SIZE and WRITE_SIZE in separate passes).
 TRAFFIC_BYTES_PER_FRAME = {
-    "wblock_mfma_kernel<32, 4>": 338285717 / 32.0,
-    "wblock_mfma_kernel<32, 2>": 387938800 / 32.0,
-    "stem_pool_kernel": 589139552 / 32.0,
+    "wblock_mfma_kernel<32, 4, 128>": 302555232 / 32.0,
+    "wblock_mfma_kernel<32, 2, 64>": 430280704 / 32.0,
+    "wblock_mfma_kernel<32, 3, 72>": 214662592 / 32.0,
+    "stem_pool_kernel": 589152640 / 32.0,
+    # profiles/r01f_pmc_summary_serial_f32_split.csv
+    "block_x3_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 369665184 / 32.0,
+    "block_x3_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 497191072 / 32.0,
+    "stem_pool_x3_kernel": 589343840 / 32.0,
 }
 H, W = 480, 640
 
