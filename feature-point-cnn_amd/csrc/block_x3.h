@@ -20,33 +20,55 @@
 
 namespace fpc {
 
-struct Split3 {
-  uint4 p[3];
-};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// 8 fp32 values -> three planes of 8 bf16 (16 bytes each)
-__device__ __forceinline__ Split3 split8(const float4& a, const float4& b) {
+template <int NP>
+struct SplitN {
+  uint4 p[NP];
+};
+typedef SplitN<3> Split3;
+
+// 8 fp32 values -> NP planes of 8 sixteen-bit terms (16 bytes each).
+//   NP = 3: bf16 terms by truncation (exact 24 = 3 x 8 bit split, any fp32 magnitude)
+//   NP = 2: fp16 terms, round-to-nearest: x = h + l + e with |e| <= 2^-24 |x| for 6.1e-5 <= |x| <= 65504 (fp16's
+//           normal range; below it the error is <= 3e-8 absolute, above it the value saturates -- block_x3.h header)
+template <int NP>
+__device__ __forceinline__ SplitN<NP> splitN(const float4& a, const float4& b) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  unsigned h[8], m[8], l[8];
+  SplitN<NP> s;
+  if constexpr (NP == 3) {
+    unsigned h[8], m[8], l[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const unsigned u = __float_as_uint(v[i]);
-    const unsigned hi = u & 0xffff0000u;
-    const float r = v[i] - __uint_as_float(hi);
-    const unsigned mi = __float_as_uint(r) & 0xffff0000u;
-    const float q = r - __uint_as_float(mi);
-    h[i] = hi;
-    m[i] = mi;
-    l[i] = __float_as_uint(q);  // <= 8 significant bits: its low 16 bits are zero
+    for (int i = 0; i < 8; ++i) {
+      const unsigned u = __float_as_uint(v[i]);
+      const unsigned hi = u & 0xffff0000u;
+      const float r = v[i] - __uint_as_float(hi);
+      const unsigned mi = __float_as_uint(r) & 0xffff0000u;
+      const float q = r - __uint_as_float(mi);
+      h[i] = hi;
+      m[i] = mi;
+      l[i] = __float_as_uint(q);  // <= 8 significant bits: its low 16 bits are zero
+    }
+    // pack pairs: element 2j in the low half, 2j+1 in the high half
+    s.p[0] = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+    s.p[1] = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
+    s.p[2] = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u),
+                        (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u));
+  } else {
+    unsigned hh[8], ll[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
+      const _Float16 l = (_Float16)__builtin_amdgcn_fmed3f(v[i] - (float)h, -65504.f, 65504.f);
+      hh[i] = __builtin_bit_cast(unsigned short, h);
+      ll[i] = __builtin_bit_cast(unsigned short, l);
+    }
+    s.p[0] = make_uint4(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16));
+    s.p[1] = make_uint4(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16));
   }
-  Split3 s;
-  // pack pairs: element 2j in the low half, 2j+1 in the high half
-  s.p[0] = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
-  s.p[1] = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
-  s.p[2] = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u),
-                      (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u));
   return s;
 }
+__device__ __forceinline__ Split3 split8(const float4& a, const float4& b) { return splitN<3>(a, b); }
 
 #define FPC_X3_MFMA(ACC, A, B)                                                                                          \
   do {                                                                                                                  \
@@ -58,15 +80,27 @@ __device__ __forceinline__ Split3 split8(const float4& a, const float4& b) {
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (A)[0]), __builtin_bit_cast(bf16x8, (B)[0]), ACC, 0, 0, 0); \
   } while (0)
 
-template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
-struct BlockX3Cfg {
+// acc += a * b on split operands: NP = 3 six bf16 MFMAs, NP = 2 three fp16 MFMAs (small terms first)
+template <int NP>
+__device__ __forceinline__ void mfma_split(f32x16& acc, const uint4* A, const uint4* B) {
+  if constexpr (NP == 3) {
+    FPC_X3_MFMA(acc, A, B);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[1]), __builtin_bit_cast(f16x8, B[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), __builtin_bit_cast(f16x8, B[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), __builtin_bit_cast(f16x8, B[0]), acc, 0, 0, 0);
+  }
+}
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP, int NP>
+struct BlockSplitCfg {
   static constexpr int NT = WM * WN * 64;
   static constexpr int HW = (TW - 1) * S + EXT, HH = (TH - 1) * S + EXT;
   static constexpr int ROW16 = KC / 8 + 1;            // 16-byte units per halo pixel and plane (+1 skew)
   static constexpr int PLANE16 = HH * HW * ROW16;
   static constexpr int ROWO4 = CMIDP / 4 + 1;         // float4 per row of the fp32 h / output tile
   static constexpr int M = WM * MB * 32, N = WN * NB * 32;
-  static constexpr int HALO_BYTES = 3 * PLANE16 * 16;
+  static constexpr int HALO_BYTES = NP * PLANE16 * 16;
   static constexpr int O_BYTES = M * ROWO4 * 16;
   static constexpr int LDS_BYTES = HALO_BYTES > O_BYTES ? HALO_BYTES : O_BYTES;
   static_assert(KC % 16 == 0 && CMIDP % 16 == 0 && CMIDP <= N, "bf16 MFMA consumes 16 channels per step");
@@ -75,8 +109,13 @@ struct BlockX3Cfg {
 // BlockBfArgs as in block_bf16.h; x and out are fp32 (in_f32 / out_f32 are ignored), csx / cso in floats.
 // Weight fragments: [step][plane][nb][lane] uint4.
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
-__global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfArgs a) {
-  using C = BlockX3Cfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
+using BlockX3Cfg = BlockSplitCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 3>;
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+using BlockH2Cfg = BlockSplitCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 2>;
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP, int NP>
+__device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
+  using C = BlockSplitCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, NP>;
   constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
   constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, PLANE16 = C::PLANE16, ROWO4 = C::ROWO4, NBT = WN * NB;
   extern __shared__ uint4 lds16[];
@@ -99,7 +138,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
     const int py = m / TW, px = m - py * TW;
     abase[mb] = ((py * S) * HW + px * S) * ROW16 + half;
   }
-  constexpr int planestride = NBT * 64, stepstride = 3 * NBT * 64;
+  constexpr int planestride = NBT * 64, stepstride = NP * NBT * 64;
   const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
 
   const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
@@ -126,10 +165,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
       const int e = tid + i * NT;
       const int pix = e / KC8, c8 = e - pix * KC8;
       if (NV % NT == 0 || e < NV) {
-        const Split3 s = split8(stage[i][0], stage[i][1]);
-        lds16[pix * ROW16 + c8] = s.p[0];
-        lds16[PLANE16 + pix * ROW16 + c8] = s.p[1];
-        lds16[2 * PLANE16 + pix * ROW16 + c8] = s.p[2];
+        const SplitN<NP> s = splitN<NP>(stage[i][0], stage[i][1]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) lds16[p * PLANE16 + pix * ROW16 + c8] = s.p[p];
       }
     }
   };
@@ -144,11 +182,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
 
   // ---------------------------------------------------------------- phase 1: KxK conv
   load_chunk(0);
-  uint4 bc[NB][3];
+  uint4 bc[NB][NP];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bc[nb][p] = wp[p * planestride + nb * 64];
+    for (int p = 0; p < NP; ++p) bc[nb][p] = wp[p * planestride + nb * 64];
   wp += stepstride;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     if (chunk) FPC_LDS_BARRIER();
@@ -159,40 +197,40 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
       const int toff = a.tapoff16[tap];
 #pragma unroll
       for (int k = 0; k < K16; ++k) {
-        uint4 bn[NB][3];
+        uint4 bn[NB][NP];
 #ifdef FPC_X3_NOB
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) { bn[nb][p] = bc[nb][p]; asm volatile("" : "+v"(bn[nb][p].x)); }
+          for (int p = 0; p < NP; ++p) { bn[nb][p] = bc[nb][p]; asm volatile("" : "+v"(bn[nb][p].x)); }
 #else
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bn[nb][p] = wp[p * planestride + nb * 64];
+          for (int p = 0; p < NP; ++p) bn[nb][p] = wp[p * planestride + nb * 64];
 #endif
         wp += stepstride;
         __builtin_amdgcn_sched_barrier(0);
-        uint4 av[MB][3];
+        uint4 av[MB][NP];
 #ifdef FPC_X3_NOA
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) { av[mb][p] = make_uint4(toff + k, tid, p, mb); asm volatile("" : "+v"(av[mb][p].x)); }
+          for (int p = 0; p < NP; ++p) { av[mb][p] = make_uint4(toff + k, tid, p, mb); asm volatile("" : "+v"(av[mb][p].x)); }
 #else
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) av[mb][p] = lds16[p * PLANE16 + abase[mb] + toff + k * 2];
+          for (int p = 0; p < NP; ++p) av[mb][p] = lds16[p * PLANE16 + abase[mb] + toff + k * 2];
 #endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb], bc[nb]);
+          for (int nb = 0; nb < NB; ++nb) mfma_split<NP>(acc[mb][nb], av[mb], bc[nb]);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+          for (int p = 0; p < NP; ++p) bc[nb][p] = bn[nb][p];
       }
     }
   }
@@ -203,7 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bc[nb][p] = wq[p * planestride + nb * 64];
+      for (int p = 0; p < NP; ++p) bc[nb][p] = wq[p * planestride + nb * 64];
     wq += stepstride;
     FPC_LDS_BARRIER();
     {
@@ -230,24 +268,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWO4 + half * 2;
     for (int k = 0; k < a.k16_h; ++k) {
-      uint4 bn[NB][3];
+      uint4 bn[NB][NP];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bn[nb][p] = wq[p * planestride + nb * 64];
+        for (int p = 0; p < NP; ++p) bn[nb][p] = wq[p * planestride + nb * 64];
       wq += stepstride;
       __builtin_amdgcn_sched_barrier(0);
-      Split3 av[MB];
+      SplitN<NP> av[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) av[mb] = split8(hl4[hbase[mb] + k * 4], hl4[hbase[mb] + k * 4 + 1]);
+      for (int mb = 0; mb < MB; ++mb) av[mb] = splitN<NP>(hl4[hbase[mb] + k * 4], hl4[hbase[mb] + k * 4 + 1]);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb].p, bc[nb]);
+        for (int nb = 0; nb < NB; ++nb) mfma_split<NP>(acc[mb][nb], av[mb].p, bc[nb]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+        for (int p = 0; p < NP; ++p) bc[nb][p] = bn[nb][p];
     }
     // -------------------------------------------------------------- phase 2b: K over x (projection)
     if (a.k16_x > 0) {
@@ -270,17 +308,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
         an[mb][1] = p[1];
       }
       for (int k = 0; k < a.k16_x; ++k) {
-        uint4 bn[NB][3];
+        uint4 bn[NB][NP];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bn[nb][p] = wq[p * planestride + nb * 64];
+          for (int p = 0; p < NP; ++p) bn[nb][p] = wq[p * planestride + nb * 64];
         wq += stepstride;
-        Split3 av[MB];
+        SplitN<NP> av[MB];
         const int kn = k + 1 < a.k16_x ? k + 1 : k;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          av[mb] = split8(an[mb][0], an[mb][1]);
+          av[mb] = splitN<NP>(an[mb][0], an[mb][1]);
           const float4* p = reinterpret_cast<const float4*>(xin + xoff[mb] + kn * 16);
           an[mb][0] = p[0];
           an[mb][1] = p[1];
@@ -289,11 +327,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb].p, bc[nb]);
+          for (int nb = 0; nb < NB; ++nb) mfma_split<NP>(acc[mb][nb], av[mb].p, bc[nb]);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+          for (int p = 0; p < NP; ++p) bc[nb][p] = bn[nb][p];
       }
     }
   }
@@ -346,6 +384,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfA
   }
 }
 
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfArgs a) {
+  block_split_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 3>(a);
+}
+
+// The same kernel on two fp16 terms per operand and three fp16 MFMAs per product (dtype = FPC_F32_SPLIT_F16)
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_h2_kernel(const BlockBfArgs a) {
+  block_split_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 2>(a);
+}
 
 // ---------------------------------------------------------------------------------
 // Stem + max-pool on split operands (stem_pool_kernel of kernels_misc.h with the 7x7/2 convolution as six

@@ -189,7 +189,17 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
   X(S320_s1_K64_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)     \
   X(S620_ct_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)     \
   X(S620_1x1_K64_C80, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 1, 64, 4, 1, 1, 3, 80)      \
-  X(S320_1x1_K64_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 1, 1, 64, 1, 4, 2, 2, 256)
+  X(S320_1x1_K64_C256, block_x3_kernel, BlockX3Cfg, 3, 3, 20, 1, 1, 64, 1, 4, 2, 2, 256)     \
+  X(H816_s1_K64_C64, block_h2_kernel, BlockH2Cfg, 2, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
+  X(H620_s2_K16_C128, block_h2_kernel, BlockH2Cfg, 2, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)     \
+  X(H620_s1_K64_C128, block_h2_kernel, BlockH2Cfg, 2, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)     \
+  X(H620_s1_K64_C80, block_h2_kernel, BlockH2Cfg, 2, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
+  X(H620_s1_K16_C80, block_h2_kernel, BlockH2Cfg, 2, 6, 20, 1, 3, 16, 4, 1, 1, 3, 80)     \
+  X(H320_s2_K16_C256, block_h2_kernel, BlockH2Cfg, 2, 3, 20, 2, 3, 16, 1, 4, 2, 2, 256)     \
+  X(H320_s1_K64_C256, block_h2_kernel, BlockH2Cfg, 2, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)     \
+  X(H620_ct_K64_C128, block_h2_kernel, BlockH2Cfg, 2, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)     \
+  X(H620_1x1_K64_C80, block_h2_kernel, BlockH2Cfg, 2, 6, 20, 1, 1, 64, 4, 1, 1, 3, 80)     \
+  X(H320_1x1_K64_C256, block_h2_kernel, BlockH2Cfg, 2, 3, 20, 1, 1, 64, 1, 4, 2, 2, 256)
 
 enum FKind {
 #define X(name, ...) FK_##name,
@@ -275,7 +285,8 @@ struct fpc_ctx {
   std::vector<float*> vbuf;          // VGG activation buffers
   size_t vconv0_off = 0;
   bool bf16 = false;                 // cfg.dtype == FPC_BF16
-  bool split = false;                // cfg.dtype == FPC_F32_SPLIT
+  bool split = false;                // cfg.dtype == FPC_F32_SPLIT or FPC_F32_SPLIT_F16
+  bool split_f16 = false;            // ... the latter: two fp16 terms per operand, three MFMAs per product
   int lgcs = 72;                     // channel stride of the logits buffer (80 in bf16 mode)
   int cin = 3;                       // 3: [n,3,H,W] frames (the reference's layout); 1: gray [n,1,H,W]
   int cap = 0, sort_cap = 0;
@@ -603,7 +614,7 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   const FKindInfo& k = g_fkinds[s.kind];
   Op op;
   op.type = OP_BF16;
-  const std::string tag = k.planes == 3 ? " [3xbf16 " : " [bf16 ";
+  const std::string tag = k.planes == 3 ? " [3xbf16 " : k.planes == 2 ? " [2xfp16 " : " [bf16 ";
   op.name = s.prefix + tag + (s.proj ? "conv1+bn1+relu+conv2+bn2+proj+relu]" : "conv1+bn1+relu+conv2+bn2+identity+relu]");
   op.prefix = s.prefix;
   op.fkind = s.kind;
@@ -646,7 +657,7 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   *blob_off += (size_t)nbt * 32;
   op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
   // split operands: six bf16 MFMAs per product
-  op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : 1.0) * 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
+  op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : k.planes == 2 ? 3.0 : 1.0) * 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
                             ((double)a.nchunk * k.KC * 9 + (a.k16_h + a.k16_x) * 16.0);
   c->ops.push_back(op);
   c->convw.push_back(cw);
@@ -662,7 +673,7 @@ static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, 
     const int py = ph >> 1, px = ph & 1;
     Op op;
     op.type = OP_BF16;
-    op.name = std::string("descriptor.up_sample+bn+relu [") + (k.planes == 3 ? "3xbf16" : "bf16") + " phase " + std::to_string(ph) + "]";
+    op.name = std::string("descriptor.up_sample+bn+relu [") + (k.planes == 3 ? "3xbf16" : k.planes == 2 ? "2xfp16" : "bf16") + " phase " + std::to_string(ph) + "]";
     op.prefix = "descriptor.up_sample";
     op.fkind = kind;
     op.phase = ph;
@@ -702,7 +713,7 @@ static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, 
     cw.b_off = *blob_off;
     *blob_off += (size_t)nbt * 32;
     op.flops_per_frame = 2.0 * a.ntaps * H * W * cin * cout;
-    op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : 1.0) * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+    op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : k.planes == 2 ? 3.0 : 1.0) * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
     c->ops.push_back(op);
     c->convw.push_back(cw);
   }
@@ -736,17 +747,20 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
 }
 
 // dtype = FPC_F32_SPLIT: the fp32 plan's buffers (all fp32), every ResNetBlock / ConvTranspose on block_x3_kernel
+// the fp16 twin of a bf16x3 instance (rows H* follow rows S* in the same order in FPC_BF16_KINDS)
+static FKind split_kind(const fpc_ctx* c, FKind s);
+
 static void build_x3_ops(fpc_ctx* c, size_t* bo) {
   const int H = c->H, W = c->W;
   const int H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
   const bool de = c->cfg.descriptor_enabled != 0;
   float* feat = c->cat + 128;
-  add_fblock(c, {"encoder.layer1.0", FK_S816_s1_K64_C64, c->x0, 64, 1, 64, 64, H4, W4, c->x1, 64, 1, 64, true, false}, bo);
-  add_fblock(c, {"encoder.layer1.1", FK_S816_s1_K64_C64, c->x1, 64, 1, 64, 64, H4, W4, c->x2, 64, 1, 64, false, false}, bo);
-  add_fblock(c, {"encoder.layer2.0", FK_S620_s2_K16_C128, c->x2, 64, 1, 64, 64, H4, W4, c->x3, 128, 1, 128, true, false}, bo);
-  add_fblock(c, {"encoder.layer2.1", FK_S620_s1_K64_C128, c->x3, 128, 1, 128, 128, Hc, Wc, feat, 256, 1, 128, false, false}, bo);
-  add_fblock(c, {"detector.layer.0", FK_S620_s1_K64_C80, feat, 256, 1, 128, 128, Hc, Wc, c->d0, 80, 1, 65, true, false}, bo);
-  add_fblock(c, {"detector.layer.1", FK_S620_s1_K16_C80, c->d0, 80, 1, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
+  add_fblock(c, {"encoder.layer1.0", split_kind(c, FK_S816_s1_K64_C64), c->x0, 64, 1, 64, 64, H4, W4, c->x1, 64, 1, 64, true, false}, bo);
+  add_fblock(c, {"encoder.layer1.1", split_kind(c, FK_S816_s1_K64_C64), c->x1, 64, 1, 64, 64, H4, W4, c->x2, 64, 1, 64, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.0", split_kind(c, FK_S620_s2_K16_C128), c->x2, 64, 1, 64, 64, H4, W4, c->x3, 128, 1, 128, true, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", split_kind(c, FK_S620_s1_K64_C128), c->x3, 128, 1, 128, 128, Hc, Wc, feat, 256, 1, 128, false, false}, bo);
+  add_fblock(c, {"detector.layer.0", split_kind(c, FK_S620_s1_K64_C80), feat, 256, 1, 128, 128, Hc, Wc, c->d0, 80, 1, 65, true, false}, bo);
+  add_fblock(c, {"detector.layer.1", split_kind(c, FK_S620_s1_K16_C80), c->d0, 80, 1, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
   {
     Op op;
     op.type = OP_SOFTMAX;
@@ -755,11 +769,11 @@ static void build_x3_ops(fpc_ctx* c, size_t* bo) {
     c->convw.push_back({});
   }
   if (de) {
-    add_fblock(c, {"descriptor.layer_in.0", FK_S320_s2_K16_C256, feat, 256, 1, 128, 128, Hc, Wc, c->y16a, 256, 1, 256, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_in.1", FK_S320_s1_K64_C256, c->y16a, 256, 1, 256, 256, H16, W16, c->y16b, 256, 1, 256, false, true}, bo);
-    add_fconvT(c, FK_S620_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
-    add_fblock(c, {"descriptor.layer_out.0", FK_S620_s1_K64_C128, c->cat, 256, 1, 256, 256, Hc, Wc, c->lo0, 128, 1, 128, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_out.1", FK_S620_s1_K64_C128, c->lo0, 128, 1, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.0", split_kind(c, FK_S320_s2_K16_C256), feat, 256, 1, 128, 128, Hc, Wc, c->y16a, 256, 1, 256, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.1", split_kind(c, FK_S320_s1_K64_C256), c->y16a, 256, 1, 256, 256, H16, W16, c->y16b, 256, 1, 256, false, true}, bo);
+    add_fconvT(c, split_kind(c, FK_S620_ct_K64_C128), c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
+    add_fblock(c, {"descriptor.layer_out.0", split_kind(c, FK_S620_s1_K64_C128), c->cat, 256, 1, 256, 256, Hc, Wc, c->lo0, 128, 1, 128, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", split_kind(c, FK_S620_s1_K64_C128), c->lo0, 128, 1, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
   }
 }
 
@@ -773,7 +787,7 @@ static void add_fconv(fpc_ctx* c, FKind kind, const std::string& prefix, const f
   const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
   Op op;
   op.type = OP_BF16;
-  op.name = prefix + (relu ? " [3xbf16 conv+bias+relu]" : " [3xbf16 conv+bias]");
+  op.name = prefix + (k.planes == 2 ? " [2xfp16 conv+bias" : " [3xbf16 conv+bias") + (relu ? "+relu]" : "]");
   op.prefix = prefix;
   op.fkind = kind;
   op.plain_conv = true;
@@ -808,7 +822,7 @@ static void add_fconv(fpc_ctx* c, FKind kind, const std::string& prefix, const f
   cw.b_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
   op.flops_per_frame = 2.0 * a.ntaps * H * W * (double)cin * cout;
-  op.mfma_flops_per_frame = 6.0 * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+  op.mfma_flops_per_frame = (k.planes == 2 ? 3.0 : 6.0) * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -861,8 +875,8 @@ static int build_vgg_plan(fpc_ctx* c) {
                   int ksize, bool relu, bool desc) {
     if (c->split) {
       FKind fk;
-      if (ksize == 3) fk = cout == 64 ? FK_S816_s1_K64_C64 : cout == 128 ? FK_S620_s1_K64_C128 : FK_S320_s1_K64_C256;
-      else fk = cout == 65 ? FK_S620_1x1_K64_C80 : FK_S320_1x1_K64_C256;
+      if (ksize == 3) fk = cout == 64 ? split_kind(c, FK_S816_s1_K64_C64) : cout == 128 ? split_kind(c, FK_S620_s1_K64_C128) : split_kind(c, FK_S320_s1_K64_C256);
+      else fk = cout == 65 ? split_kind(c, FK_S620_1x1_K64_C80) : split_kind(c, FK_S320_1x1_K64_C256);
       add_fconv(c, fk, prefix, x, cin, cin, cin, Hx, Wx, out, cso, cout, ksize, relu, desc, &bo);
       return;
     }
@@ -976,6 +990,11 @@ static int build_vgg_plan(fpc_ctx* c) {
     }
   }
   return FPC_OK;
+}
+
+static FKind split_kind(const fpc_ctx* c, FKind s) {
+  if (!c->split_f16) return s;
+  return (FKind)((int)s + ((int)FK_H816_s1_K64_C64 - (int)FK_S816_s1_K64_C64));
 }
 
 static int build_plan(fpc_ctx* c) {
@@ -1919,7 +1938,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   // H/8 or W/8 breaks its concat, so frames must be multiples of 16 unless it is disabled
   const int mult = (cfg->descriptor_enabled && cfg->arch != FPC_ARCH_VGG) ? 16 : 8;
   if (cfg->in_channels != 0 && cfg->in_channels != 1 && cfg->in_channels != 3) return FPC_E_INVALID;
-  if (cfg->dtype != FPC_F32 && cfg->dtype != FPC_BF16 && cfg->dtype != FPC_F32_SPLIT) return FPC_E_INVALID;
+  if (cfg->dtype < FPC_F32 || cfg->dtype > FPC_F32_SPLIT_F16) return FPC_E_INVALID;
   if (cfg->arch != FPC_ARCH_RESNET && cfg->arch != FPC_ARCH_VGG) return FPC_E_INVALID;
   // the C++ network takes one gray plane (cpp/src/settings.h:19) and has no bf16 plan
   if (cfg->arch == FPC_ARCH_VGG && (cfg->in_channels != 1 || cfg->dtype == FPC_BF16)) return FPC_E_INVALID;
@@ -1949,7 +1968,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->vgg = cfg->arch == FPC_ARCH_VGG;
   c->D = c->vgg ? 256 : 128;
   c->bf16 = cfg->dtype == FPC_BF16;
-  c->split = cfg->dtype == FPC_F32_SPLIT;
+  c->split = cfg->dtype == FPC_F32_SPLIT || cfg->dtype == FPC_F32_SPLIT_F16;
+  c->split_f16 = cfg->dtype == FPC_F32_SPLIT_F16;
   c->lgcs = (c->bf16 || c->split) ? 80 : 72;
   // kept points are pairwise > nms_dist apart (infinity norm): at most one per (r+1)^2 cell
   const int r1 = cfg->nms_dist + 1;

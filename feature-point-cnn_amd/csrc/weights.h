@@ -116,6 +116,59 @@ inline void host_split3(float x, uint16_t t[3]) {
   t[2] = (uint16_t)(w >> 16);
 }
 
+// float -> IEEE half, round to nearest even, saturating at +-65504 (the device's v_cvt_f16_f32 of a clamped value)
+inline uint16_t host_f2h(float x) {
+  if (x > 65504.f) x = 65504.f;
+  if (x < -65504.f) x = -65504.f;
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+  uint32_t m = u & 0x7fffffu;
+  if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7e00u);  // NaN
+  if (e >= 31) return (uint16_t)(sign | 0x7bffu);
+  if (e <= 0) {  // subnormal half (or zero)
+    if (e < -10) return (uint16_t)sign;
+    m |= 0x800000u;
+    const int shift = 14 - e;  // 24-bit significand -> 10 bits, plus the subnormal shift
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;  // may carry into the exponent: still correct
+  if (r >= 0x7c00u) r = 0x7bffu;
+  return (uint16_t)(sign | r);
+}
+inline float host_h2f(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, u;
+  if (e == 0) {
+    if (m == 0) {
+      u = sign;
+    } else {
+      int sh = 0;
+      while (!(m & 0x400u)) {
+        m <<= 1;
+        ++sh;
+      }
+      u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else {
+    u = sign | ((e - 15 + 127) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// Two-term fp16 split (block_x3.h, NP = 2): x ~ t[0] + t[1]
+inline void host_split2_f16(float x, uint16_t t[2]) {
+  t[0] = host_f2h(x);
+  t[1] = host_f2h(x - host_h2f(t[0]));
+}
+
 // The same for block_bf16_kernel / block_x3_kernel: 16 channels per step, 8 bf16 (16 bytes) per lane;
 //   planes = 1: frag[(step * nbt + nb) * 64 + lane] = { bf16(B[step*16 + 8*half + j][nb*32 + (lane&31)]) }, j = 0..7
 //   planes = 3: frag[((step * 3 + p) * nbt + nb) * 64 + lane] = term p of the exact split of the same element
@@ -139,6 +192,10 @@ inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, in
                 const float v = (n < cout && c < s.cin) ? (float)(s.w(n, c, tap) * (*s.scale)[n]) : 0.f;
                 if (planes == 1) {
                   o16[((step * nbt + nb) * 64 + lane) * 8 + j] = host_f2bf(v);
+                } else if (planes == 2) {  // block_h2_kernel: two fp16 terms
+                  uint16_t t[2];
+                  host_split2_f16(v, t);
+                  for (int p = 0; p < 2; ++p) o16[(((step * 2 + p) * nbt + nb) * 64 + lane) * 8 + j] = t[p];
                 } else {
                   uint16_t t[3];
                   host_split3(v, t);

@@ -54,9 +54,10 @@ class Engine:
         cfg.nms_dist, cfg.conf_thresh, cfg.border_remove = nms_dist, conf_thresh, border_remove
         cfg.descriptor_enabled, cfg.max_keypoints = int(bool(descriptor_enabled)), max_keypoints
         cfg.in_channels = in_channels
-        if dtype not in ("f32", "bf16", "f32_split"):
-            raise ValueError("dtype must be 'f32', 'bf16' or 'f32_split', got %r" % (dtype,))
-        cfg.dtype = {"f32": 0, "bf16": 1, "f32_split": 2}[dtype]   # FPC_F32 / FPC_BF16 / FPC_F32_SPLIT (include/fpc.h)
+        codes = {"f32": 0, "bf16": 1, "f32_split": 2, "f32_split_f16": 3}   # FPC_F32 ... FPC_F32_SPLIT_F16 (include/fpc.h)
+        if dtype not in codes:
+            raise ValueError("dtype must be one of %s, got %r" % (sorted(codes), dtype))
+        cfg.dtype = codes[dtype]
         self.dtype = dtype
         if arch not in ("resnet", "vgg"):
             raise ValueError("arch must be 'resnet' (python/src/superpoint.py) or 'vgg' (cpp/src/model.cc), got %r" % (arch,))

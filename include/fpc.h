@@ -42,7 +42,7 @@ enum {
   FPC_E_NOT_CONVERGED = -7 /* NMS round limit hit (never seen)     */
 };
 
-enum { FPC_F32 = 0, FPC_BF16 = 1, FPC_F32_SPLIT = 2 };
+enum { FPC_F32 = 0, FPC_BF16 = 1, FPC_F32_SPLIT = 2, FPC_F32_SPLIT_F16 = 3 };
 enum { FPC_ARCH_RESNET = 0, FPC_ARCH_VGG = 1 };
 
 /* Replaces SuperPointSettings (python/src/settings.py:2-8) / Settings
@@ -65,7 +65,10 @@ typedef struct fpc_config {
                           /* fp32 accumulation (BASELINE.json configs[4]); FPC_F32_SPLIT   */
                           /* (2): fp32 tensors, matrix products on the bf16 pipe with each */
                           /* operand split exactly into three bf16 terms (block_x3.h):     */
-                          /* fp32-level accuracy, same 1e-4 parity bar as FPC_F32          */
+                          /* fp32-level accuracy, same 1e-4 parity bar as FPC_F32;         */
+                          /* FPC_F32_SPLIT_F16 (3): the same with two fp16 terms per        */
+                          /* operand and three MFMAs per product (faster; operands must lie */
+                          /* in fp16's range, |x| <= 65504, or they saturate)               */
   int arch;               /* FPC_ARCH_RESNET (0): the Python network (superpoint.py), 128-D; */
                           /* FPC_ARCH_VGG (1): the C++ frontend's superpoint::SPModel        */
                           /* (cpp/src/model.cc, settings.h:19-25): gray input                */

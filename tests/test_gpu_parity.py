@@ -42,7 +42,7 @@ def test_native_library_is_loaded(torch_gpu):
     assert "libfpc.so" in maps
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+@pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
 def test_f1_small_frame_dense_maps(torch_gpu, golden_dir, dtype):
     g = np.load(os.path.join(golden_dir, "f1_layers_32x48.npz"))
     sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
@@ -74,7 +74,7 @@ def _check_frame_against_oracle_postproc(oracle, prob_b, desc_b, res, h, w):
         np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+@pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
 @pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
 def test_f5_end_to_end(torch_gpu, golden_dir, tag, dtype):
     """The reference's own outputs (tests/golden/make_golden.py) at the north_star bar -- dense maps within
@@ -344,7 +344,7 @@ def test_cpp_entry_point(torch_gpu, tmp_path):
     e.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+@pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
 def test_hd_frames_and_odd_batch(torch_gpu, dtype):
     """BASELINE.json configs[4] geometry (1280x960) in fp32, and a batch that does not split evenly
     over the sub-batch streams: dense maps against the oracle, post-processing exact."""
@@ -647,7 +647,7 @@ def _gray(seed, n, h, w):
     return synth.make_batch(seed, n, h, w, gray=True)[:, :1].copy()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32_split"])
+@pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
 def test_vgg_network_against_reference_binary_fixtures(torch_gpu, golden_dir, dtype):
     """Dense maps of the HIP path vs the outputs of the reference's own cpp/src/model.cc (fixtures F7, written by
     oracle/_ref/ref_vgg_forward) at the 1e-4 bar, and vs the oracle; post-processing exact on those maps."""
