@@ -178,10 +178,11 @@ def main():
     ap.add_argument("--workload", choices=["vga32", "hd64-bf16"], default="vga32",
                     help="vga32 = BASELINE.json configs[1] (the headline; default); hd64-bf16 = configs[4]: 64 frames of "
                          "1280x960 per step, bf16 activations / weights with fp32 accumulation")
-    ap.add_argument("--dtype", choices=["f32", "f32_split"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "f32_split", "f32_split_f16"], default="f32",
                     help="vga32 only. f32 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32, Winograd where it pays). "
                          "f32_split: fp32 tensors, every product as six bf16 MFMAs on exactly split operands "
-                         "(block_x3.h) -- same 1e-4 parity bar, reported beside the headline as `split_operand_mode`")
+                         "(block_x3.h) -- same 1e-4 parity bar, reported beside the headline as `split_operand_mode`. "
+                         "f32_split_f16: the same with two fp16 terms per operand and three MFMAs per product")
     ap.add_argument("--arch", choices=["resnet", "vgg"], default="resnet",
                     help="resnet (default): the Python network of BASELINE.json's configs. vgg: the cpp/ frontend's "
                          "superpoint::SPModel (SURVEY 8f rank 4), gray frames, 52 GFLOP per VGA frame")
@@ -190,8 +191,8 @@ def main():
     args = ap.parse_args()
     global H, W, BATCH, PEAK_TFLOPS, PEAK_ISSUED_TFLOPS
     dtype = args.dtype
-    if dtype == "f32_split":
-        PEAK_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # six bf16 MFMAs per fp32 product
+    if dtype in ("f32_split", "f32_split_f16"):
+        PEAK_TFLOPS = PEAK_BF16_MFMA_TFLOPS / (6.0 if dtype == "f32_split" else 3.0)   # six bf16 / three fp16 MFMAs per product
         PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
     if args.workload == "hd64-bf16":
         H, W, BATCH, dtype, PEAK_TFLOPS = 960, 1280, 64, "bf16", PEAK_BF16_MFMA_TFLOPS
@@ -271,28 +272,31 @@ def main():
         d1 = time.perf_counter() - t1
         serial = (symbol_stats(e1.timings(), ks), d1 / ks * 1e3, e1.timings(), ks)
         e1.close()
-    alt = None
-    if rank == 0 and world == 1 and not args.no_alt_pass and args.workload == "vga32":
-        # the other fp32 arithmetic mode on the same frames (not part of `value`)
+    alt = {}
+    if rank == 0 and world == 1 and not args.no_alt_pass and args.workload == "vga32" and not vgg:
+        # the other fp32 arithmetic modes on the same frames (not part of `value`)
         os.environ.pop("FPC_STREAMS", None)
         os.environ.pop("FPC_SPLIT_HEADS", None)
-        adt = "f32_split" if dtype == "f32" else "f32"
-        ea = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=adt)
-        ea.load_state_dict(sd)
-        for _ in range(3):
-            ea.detect_async(frames, BATCH)
-        ea.sync()
-        ks = min(20, max(5, args.steps))
-        t1 = time.perf_counter()
-        for _ in range(ks):
-            ea.detect_async(frames, BATCH)
-        ea.sync()
-        d1 = time.perf_counter() - t1
-        acnt, _ = ea.counts(BATCH)
-        alt = {"dtype": adt, "value": round(BATCH * ks / d1, 2), "unit": "frames/s", "steps": ks,
-               "ms_per_step": round(d1 / ks * 1e3, 4), "keypoints_per_frame": round(float(np.mean(acnt)), 1),
-               "same_keypoint_counts_as_headline_mode": bool(np.array_equal(acnt, cnt))}
-        ea.close()
+        for adt in ("f32", "f32_split", "f32_split_f16"):
+            if adt == dtype:
+                continue
+            ea = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=adt)
+            ea.load_state_dict(sd)
+            for _ in range(3):
+                ea.detect_async(frames, BATCH)
+            ea.sync()
+            ks = min(20, max(5, args.steps))
+            t1 = time.perf_counter()
+            for _ in range(ks):
+                ea.detect_async(frames, BATCH)
+            ea.sync()
+            d1 = time.perf_counter() - t1
+            acnt, _ = ea.counts(BATCH)
+            key = {"f32": "plain_f32_mfma_mode", "f32_split": "split_operand_mode", "f32_split_f16": "split_operand_fp16_mode"}[adt]
+            alt[key] = {"dtype": adt, "value": round(BATCH * ks / d1, 2), "unit": "frames/s", "steps": ks,
+                        "ms_per_step": round(d1 / ks * 1e3, 4), "keypoints_per_frame": round(float(np.mean(acnt)), 1),
+                        "same_keypoint_counts_as_headline_mode": bool(np.array_equal(acnt, cnt))}
+            ea.close()
     host_fed = None
     if rank == 0 and world == 1 and not args.no_host_fed and args.workload == "vga32" and not args.gray:
         host_fed = host_fed_rates(sd, frames_np, local, dtype)
@@ -303,7 +307,8 @@ def main():
         flops_frame = 2.0 * (arch.vgg_conv_macs(H, W) if vgg else arch.conv_macs(H, W))
         wl = ("batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
               "(BASELINE.json configs[1]; configs[2] when n_gpus=8)" +
-              ("; products as six bf16 MFMAs on exactly split fp32 operands" if dtype == "f32_split" else "")
+              ("; products as six bf16 MFMAs on exactly split fp32 operands" if dtype == "f32_split" else
+               "; products as three fp16 MFMAs on two-term split fp32 operands" if dtype == "f32_split_f16" else "")
               ) if dtype != "bf16" else (
               "batch=64 1280x960 frames per GPU, super_point checkpoint layout, bf16 activations/weights, fp32 "
               "accumulation, fp32 post-processing (BASELINE.json configs[4])")
@@ -314,14 +319,15 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": "bf16", "f32_split": "f32 (3 x bf16 split operands, 6 MFMA per product, f32 accumulate)"}[dtype],
+            "dtype": {"f32": "f32", "bf16": "bf16", "f32_split": "f32 (3 x bf16 split operands, 6 MFMA per product, f32 accumulate)",
+                      "f32_split_f16": "f32 (2 x fp16 split operands, 3 MFMA per product, f32 accumulate)"}[dtype],
             "data": "synthetic (seeded frames + seeded checkpoint in the reference's layout)",
             "config": {"workload": wl, "frames_per_step_per_gpu": BATCH, "height": H, "width": W, "input_channels": cin,
                        "parallelism": "frame-sharded x%d, no data-path collective" % world},
             "frames_per_sec_per_gpu": round(value / world, 2),
             "whole_path_tflops": round(value * flops_frame / 1e12, 3),
             "whole_path_frac_of_%s_mfma_peak" % ("f32" if dtype == "f32" else "bf16"): round(
-                value / world * flops_frame * (6.0 if dtype == "f32_split" else 1.0) / 1e12 /
+                value / world * flops_frame * {"f32_split": 6.0, "f32_split_f16": 3.0}.get(dtype, 1.0) / 1e12 /
                 (PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
             "keypoints_per_frame": round(float(np.mean(cnt)), 1),
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
@@ -352,8 +358,7 @@ def main():
                 out["layer_ms_serial"] = {k: round(float(np.mean(v)), 4) for k, v in lay.items()}
         if host_fed is not None:
             out["host_fed"] = host_fed
-        if alt is not None:
-            out["split_operand_mode" if alt["dtype"] == "f32_split" else "plain_f32_mfma_mode"] = alt
+        out.update(alt)
         if world == 1 and not args.no_cpu_baseline and vgg:
             cb = cpu_baseline_vgg_reference(sd, frames_np[:4])
             if cb is not None:

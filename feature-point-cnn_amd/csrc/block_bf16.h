@@ -45,6 +45,7 @@ struct BlockBfArgs {
   int OH, OW, oys, oxs, oy0, ox0;   // output pixel = (y*oys + oy0, x*oxs + ox0) in an OH x OW buffer
   int pad;               // halo origin = tile origin * S - pad
   int norelu;            // conv_only: 1 = no ReLU (the last 1x1 of a head of the C++ network)
+  int* range_flag;       // block_h2_kernel: set to 1 when a value that a later layer will split leaves fp16's range
 };
 
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>

@@ -179,6 +179,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+  bool bad = false;  // NP == 2: a value outside fp16's range was produced (it saturates when the next layer splits it)
 
   // ---------------------------------------------------------------- phase 1: KxK conv
   load_chunk(0);
@@ -257,6 +258,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
             const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const float v = acc[mb][nb][r] + bias;
             if (n < CMIDP) hl[m * (ROWO4 * 4) + n] = v > 0.f ? v : 0.f;
+            if (NP == 2) bad |= v > 65504.f;
             acc[mb][nb][r] = 0.f;
           }
       }
@@ -377,13 +379,14 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
         if (!a.norelu) {
           v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
         }
+        if (NP == 2) bad |= fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > 65504.f;
         const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
         *reinterpret_cast<float4*>(outp + opix * a.cso + c4 * 4) = v;
       }
     }
   }
+  if (NP == 2 && bad && a.range_flag) atomicOr(a.range_flag, 1);
 }
-
 
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
 __global__ __launch_bounds__(WM* WN * 64, 2) void block_x3_kernel(const BlockBfArgs a) {

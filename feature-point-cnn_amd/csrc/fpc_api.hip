@@ -1248,7 +1248,17 @@ postproc:
 }
 
 // ---- checkpoint -> blob -----------------------------------------------------------------
+static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, bool& range_bad);
 static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
+  bool range_bad = false;
+  const int rc = pack_all_impl(c, m, missing, range_bad);
+  if (rc == FPC_OK && range_bad) {
+    *missing = "a BatchNorm-folded weight exceeds fp16's range (|w| > 65504): FPC_F32_SPLIT_F16 cannot represent it";
+    return FPC_E_RANGE;
+  }
+  return rc;
+}
+static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, bool& range_bad) {
   std::vector<float>& blob = c->host_blob;
   blob.assign(c->blob_floats, 0.f);
   auto need = [&](const std::string& k, std::initializer_list<int64_t> shp) -> const float* {
@@ -1282,7 +1292,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
       std::vector<float> frag;
       if (op.type == OP_BF16) {
         const FKindInfo& k = g_fkinds[op.fkind];
-        frag = pack_conv_bf16({src}, co, k.WN * k.NB, k.KC, k.planes);
+        frag = pack_conv_bf16({src}, co, k.WN * k.NB, k.KC, k.planes, &range_bad);
       } else {
         frag = pack_conv({src}, co, op.args.nbt, g_kinds[op.kind].KC);
       }
@@ -1446,7 +1456,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
         PackSource s{ci, a.nchunk * k.KC, (int)taps.size(),
                      [&](int n, int cc, int t) { return (double)w[((cc * 128 + n) * 3 + taps[t].first) * 3 + taps[t].second]; },
                      &f.s};
-        std::vector<float> frag = pack_conv_bf16({s}, co, nbt, k.KC, k.planes);
+        std::vector<float> frag = pack_conv_bf16({s}, co, nbt, k.KC, k.planes, &range_bad);
         memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
         for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)((double)bct[n] * f.s[n] + f.t[n]);
         continue;
@@ -1457,7 +1467,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
       if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
         return FPC_E_MISSING_KEY;
       PackSource s1{ci, a.nchunk * k.KC, 9, [&](int n, int c_, int t) { return (double)w1[((size_t)(n * ci + c_)) * 9 + t]; }, &f1.s};
-      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC, k.planes);
+      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC, k.planes, &range_bad);
       memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
       std::vector<PackSource> srcs;
@@ -1470,7 +1480,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
         srcs.push_back({ci, a.k16_x * 16, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
         for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
       }
-      frag = pack_conv_bf16(srcs, co, nbt, 16, k.planes);
+      frag = pack_conv_bf16(srcs, co, nbt, 16, k.planes, &range_bad);
       memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
       continue;
@@ -1743,6 +1753,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         LaunchTimer t(c, (int)i, sb.st, n);
         BlockBfArgs a = op.fargs;
         a.frame0 = f0;
+        a.range_flag = c->split_f16 ? c->status + 1 : nullptr;
         g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
         break;
       }
@@ -1909,6 +1920,7 @@ const char* fpc_strerror(int code) {
     case FPC_E_MISSING_KEY: return "checkpoint entry missing or of the wrong shape (see fpc_last_hip_error)";
     case FPC_E_CAPACITY: return "caller buffer too small";
     case FPC_E_NOT_CONVERGED: return "NMS round limit hit";
+    case FPC_E_RANGE: return "value outside fp16's range in FPC_F32_SPLIT_F16 mode (use FPC_F32_SPLIT or FPC_F32)";
     default: return "unknown error";
   }
 }
@@ -2146,6 +2158,7 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
+  if (c->split_f16) HIPCHECK(hipMemsetAsync(c->status + 1, 0, sizeof(int32_t), c->stream));
   int rc = for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 0); });
   if (rc != FPC_OK) return rc;
   const int HWc = c->Hc * c->Wc;
@@ -2173,6 +2186,7 @@ int fpc_detect(fpc_ctx* c, const float* frames, int n) {
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
+  if (c->split_f16) HIPCHECK(hipMemsetAsync(c->status + 1, 0, sizeof(int32_t), c->stream));
   return for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 1); });
 }
 
@@ -2272,9 +2286,10 @@ int fpc_get_counts(fpc_ctx* c, int n, int32_t* count, int32_t* ncand) {
   if (!c || n < 1 || n > c->B) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   HIPCHECK(hipStreamSynchronize(c->stream));
-  int32_t st = 0;
-  HIPCHECK(hipMemcpy(&st, c->status, sizeof(st), hipMemcpyDeviceToHost));
-  if (st) return FPC_E_NOT_CONVERGED;
+  int32_t st[2] = {0, 0};
+  HIPCHECK(hipMemcpy(st, c->status, sizeof(st), hipMemcpyDeviceToHost));
+  if (st[0]) return FPC_E_NOT_CONVERGED;
+  if (st[1]) return FPC_E_RANGE;
   if (count) HIPCHECK(hipMemcpy(count, c->count, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   if (ncand) HIPCHECK(hipMemcpy(ncand, c->ncand, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   return FPC_OK;

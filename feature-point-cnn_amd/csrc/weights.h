@@ -173,7 +173,8 @@ inline void host_split2_f16(float x, uint16_t t[2]) {
 //   planes = 1: frag[(step * nbt + nb) * 64 + lane] = { bf16(B[step*16 + 8*half + j][nb*32 + (lane&31)]) }, j = 0..7
 //   planes = 3: frag[((step * 3 + p) * nbt + nb) * 64 + lane] = term p of the exact split of the same element
 // Returned as floats (4 per lane) so that it sits in the same blob.
-inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, int cout, int nbt, int KC, int planes = 1) {
+inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, int cout, int nbt, int KC, int planes = 1,
+                                         bool* out_of_fp16_range = nullptr) {
   const int K16 = KC / 16;
   size_t nsteps = 0;
   for (auto& s : srcs) nsteps += (size_t)(s.cin_pad / KC) * s.ntaps * K16;
@@ -193,6 +194,7 @@ inline std::vector<float> pack_conv_bf16(const std::vector<PackSource>& srcs, in
                 if (planes == 1) {
                   o16[((step * nbt + nb) * 64 + lane) * 8 + j] = host_f2bf(v);
                 } else if (planes == 2) {  // block_h2_kernel: two fp16 terms
+                  if (out_of_fp16_range && !(std::fabs(v) <= 65504.f)) *out_of_fp16_range = true;
                   uint16_t t[2];
                   host_split2_f16(v, t);
                   for (int p = 0; p < 2; ++p) o16[(((step * 2 + p) * nbt + nb) * 64 + lane) * 8 + j] = t[p];

@@ -39,7 +39,10 @@ enum {
   FPC_E_NO_WEIGHTS = -4,  /* forward/detect before any weights were loaded        */
   FPC_E_MISSING_KEY = -5, /* checkpoint entry missing or of the wrong shape       */
   FPC_E_CAPACITY = -6,    /* caller buffer too small (needed size is reported)    */
-  FPC_E_NOT_CONVERGED = -7 /* NMS round limit hit (never seen)     */
+  FPC_E_NOT_CONVERGED = -7, /* NMS round limit hit (never seen)    */
+  FPC_E_RANGE = -8        /* FPC_F32_SPLIT_F16 only: a folded weight (at load) or an */
+                          /* activation (reported by fpc_get_counts) left fp16's     */
+                          /* range |x| <= 65504; use FPC_F32_SPLIT or FPC_F32        */
 };
 
 enum { FPC_F32 = 0, FPC_BF16 = 1, FPC_F32_SPLIT = 2, FPC_F32_SPLIT_F16 = 3 };

@@ -735,3 +735,33 @@ def test_cpp_entry_point_with_the_cpp_network(torch_gpu, tmp_path):
     np.testing.assert_allclose(got[:, 3:6], d[:, 0:3], atol=1e-6)
     np.testing.assert_allclose(got[:, 7], d[:, 255], atol=1e-6)
     e.close()
+
+
+def test_fp16_split_mode_reports_values_outside_its_range(torch_gpu):
+    """dtype="f32_split_f16" splits operands into fp16 terms: a folded weight beyond 65504 is refused at load,
+    an activation beyond it is reported (FPC_E_RANGE) when the results are fetched -- never silently wrong; the
+    bf16-term mode takes the same checkpoints."""
+    from fpc_amd._lib import FpcError
+    h, w = 64, 96
+    fr = synth.make_batch(5, 1, h, w)
+    sd = synth.make_state_dict(3, dustbin_bias=2.0)
+    big_w = dict(sd)
+    big_w["encoder.layer2.1.conv1.weight"] = sd["encoder.layer2.1.conv1.weight"] * np.float32(4e6)
+    e = engine(h, w, dtype="f32_split_f16")
+    with pytest.raises(FpcError) as ei:
+        e.load_state_dict(big_w)
+    assert ei.value.code == -8
+    big_a = dict(sd)                                   # moderate weights, activations growing x600 per block
+    for k in ("encoder.layer1.0.bn2.weight", "encoder.layer1.0.identity_downsample.1.weight", "encoder.layer1.1.bn2.weight"):
+        big_a[k] = sd[k] * np.float32(600.0)
+    e.load_state_dict(big_a)
+    with pytest.raises(FpcError) as ei:
+        e.detect(fr)
+    assert ei.value.code == -8
+    e.load_state_dict(sd)                              # the flag is per call: a sane checkpoint works again
+    assert len(e.detect(fr)[0][1]) > 0
+    e.close()
+    b = engine(h, w, dtype="f32_split")                # bf16 terms carry fp32's exponent range
+    b.load_state_dict(big_a)
+    b.detect(fr)
+    b.close()
