@@ -411,13 +411,14 @@ constexpr int STEMX_LDS_BYTES = (3 * STEMX_PLANE * 2 > 256 * STEM_TROW * 4) ? 3 
 
 struct StemX3Args {
   const float* in;      // [B,CIN,H,W]
-  const uint4* wfrag;   // [steps + 2][3 planes][2 nb][64] uint4
+  const uint4* wfrag;   // [steps + 2][NP planes][2 nb][64] uint4
   const float* bias;    // [64]
   float* out;           // [B,Hp,Wp,64], zero-filled
   int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
+  int* range_flag;      // NP == 2: raised when an output leaves fp16's range
 };
 
-template <int CIN>
+template <int CIN, int NP>
 __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
   constexpr int ROWS = CIN * 7, STEPS = (ROWS + 1) / 2;  // 21 -> 11 steps; 7 -> 4
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STEMX_LDS_BYTES];
@@ -433,12 +434,12 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
   const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
 
   const uint4* wp = a.wfrag + lane;
-  uint4 bc[2][3];
+  uint4 bc[2][NP];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bc[nb][p] = wp[(p * 2 + nb) * 64];
-  wp += 6 * 64;
+    for (int p = 0; p < NP; ++p) bc[nb][p] = wp[(p * 2 + nb) * 64];
+  wp += 2 * NP * 64;
 
   {  // input window -> three bf16 planes in LDS (pad columns zero): loads first, then split + write
     constexpr int NE = CIN * STEM_HALO * STEMX_LW, IT = (NE + 255) / 256;
@@ -457,14 +458,21 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
       if (e < NE) {
-        const unsigned u = __float_as_uint(v[i]);
-        const unsigned hi = u & 0xffff0000u;
-        const float r = v[i] - __uint_as_float(hi);
-        const unsigned mi = __float_as_uint(r) & 0xffff0000u;
-        const float q = r - __uint_as_float(mi);
-        lds16[e] = (unsigned short)(hi >> 16);
-        lds16[STEMX_PLANE + e] = (unsigned short)(mi >> 16);
-        lds16[2 * STEMX_PLANE + e] = (unsigned short)(__float_as_uint(q) >> 16);
+        if constexpr (NP == 3) {
+          const unsigned u = __float_as_uint(v[i]);
+          const unsigned hi = u & 0xffff0000u;
+          const float r = v[i] - __uint_as_float(hi);
+          const unsigned mi = __float_as_uint(r) & 0xffff0000u;
+          const float q = r - __uint_as_float(mi);
+          lds16[e] = (unsigned short)(hi >> 16);
+          lds16[STEMX_PLANE + e] = (unsigned short)(mi >> 16);
+          lds16[2 * STEMX_PLANE + e] = (unsigned short)(__float_as_uint(q) >> 16);
+        } else {  // two fp16 terms (frame values lie in [0, 1]; clamped like every other operand)
+          const _Float16 hh = (_Float16)__builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
+          const _Float16 ll = (_Float16)__builtin_amdgcn_fmed3f(v[i] - (float)hh, -65504.f, 65504.f);
+          lds16[e] = __builtin_bit_cast(unsigned short, hh);
+          lds16[STEMX_PLANE + e] = __builtin_bit_cast(unsigned short, ll);
+        }
       }
     }
   }
@@ -486,33 +494,33 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
 
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    uint4 bn[2][3];
+    uint4 bn[2][NP];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bn[nb][p] = wp[(p * 2 + nb) * 64];
-    wp += 6 * 64;
+      for (int p = 0; p < NP; ++p) bn[nb][p] = wp[(p * 2 + nb) * 64];
+    wp += 2 * NP * 64;
     __builtin_amdgcn_sched_barrier(0);
     // this lane's filter row: (c, ky); a padded row (weights zero) re-reads the last real one
     const int r0 = 2 * s < ROWS ? 2 * s : ROWS - 1, r1 = 2 * s + 1 < ROWS ? 2 * s + 1 : ROWS - 1;
     const int off0 = ((r0 / 7) * STEM_HALO + (r0 % 7)) * (STEMX_LW / 2), off1 = ((r1 / 7) * STEM_HALO + (r1 % 7)) * (STEMX_LW / 2);
     const int off = half ? off1 : off0;
-    uint4 av[2][3];
+    uint4 av[2][NP];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const unsigned* q = lds32 + p * (STEMX_PLANE / 2) + abase[mb] + off;
         av[mb][p] = make_uint4(q[0], q[1], q[2], q[3]);
       }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) FPC_X3_MFMA(acc[mb][nb], av[mb], bc[nb]);
+      for (int nb = 0; nb < 2; ++nb) mfma_split<NP>(acc[mb][nb], av[mb], bc[nb]);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bc[nb][p] = bn[nb][p];
+      for (int p = 0; p < NP; ++p) bc[nb][p] = bn[nb][p];
   }
 
   // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool (as stem_pool_kernel)
@@ -548,6 +556,7 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
         }
       }
       if (mx < 0.f) continue;
+      if (NP == 2 && mx > 65504.f && a.range_flag) atomicOr(a.range_flag, 1);
       float* dst = a.out + ((size_t)(b * a.Hp + gpy) * a.Wp + gpx) * 64 + nb * 32 + c;
       if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
         *dst = mx;

@@ -1058,7 +1058,7 @@ static int build_plan(fpc_ctx* c) {
     op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;  // of the reference's 3-channel convolution, also for gray frames
     op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
     if (c->split || c->bf16)  // stem_pool_x3_kernel: (rows + 1) / 2 K16 steps of six bf16 MFMAs
-      op.mfma_flops_per_frame = 6 * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
+      op.mfma_flops_per_frame = (c->split_f16 ? 3 : 6) * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
     c->ops.push_back(op);
     c->convw.push_back({});
     c->stem_w_off = bo;
@@ -1321,9 +1321,17 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
                 if (c->cin == 3) v = (double)w[n * 147 + k];
                 else v = (double)w[n * 147 + k] + (double)w[n * 147 + 49 + k] + (double)w[n * 147 + 98 + k];
               }
-              uint16_t t3[3];
-              host_split3((float)(v * f.s[n]), t3);
-              for (int pl = 0; pl < 3; ++pl) d16[((((size_t)st * 3 + pl) * 2 + nb) * 64 + lane) * 8 + j] = t3[pl];
+              const float wv = (float)(v * f.s[n]);
+              if (c->split_f16) {
+                if (!(std::fabs(wv) <= 65504.f)) range_bad = true;
+                uint16_t t2[2];
+                host_split2_f16(wv, t2);
+                for (int pl = 0; pl < 2; ++pl) d16[((((size_t)st * 2 + pl) * 2 + nb) * 64 + lane) * 8 + j] = t2[pl];
+              } else {
+                uint16_t t3[3];
+                host_split3(wv, t3);
+                for (int pl = 0; pl < 3; ++pl) d16[((((size_t)st * 3 + pl) * 2 + nb) * 64 + lane) * 8 + j] = t3[pl];
+              }
             }
     } else
     for (int g = 0; g < kg; ++g)
@@ -1684,10 +1692,15 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             StemX3Args x{};
             x.in = a.in; x.wfrag = reinterpret_cast<const uint4*>(a.wfrag); x.bias = a.bias; x.out = a.out;
             x.H = H; x.W = W; x.Ho = a.Ho; x.Wo = a.Wo; x.Hp = a.Hp; x.Wp = a.Wp; x.tiles_x = a.tiles_x; x.tiles_y = a.tiles_y;
-            if (c->cin == 1)
-              hipLaunchKernelGGL(stem_pool_x3_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, x);
-            else
-              hipLaunchKernelGGL(stem_pool_x3_kernel<3>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, x);
+            x.range_flag = c->split_f16 ? c->status + 1 : nullptr;
+            const dim3 grid(a.tiles_x * a.tiles_y * n);
+            if (c->split_f16) {
+              if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 2>), grid, dim3(256), 0, sb.st, x);
+              else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 2>), grid, dim3(256), 0, sb.st, x);
+            } else {
+              if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 3>), grid, dim3(256), 0, sb.st, x);
+              else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 3>), grid, dim3(256), 0, sb.st, x);
+            }
           } else if (c->cin == 1)
             hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
           else
