@@ -199,31 +199,17 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
 #pragma unroll
       for (int k = 0; k < K16; ++k) {
         uint4 bn[NB][NP];
-#ifdef FPC_X3_NOB
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) { bn[nb][p] = bc[nb][p]; asm volatile("" : "+v"(bn[nb][p].x)); }
-#else
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
           for (int p = 0; p < NP; ++p) bn[nb][p] = wp[p * planestride + nb * 64];
-#endif
         wp += stepstride;
         __builtin_amdgcn_sched_barrier(0);
         uint4 av[MB][NP];
-#ifdef FPC_X3_NOA
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) { av[mb][p] = make_uint4(toff + k, tid, p, mb); asm volatile("" : "+v"(av[mb][p].x)); }
-#else
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int p = 0; p < NP; ++p) av[mb][p] = lds16[p * PLANE16 + abase[mb] + toff + k * 2];
-#endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
