@@ -83,7 +83,9 @@ __device__ __forceinline__ Split3 split8(const float4& a, const float4& b) { ret
 // acc += a * b on split operands: NP = 3 six bf16 MFMAs, NP = 2 three fp16 MFMAs (small terms first)
 template <int NP>
 __device__ __forceinline__ void mfma_split(f32x16& acc, const uint4* A, const uint4* B) {
-  if constexpr (NP == 3) {
+  if constexpr (NP == 1) {  // plain bf16 operands (FPC_BF16's stem)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0]), __builtin_bit_cast(bf16x8, B[0]), acc, 0, 0, 0);
+  } else if constexpr (NP == 3) {
     FPC_X3_MFMA(acc, A, B);
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[1]), __builtin_bit_cast(f16x8, B[0]), acc, 0, 0, 0);
@@ -444,7 +446,9 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
       if (e < NE) {
-        if constexpr (NP == 3) {
+        if constexpr (NP == 1) {
+          lds16[e] = f2bf(v[i]);
+        } else if constexpr (NP == 3) {
           const unsigned u = __float_as_uint(v[i]);
           const unsigned hi = u & 0xffff0000u;
           const float r = v[i] - __uint_as_float(hi);

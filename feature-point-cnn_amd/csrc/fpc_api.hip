@@ -1058,7 +1058,7 @@ static int build_plan(fpc_ctx* c) {
     op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;  // of the reference's 3-channel convolution, also for gray frames
     op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
     if (c->split || c->bf16)  // stem_pool_x3_kernel: (rows + 1) / 2 K16 steps of six bf16 MFMAs
-      op.mfma_flops_per_frame = (c->split_f16 ? 3 : 6) * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
+      op.mfma_flops_per_frame = (c->bf16 ? 1 : c->split_f16 ? 3 : 6) * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
     c->ops.push_back(op);
     c->convw.push_back({});
     c->stem_w_off = bo;
@@ -1322,7 +1322,9 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
                 else v = (double)w[n * 147 + k] + (double)w[n * 147 + 49 + k] + (double)w[n * 147 + 98 + k];
               }
               const float wv = (float)(v * f.s[n]);
-              if (c->split_f16) {
+              if (c->bf16) {
+                d16[(((size_t)st * 2 + nb) * 64 + lane) * 8 + j] = host_f2bf(wv);
+              } else if (c->split_f16) {
                 if (!(std::fabs(wv) <= 65504.f)) range_bad = true;
                 uint16_t t2[2];
                 host_split2_f16(wv, t2);
@@ -1697,6 +1699,9 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             if (c->split_f16) {
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 2>), grid, dim3(256), 0, sb.st, x);
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 2>), grid, dim3(256), 0, sb.st, x);
+            } else if (c->bf16) {  // bf16 mode: bf16 operands like every other layer of the mode
+              if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 1>), grid, dim3(256), 0, sb.st, x);
+              else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 1>), grid, dim3(256), 0, sb.st, x);
             } else {
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 3>), grid, dim3(256), 0, sb.st, x);
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 3>), grid, dim3(256), 0, sb.st, x);
