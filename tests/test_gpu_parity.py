@@ -703,6 +703,17 @@ def test_vgg_batch_and_matching(torch_gpu):
     om, od = oracle.match(q, t, True)
     np.testing.assert_array_equal(m, om)
     e.close()
+    # detector only (descriptor head skipped) and 8-bit gray input give the same keypoints
+    m = engine(h, w, 1, in_channels=1, arch="vgg", descriptor_enabled=False)
+    m.load_state_dict(sd)
+    xy, conf, d, _ = m.detect(fr[:1])[0]
+    assert d is None
+    np.testing.assert_array_equal(xy, res[0][0])
+    u8 = np.clip(np.rint(fr[:1, 0] * 255.0), 0, 255).astype(np.uint8)
+    a = m.detect_u8(u8, "gray")[0]
+    b = m.detect(oracle.u8_to_float(u8, 0))[0]
+    np.testing.assert_array_equal(a[0], b[0])
+    m.close()
     with pytest.raises(Exception):
         engine(h, w, 1, in_channels=3, arch="vgg")        # the C++ network takes one gray plane
 
