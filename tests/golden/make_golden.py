@@ -222,6 +222,39 @@ def golden_end_to_end():
               "thresh margin %.3g" % thr_margin, "NaN desc:", int(np.isnan(desc).sum()))
 
 
+def golden_get_points_random():
+    """F3b: get_points (netutils.py:78-100 -> nms.py:4-53) on 48 random tie-free maps of varying size and
+    density AND varying settings (nms_dist 1..6, border_remove 0..6, confidence_thresh): pins the oracle's
+    handling of the parameters, which F3 (reference defaults only) does not."""
+    cases = {}
+    rng = np.random.Generator(np.random.PCG64(2024))
+    for i in range(48):
+        h, w = int(rng.choice([24, 32, 40, 48, 64])), int(rng.choice([32, 40, 56, 64, 80]))
+        dens = float(rng.choice([0.01, 0.05, 0.2, 0.5, 1.0]))
+        n = max(1, int(dens * h * w))
+        settings = SuperPointSettings()
+        if i >= 8:                                   # the first 8 keep the reference's defaults
+            settings.nms_dist = int(rng.integers(1, 7))
+            settings.border_remove = int(rng.integers(0, 7))
+            settings.confidence_thresh = float(rng.choice([0.015, 0.05, 0.3]))
+        idx = rng.choice(h * w, n, replace=False)
+        vals = (0.001 + 0.99 * (rng.permutation(n) + rng.uniform(0.1, 0.9)) / n).astype(np.float32)
+        assert len(np.unique(vals)) == n             # tie-free: the reference's order is then defined
+        pm = np.zeros((1, h, w), np.float32)
+        pm[0].ravel()[idx] = vals
+        res = np.asarray(get_points(torch.from_numpy(pm), h, w, settings), dtype=np.float64)
+        k = "c%02d" % i
+        cases[k + "_hw"] = np.array([h, w], np.int32)
+        cases[k + "_par"] = np.array([settings.nms_dist, settings.border_remove], np.int32)
+        cases[k + "_thr"] = np.float32(settings.confidence_thresh)
+        cases[k + "_idx"] = idx.astype(np.int32)
+        cases[k + "_val"] = vals
+        cases[k + "_out"] = res.astype(np.float32) if res.size else np.zeros((3, 0), np.float32)
+    np.savez_compressed(os.path.join(HERE, "f3b_get_points_random.npz"), **cases)
+    print("F3b random get_points cases: 48, kept per case",
+          [int(cases["c%02d_out" % i].shape[1]) for i in range(48)])
+
+
 def golden_u8():
     """F6: the reference's 8-bit -> float conversion, evaluated by the libraries the reference calls, for all
     256 byte values: `frame.astype('float32') / 255.0` (python/src/camera.py:31; dataset_utils.py:23 is the
@@ -245,11 +278,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         golden_u8()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "f3b":
+        golden_get_points_random()
+        sys.exit(0)
     golden_layers()
     golden_restore()
     golden_get_points()
     golden_get_descriptors()
     golden_end_to_end()
     golden_u8()
+    golden_get_points_random()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

@@ -776,3 +776,23 @@ def test_fp16_split_mode_reports_values_outside_its_range(torch_gpu):
     b.load_state_dict(big_a)
     b.detect(fr)
     b.close()
+
+
+def test_f3b_random_maps_and_settings_on_gpu(torch_gpu, golden_dir):
+    """Fixture F3b (the reference's get_points on 48 random maps with varying nms_dist / border_remove /
+    confidence_thresh) through fpc_get_points: indices and confidence bits identical to the reference's."""
+    g = np.load(os.path.join(golden_dir, "f3b_get_points_random.npz"))
+    for i in range(48):
+        k = "c%02d" % i
+        h, w = [int(v) for v in g[k + "_hw"]]
+        pm = np.zeros(h * w, np.float32)
+        pm[g[k + "_idx"]] = g[k + "_val"]
+        ref = g[k + "_out"]
+        e = engine(h, w, 1, descriptor_enabled=False, nms_dist=int(g[k + "_par"][0]), border_remove=int(g[k + "_par"][1]),
+                   conf_thresh=float(g[k + "_thr"]))
+        xy, conf, d, _ = e.get_points(torch_gpu.from_numpy(pm.reshape(1, h, w)))[0]
+        assert len(conf) == ref.shape[1], k
+        np.testing.assert_array_equal(xy[:, 0], ref[0].astype(np.int32), err_msg=k)
+        np.testing.assert_array_equal(xy[:, 1], ref[1].astype(np.int32), err_msg=k)
+        np.testing.assert_array_equal(conf, ref[2].astype(np.float32), err_msg=k)
+        e.close()

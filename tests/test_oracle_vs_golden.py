@@ -182,3 +182,27 @@ def test_vgg_oracle_against_live_reference_binary(golden_dir):
     prob, desc, logits = oracle.vgg_forward(fr, sd, arch.vgg_state_dict_spec())
     np.testing.assert_allclose(logits, point, rtol=0, atol=2e-5)
     np.testing.assert_allclose(desc, dref, rtol=0, atol=2e-6)
+
+
+def _f3b_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "f3b_get_points_random.npz"))
+    for i in range(48):
+        k = "c%02d" % i
+        h, w = [int(v) for v in g[k + "_hw"]]
+        pm = np.zeros(h * w, np.float32)
+        pm[g[k + "_idx"]] = g[k + "_val"]
+        yield k, pm.reshape(h, w), int(g[k + "_par"][0]), int(g[k + "_par"][1]), float(g[k + "_thr"]), g[k + "_out"]
+
+
+def test_f3b_get_points_random_maps_and_settings(golden_dir):
+    """48 random tie-free maps through the reference's get_points with varying nms_dist / border_remove /
+    confidence_thresh (fixture F3b): indices and confidences exact."""
+    n = 0
+    for k, pm, nms, border, thr, ref in _f3b_cases(golden_dir):
+        xs, ys, conf, _ = oracle.get_points(pm, conf_thresh=thr, nms_dist=nms, border_remove=border)
+        assert len(xs) == ref.shape[1], k
+        np.testing.assert_array_equal(xs, ref[0].astype(np.int32), err_msg=k)
+        np.testing.assert_array_equal(ys, ref[1].astype(np.int32), err_msg=k)
+        np.testing.assert_array_equal(conf, ref[2].astype(np.float32), err_msg=k)
+        n += 1
+    assert n == 48
