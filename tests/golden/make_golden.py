@@ -188,6 +188,29 @@ def golden_get_descriptors():
     print("F4 get_descriptors", out.shape)
 
 
+def golden_get_descriptors_random():
+    """F4b: get_descriptors (netutils.py:103-121) at the real descriptor length (128) and other geometries:
+    wide / tall / HD-like aspect ratios, every pixel of one row and one column, signed map values."""
+    settings = SuperPointSettings()
+    rng = np.random.Generator(np.random.PCG64(91))
+    cases = {}
+    for i, (hc, wc) in enumerate([(6, 8), (3, 40), (30, 4), (15, 20), (12, 16)]):
+        h, w = hc * 8, wc * 8
+        dm = rng.normal(0.0, 1.0, (1, 128, hc, wc)).astype(np.float32)
+        n = 60
+        xs = np.concatenate([rng.integers(0, w, n), np.arange(0, w, max(1, w // 16)), np.full(8, w - 1)])
+        ys = np.concatenate([rng.integers(0, h, n), np.full(len(np.arange(0, w, max(1, w // 16))), h // 2),
+                             np.linspace(0, h - 1, 8).astype(np.int64)])
+        pts = np.stack([xs.astype(np.float64), ys.astype(np.float64), np.linspace(0.9, 0.1, len(xs))])
+        out = get_descriptors(pts, torch.from_numpy(dm), h, w, settings)
+        cases["c%d_map" % i] = dm
+        cases["c%d_pts" % i] = pts[:2].astype(np.int32)
+        cases["c%d_out" % i] = out.astype(np.float32)
+        cases["c%d_hw" % i] = np.array([h, w], np.int32)
+    np.savez_compressed(os.path.join(HERE, "f4b_get_descriptors_random.npz"), **cases)
+    print("F4b get_descriptors cases: 5")
+
+
 def golden_end_to_end():
     """F5: full path on whole frames: keypoints, confidences, a descriptor subset and
     strided probes of the dense maps."""
@@ -278,6 +301,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         golden_u8()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "f4b":
+        golden_get_descriptors_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f3b":
         golden_get_points_random()
         sys.exit(0)
@@ -288,5 +314,6 @@ if __name__ == "__main__":
     golden_end_to_end()
     golden_u8()
     golden_get_points_random()
+    golden_get_descriptors_random()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

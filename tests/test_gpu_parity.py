@@ -796,3 +796,26 @@ def test_f3b_random_maps_and_settings_on_gpu(torch_gpu, golden_dir):
         np.testing.assert_array_equal(xy[:, 1], ref[1].astype(np.int32), err_msg=k)
         np.testing.assert_array_equal(conf, ref[2].astype(np.float32), err_msg=k)
         e.close()
+
+
+def test_f4b_descriptor_sampling_geometries_on_gpu(torch_gpu, golden_dir):
+    """Fixture F4b through fpc_get_points' descriptor sampling: the reference's get_descriptors on wide / tall maps.
+    The keypoints are planted in a probability map (distinct confidences, NMS off) so that the kernel samples
+    exactly the fixture's points."""
+    g = np.load(os.path.join(golden_dir, "f4b_get_descriptors_random.npz"))
+    for i in range(5):
+        h, w = [int(v) for v in g["c%d_hw" % i]]
+        if h % 16 or w % 16:
+            continue        # a full ctx needs multiples of 16 (descriptor head); the oracle test covers these cases
+        pts, ref = g["c%d_pts" % i], g["c%d_out" % i]
+        flat = pts[1].astype(np.int64) * w + pts[0]
+        uniq, first = np.unique(flat, return_index=True)          # a pixel can only be one keypoint
+        pm = np.zeros(h * w, np.float32)
+        pm[uniq] = np.linspace(0.9, 0.1, len(uniq)).astype(np.float32)
+        e = engine(h, w, 1, nms_dist=0, border_remove=0, conf_thresh=0.05)
+        xy, conf, d, _ = e.get_points(torch_gpu.from_numpy(pm.reshape(1, h, w)), torch_gpu.from_numpy(g["c%d_map" % i]))[0]
+        assert len(conf) == len(uniq)
+        col = {int(f): int(j) for f, j in zip(uniq, first)}
+        want = np.stack([ref[:, col[int(y) * w + int(x)]] for x, y in xy])
+        np.testing.assert_allclose(d, want, rtol=0, atol=2e-6)
+        e.close()

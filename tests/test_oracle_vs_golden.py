@@ -206,3 +206,13 @@ def test_f3b_get_points_random_maps_and_settings(golden_dir):
         np.testing.assert_array_equal(conf, ref[2].astype(np.float32), err_msg=k)
         n += 1
     assert n == 48
+
+
+def test_f4b_get_descriptors_geometries(golden_dir):
+    """Fixture F4b: the reference's get_descriptors at D = 128 on wide / tall / HD-like maps."""
+    g = np.load(os.path.join(golden_dir, "f4b_get_descriptors_random.npz"))
+    for i in range(5):
+        h, w = [int(v) for v in g["c%d_hw" % i]]
+        pts = g["c%d_pts" % i]
+        out = oracle.get_descriptors(g["c%d_map" % i][0], pts[0], pts[1], h, w)
+        np.testing.assert_allclose(out.T, g["c%d_out" % i], rtol=0, atol=2e-6)
