@@ -302,6 +302,7 @@ struct fpc_ctx {
   int num_cus = 256;
   int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
   int nms_passes = 2;
+  int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
 #ifdef FPC_DIAG
   unsigned long long* diag_stamps = nullptr;
@@ -1843,7 +1844,7 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
   // enough workgroups that a typical frame (a few thousand candidates) has about one candidate
   // per thread; a few launches back to back (each runs rounds while it makes progress), then the
   // sort kernel finishes whatever is left
-  const int G = std::max(1, std::min(32, 512 / n));
+  const int G = c->nms_g > 0 ? c->nms_g : std::max(1, std::min(16, 512 / n));
   for (int pass = 0; pass < c->nms_passes; ++pass) {
     if (c->cfg.nms_dist == 4)
       hipLaunchKernelGGL(nms_rounds_kernel<4>, dim3(G, n), dim3(NMS_ROUNDS_THREADS), 0, sb.st, a);
@@ -2019,6 +2020,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_WINOGRAD_IN1")) c->winograd_in1 = atoi(e) != 0;
     if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
+    if (const char* e = getenv("FPC_NMS_G")) c->nms_g = std::max(0, std::min(64, atoi(e)));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < nsub; ++i) {
       hipStream_t st;
