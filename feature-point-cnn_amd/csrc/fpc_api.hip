@@ -296,7 +296,7 @@ struct fpc_ctx {
   std::vector<hipEvent_t> ev_join;
   std::vector<hipStream_t> side;     // per sub-batch: detector head + NMS next to the descriptor head
   std::vector<hipEvent_t> ev_enc, ev_det;
-  bool split_heads = true;           // FPC_SPLIT_HEADS=0: one stream per sub-batch
+  bool split_heads = false;          // FPC_SPLIT_HEADS=1: detector head + NMS of a sub-batch on a side stream next to its descriptor head
   hipEvent_t ev_fork = nullptr;
   int min_sub = 4;                   // smallest sub-batch worth its own stream
   int num_cus = 256;
@@ -2011,7 +2011,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
   {
-    int nsub = 2;
+    int nsub = c->split ? 3 : 2;   // measured: 2 sub-batches for the fp32-MFMA kernels, 3 for the (shorter) split-operand ones
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
