@@ -404,6 +404,9 @@ struct StemX3Args {
   float* out;           // [B,Hp,Wp,64], zero-filled
   int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
   int* range_flag;      // NP == 2: raised when an output leaves fp16's range
+#ifdef FPC_DIAG
+  unsigned long long* stamps;
+#endif
 };
 
 template <int CIN, int NP>
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
 
+  FPC_STAMP(0)
   const uint4* wp = a.wfrag + lane;
   uint4 bc[2][NP];
 #pragma unroll
@@ -467,6 +471,7 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
     }
   }
   __syncthreads();
+  FPC_STAMP(1)
 
   int abase[2];  // dword index of (row 0, 2*px) of this lane's output pixel
 #pragma unroll
@@ -513,9 +518,8 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
       for (int p = 0; p < NP; ++p) bc[nb][p] = bn[nb][p];
   }
 
+  FPC_STAMP(2)
   // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool (as stem_pool_kernel)
-  const int gy0 = ty * STEM_T, gx0 = tx * STEM_T;
-  const int c = tid & 31;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     __syncthreads();
@@ -529,30 +533,9 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
         lds[m * STEM_TROW + l31] = v > 0.f ? v : 0.f;
       }
     __syncthreads();
-    for (int p = tid >> 5; p < 81; p += 8) {
-      const int py = p / 9, px = p - py * 9;
-      const int gpy = ty * 8 + py, gpx = tx * 8 + px;
-      if (gpy >= a.Hp || gpx >= a.Wp) continue;
-      float mx = -1.f;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int rr = 2 * py - 1 + dy;
-        if (rr < 0 || rr > 15 || gy0 + rr >= a.Ho) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int cc = 2 * px - 1 + dx;
-          if (cc < 0 || cc > 15 || gx0 + cc >= a.Wo) continue;
-          mx = fmaxf(mx, lds[(rr * STEM_T + cc) * STEM_TROW + c]);
-        }
-      }
-      if (mx < 0.f) continue;
-      if (NP == 2 && mx > 65504.f && a.range_flag) atomicOr(a.range_flag, 1);
-      float* dst = a.out + ((size_t)(b * a.Hp + gpy) * a.Wp + gpx) * 64 + nb * 32 + c;
-      if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
-        *dst = mx;
-      else
-        atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
-    }
+    if (nb == 0) { FPC_STAMP(3) } else { FPC_STAMP(5) }
+    stem_pool_emit(lds, a.out, b, ty, tx, nb, a.Ho, a.Wo, a.Hp, a.Wp, tid, NP == 2 ? a.range_flag : nullptr);
+    if (nb == 0) { FPC_STAMP(4) } else { FPC_STAMP(6) }
   }
 }
 

@@ -1696,6 +1696,16 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             x.in = a.in; x.wfrag = reinterpret_cast<const uint4*>(a.wfrag); x.bias = a.bias; x.out = a.out;
             x.H = H; x.W = W; x.Ho = a.Ho; x.Wo = a.Wo; x.Hp = a.Hp; x.Wp = a.Wp; x.tiles_x = a.tiles_x; x.tiles_y = a.tiles_y;
             x.range_flag = c->split_f16 ? c->status + 1 : nullptr;
+#ifdef FPC_DIAG
+            x.stamps = nullptr;
+            if (const char* e = getenv("FPC_STAMP_OP"))
+              if (op.name.find(e) != std::string::npos) {
+                if (!c->diag_stamps) hipHostMalloc((void**)&c->diag_stamps, (size_t)65536 * 8 * sizeof(unsigned long long));
+                memset(c->diag_stamps, 0, (size_t)65536 * 8 * sizeof(unsigned long long));
+                x.stamps = c->diag_stamps;
+                c->diag_n = a.tiles_x * a.tiles_y * n;
+              }
+#endif
             const dim3 grid(a.tiles_x * a.tiles_y * n);
             if (c->split_f16) {
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 2>), grid, dim3(256), 0, sb.st, x);

@@ -133,6 +133,52 @@ __device__ __forceinline__ constexpr int stem_koff_c(int k) {
   return (k / 49) * (STEM_HALO * STEM_LW) + ((k % 49) / 7) * STEM_LW + (k % 7);
 }
 
+// MaxPool2d(3, stride 2, padding 1) of one 32-channel half of the 16x16 conv tile held in LDS
+// (lds[(row * 16 + col) * STEM_TROW + channel], post-ReLU so every value is >= 0).  Thread (c = tid & 31,
+// j = tid >> 5) owns pooled row j of the tile for its channel: it reads the three conv rows once (48 LDS reads),
+// reduces them to 16 column maxima and emits the 9 window maxima of the row from registers -- straight-line code
+// with compile-time column indices.  Pooled row 8 (conv row 15 only; the rest of its windows belongs to the tile
+// below) is done by group j == 0.  Windows that straddle tiles are completed with atomicMax on the float bits.
+__device__ __forceinline__ void stem_pool_emit(const float* lds, float* out, int b, int ty, int tx, int nb, int Ho, int Wo,
+                                               int Hp, int Wp, int tid, int* range_flag) {
+  const int c = tid & 31, j = tid >> 5;
+  const int gy0 = ty * STEM_T, gx0 = tx * STEM_T;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int py = pass == 0 ? j : 8;
+    if (pass == 1 && j != 0) break;
+    const int gpy = ty * 8 + py;
+    if (gpy >= Hp) continue;
+    float cm[STEM_T];
+#pragma unroll
+    for (int cc = 0; cc < STEM_T; ++cc) cm[cc] = -1.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int rr = 2 * py - 1 + dy;
+      if (rr < 0 || rr > STEM_T - 1 || gy0 + rr >= Ho) continue;
+#pragma unroll
+      for (int cc = 0; cc < STEM_T; ++cc) cm[cc] = fmaxf(cm[cc], lds[(rr * STEM_T + cc) * STEM_TROW + c]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < STEM_T; ++cc)
+      if (gx0 + cc >= Wo) cm[cc] = -1.f;  // conv columns beyond the image
+    float* row = out + ((size_t)(b * Hp + gpy) * Wp + tx * 8) * 64 + nb * 32 + c;
+#pragma unroll
+    for (int px = 0; px < 9; ++px) {
+      if (tx * 8 + px >= Wp) continue;
+      float mx = px < 8 ? cm[2 * px] : -1.f;
+      if (px > 0) mx = fmaxf(mx, cm[2 * px - 1]);
+      if (px < 8) mx = fmaxf(mx, cm[2 * px + 1]);
+      if (mx < 0.f) continue;  // no pixel of this window lies in this tile
+      if (range_flag && mx > 65504.f) atomicOr(range_flag, 1);
+      if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
+        row[px * 64] = mx;  // whole window inside this tile
+      else
+        atomicMax(reinterpret_cast<unsigned int*>(row + px * 64), __float_as_uint(mx));
+    }
+  }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   constexpr int KREAL = CIN * 49, KG = (KREAL + 7) / 8;  // 147 -> 19 groups of 8; 49 -> 7
@@ -217,8 +263,6 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   }
 
   // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool
-  const int gy0 = ty * STEM_T, gx0 = tx * STEM_T;       // conv-output origin of the tile
-  const int c = tid & 31;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     __syncthreads();  // nb == 0: halo reads done; nb == 1: previous half's pooling reads done
@@ -232,29 +276,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
         lds[m * STEM_TROW + l31] = v > 0.f ? v : 0.f;
       }
     __syncthreads();
-    for (int p = tid >> 5; p < 81; p += 8) {  // 9 x 9 pooled positions touched by this tile
-      const int py = p / 9, px = p - py * 9;
-      const int gpy = ty * 8 + py, gpx = tx * 8 + px;
-      if (gpy >= a.Hp || gpx >= a.Wp) continue;
-      float mx = -1.f;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int rr = 2 * py - 1 + dy;
-        if (rr < 0 || rr > 15 || gy0 + rr >= a.Ho) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int cc = 2 * px - 1 + dx;
-          if (cc < 0 || cc > 15 || gx0 + cc >= a.Wo) continue;
-          mx = fmaxf(mx, lds[(rr * STEM_T + cc) * STEM_TROW + c]);
-        }
-      }
-      if (mx < 0.f) continue;  // no pixel of this window lies in this tile
-      float* dst = a.out + ((size_t)(b * a.Hp + gpy) * a.Wp + gpx) * 64 + nb * 32 + c;
-      if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
-        *dst = mx;  // whole window inside this tile
-      else
-        atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
-    }
+    stem_pool_emit(lds, a.out, b, ty, tx, nb, a.Ho, a.Wo, a.Hp, a.Wp, tid, nullptr);
   }
 }
 
