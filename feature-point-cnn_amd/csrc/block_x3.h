@@ -413,7 +413,6 @@ template <int CIN, int NP>
 __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
   constexpr int ROWS = CIN * 7, STEPS = (ROWS + 1) / 2;  // 21 -> 11 steps; 7 -> 4
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STEMX_LDS_BYTES];
-  unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds_raw);
   const unsigned* lds32 = reinterpret_cast<const unsigned*>(lds_raw);
   float* lds = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -433,40 +432,51 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
     for (int p = 0; p < NP; ++p) bc[nb][p] = wp[(p * 2 + nb) * 64];
   wp += 2 * NP * 64;
 
-  {  // input window -> three bf16 planes in LDS (pad columns zero): loads first, then split + write
-    constexpr int NE = CIN * STEM_HALO * STEMX_LW, IT = (NE + 255) / 256;
-    float v[IT];
+  {  // input window -> NP sixteen-bit planes in LDS, as aligned float4 row segments: LDS column 0 is image column
+     // ix0 - 1 (= 32 tx - 4; W is a multiple of 8, so a float4 is entirely inside or outside the frame); the 8 K-values
+     // of a lane then start at the even column 2 px with the zero-weight pad in FRONT (kx' = kx + 1).
+    constexpr int NQ = STEMX_LW / 4, NE = CIN * STEM_HALO * NQ, IT = (NE + 255) / 256;
+    float4 v[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
-      const int row = e / STEMX_LW, hx = e - row * STEMX_LW;
+      const int row = e / NQ, q = e - row * NQ;
       const int c = row / STEM_HALO, hy = row - c * STEM_HALO;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = e < NE && hx < STEM_HALO && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float x = a.in[ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0];
-      v[i] = ok ? x : 0.f;
+      const int iy = iy0 + hy, ix = ix0 - 1 + 4 * q;
+      const bool ok = e < NE && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float4 x = *reinterpret_cast<const float4*>(a.in + (ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0));
+      v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    uint2* lds64 = reinterpret_cast<uint2*>(lds_raw);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
       if (e < NE) {
-        if constexpr (NP == 1) {
-          lds16[e] = f2bf(v[i]);
-        } else if constexpr (NP == 3) {
-          const unsigned u = __float_as_uint(v[i]);
-          const unsigned hi = u & 0xffff0000u;
-          const float r = v[i] - __uint_as_float(hi);
-          const unsigned mi = __float_as_uint(r) & 0xffff0000u;
-          const float q = r - __uint_as_float(mi);
-          lds16[e] = (unsigned short)(hi >> 16);
-          lds16[STEMX_PLANE + e] = (unsigned short)(mi >> 16);
-          lds16[2 * STEMX_PLANE + e] = (unsigned short)(__float_as_uint(q) >> 16);
-        } else {  // two fp16 terms (frame values lie in [0, 1]; clamped like every other operand)
-          const _Float16 hh = (_Float16)__builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
-          const _Float16 ll = (_Float16)__builtin_amdgcn_fmed3f(v[i] - (float)hh, -65504.f, 65504.f);
-          lds16[e] = __builtin_bit_cast(unsigned short, hh);
-          lds16[STEMX_PLANE + e] = __builtin_bit_cast(unsigned short, ll);
+        const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        unsigned short t[NP][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if constexpr (NP == 1) {
+            t[0][k] = f2bf(f[k]);
+          } else if constexpr (NP == 3) {
+            const unsigned u = __float_as_uint(f[k]);
+            const unsigned hi = u & 0xffff0000u;
+            const float r = f[k] - __uint_as_float(hi);
+            const unsigned mi = __float_as_uint(r) & 0xffff0000u;
+            const float qq = r - __uint_as_float(mi);
+            t[0][k] = (unsigned short)(hi >> 16);
+            t[1][k] = (unsigned short)(mi >> 16);
+            t[NP - 1][k] = (unsigned short)(__float_as_uint(qq) >> 16);
+          } else {  // two fp16 terms (frame values lie in [0, 1]; clamped like every other operand)
+            const _Float16 hh = (_Float16)__builtin_amdgcn_fmed3f(f[k], -65504.f, 65504.f);
+            const _Float16 ll = (_Float16)__builtin_amdgcn_fmed3f(f[k] - (float)hh, -65504.f, 65504.f);
+            t[0][k] = __builtin_bit_cast(unsigned short, hh);
+            t[NP - 1][k] = __builtin_bit_cast(unsigned short, ll);
+          }
         }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)  // element e * 4 of plane p = 8-byte unit p * STEMX_PLANE / 4 + e
+          lds64[p * (STEMX_PLANE / 4) + e] = make_uint2(t[p][0] | ((unsigned)t[p][1] << 16), t[p][2] | ((unsigned)t[p][3] << 16));
       }
     }
   }

@@ -1317,8 +1317,8 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
             for (int j = 0; j < 8; ++j) {
               const int row = 2 * st + (lane >> 5), n = nb * 32 + (lane & 31);
               double v = 0.0;
-              if (row < rows && j < 7) {
-                const int k = row * 7 + j;  // (c, ky, kx) flattened exactly as conv1.weight[n]
+              if (row < rows && j > 0) {     // j = 0: the zero-weight pad (LDS column 0 is one pixel left of the window)
+                const int k = row * 7 + j - 1;  // (c, ky, kx = j - 1) flattened exactly as conv1.weight[n]
                 if (c->cin == 3) v = (double)w[n * 147 + k];
                 else v = (double)w[n * 147 + k] + (double)w[n * 147 + 49 + k] + (double)w[n * 147 + 98 + k];
               }

@@ -198,27 +198,25 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   q1[0] = wp[128];
   q1[1] = wp[192];
 
-  {  // input window -> LDS: all loads of a thread are issued before the first LDS write
-    constexpr int NE = CIN * STEM_HALO * STEM_HALO, IT = (NE + 255) / 256;
-    float v[IT];
+  {  // input window -> LDS as aligned float4 row segments: LDS column 0 is image column ix0 - 1 (= 32 tx - 4, a multiple
+     // of 4, and W is a multiple of 8, so every float4 lies entirely inside or entirely outside the frame); 40 columns
+     // per row cover the 37 the tile needs.  All loads of a thread are issued before its first LDS write.
+    constexpr int NQ = STEM_LW / 4, NE = CIN * STEM_HALO * NQ, IT = (NE + 255) / 256;
+    float4 v[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
-      const int c = e / (STEM_HALO * STEM_HALO);
-      const int r = e - c * (STEM_HALO * STEM_HALO);
-      const int hy = r / STEM_HALO, hx = r - hy * STEM_HALO;
-      const int iy = iy0 + hy, ix = ix0 + hx;
+      const int row = e / NQ, q = e - row * NQ;
+      const int c = row / STEM_HALO, hy = row - c * STEM_HALO;
+      const int iy = iy0 + hy, ix = ix0 - 1 + 4 * q;
       const bool ok = e < NE && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float x = a.in[ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0];
-      v[i] = ok ? x : 0.f;
+      const float4 x = *reinterpret_cast<const float4*>(a.in + (ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0));
+      v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
-      const int c = e / (STEM_HALO * STEM_HALO);
-      const int r = e - c * (STEM_HALO * STEM_HALO);
-      const int hy = r / STEM_HALO, hx = r - hy * STEM_HALO;
-      if (e < NE) lds[(c * STEM_HALO + hy) * STEM_LW + hx] = v[i];
+      if (e < NE) *reinterpret_cast<float4*>(lds + e * 4) = v[i];  // e * 4 == row * STEM_LW + 4 * q
     }
   }
   __syncthreads();
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const int m = (wave * 2 + mb) * 32 + l31;
-    abase[mb] = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T);
+    abase[mb] = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T) + 1;  // + 1: LDS column 0 is image column ix0 - 1
   }
   f32x16 acc[2][2];
 #pragma unroll
