@@ -431,6 +431,12 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) bc[nb][p] = wp[(p * 2 + nb) * 64];
   wp += 2 * NP * 64;
+  uint4 b1[2][NP];  // fragments run two steps ahead (the blob carries two zero steps of padding)
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) b1[nb][p] = wp[(p * 2 + nb) * 64];
+  wp += 2 * NP * 64;
 
   {  // input window -> NP sixteen-bit planes in LDS, as aligned float4 row segments: LDS column 0 is image column
      // ix0 - 1 (= 32 tx - 4; W is a multiple of 8, so a float4 is entirely inside or outside the frame); the 8 K-values
@@ -525,7 +531,10 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bc[nb][p] = bn[nb][p];
+      for (int p = 0; p < NP; ++p) {
+        bc[nb][p] = b1[nb][p];
+        b1[nb][p] = bn[nb][p];
+      }
   }
 
   FPC_STAMP(2)
