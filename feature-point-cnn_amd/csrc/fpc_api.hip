@@ -1834,7 +1834,7 @@ static void run_softmax(fpc_ctx* c, const Sub& sb) {
   const size_t HW = (size_t)c->H * c->W;
   hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
   LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st, sb.n);
-  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)16 * c->W * sizeof(float), sb.st,
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)12 * c->W * sizeof(float), sb.st,
                      c->lg + (size_t)sb.f0 * c->Hc * c->Wc * c->lgcs, c->lgcs, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
                      c->prob + sb.f0 * HW, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
 }
@@ -1985,7 +1985,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   if (cfg->arch == FPC_ARCH_VGG && (cfg->in_channels != 1 || cfg->dtype == FPC_BF16)) return FPC_E_INVALID;
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
-      (long long)cfg->height * cfg->width >= (1ll << 30))
+      (long long)cfg->height * cfg->width >= (1ll << 30) ||
+      cfg->width > 3328)  // softmax_d2s_kernel keeps an 8 x W strip (48 W bytes) in the 160 KB of LDS
     return FPC_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
@@ -2061,7 +2062,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   for (int k = 0; k < FK_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_fkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_fkinds[k].lds_bytes));
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 * cfg->width * (int)sizeof(float)));
+                               12 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
 #ifdef FPC_DIAG

@@ -323,21 +323,33 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
   // one workgroup per ROW of cells: the 8 x W strip of probabilities is assembled in LDS so
   // that the dense maps are written as whole rows, and the strip's candidates are appended
   // with ONE global atomic (per-wave atomics on one counter serialise at ~11 ns each).
-  extern __shared__ float strip[];                 // [8][W] floats, then [8*W] candidate slots
+  extern __shared__ float strip[];                 // [8][W] floats, then [8*W] 16-bit candidate slots (8 W < 65536)
   __shared__ int s_cnt, s_base;
   const int W = Wc * 8, H = Hc * 8;
-  uint32_t* s_list = reinterpret_cast<uint32_t*>(strip + 8 * W);
+  unsigned short* s_list = reinterpret_cast<unsigned short*>(strip + 8 * W);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / Hc, i = blockIdx.x - b * Hc;
   if (tid == 0) s_cnt = 0;
-  for (int j = wave; j < Wc; j += 4) {
-    const float* l = logits + ((size_t)(b * Hc + i) * Wc + j) * cs;
-    const float e = expf(l[lane]);
-    const float ed = expf(l[64]);
-    float s = e;
+  // four cells per iteration and wave: their eight loads are in flight together (one cell at a time left every
+  // iteration exposed to a full memory round trip)
+  const float* lrow = logits + (size_t)(b * Hc + i) * Wc * cs;
+  for (int j0 = wave * 4; j0 < Wc; j0 += 16) {
+    float lv[4], ld[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    strip[(lane >> 3) * W + j * 8 + (lane & 7)] = e / ((s + ed) + .00001f);
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u < Wc ? j0 + u : Wc - 1;
+      lv[u] = lrow[(size_t)j * cs + lane];
+      ld[u] = lrow[(size_t)j * cs + 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float e = expf(lv[u]);
+      const float ed = expf(ld[u]);
+      float s = e;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (j0 + u < Wc) strip[(lane >> 3) * W + (j0 + u) * 8 + (lane & 7)] = e / ((s + ed) + .00001f);
+    }
   }
   __syncthreads();
   const size_t fbase = (size_t)b * H * W + (size_t)i * 8 * W;
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
       int off = 0;
       if (lane == 0) off = atomicAdd(&s_cnt, __popcll(mask));
       off = __shfl(off, 0);
-      if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (uint32_t)(i * 8 * W + k);
+      if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (unsigned short)k;
     }
   }
   __syncthreads();
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
   if (tid == 0) s_base = atomicAdd(&ncand[b], n);
   __syncthreads();
   uint32_t* dst = cand + (size_t)b * H * W + s_base;
-  for (int k = tid; k < n; k += 256) dst[k] = s_list[k];
+  for (int k = tid; k < n; k += 256) dst[k] = (uint32_t)(i * 8 * W) + s_list[k];
 }
 
 // Same outputs from a caller-provided dense probability map (fpc_get_points).
