@@ -46,6 +46,9 @@ struct BlockBfArgs {
   int pad;               // halo origin = tile origin * S - pad
   int norelu;            // conv_only: 1 = no ReLU (the last 1x1 of a head of the C++ network)
   int* range_flag;       // block_h2_kernel: set to 1 when a value that a later layer will split leaves fp16's range
+#ifdef FPC_DIAG
+  unsigned long long* stamps;
+#endif
 };
 
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>

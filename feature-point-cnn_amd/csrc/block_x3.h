@@ -183,6 +183,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   bool bad = false;  // NP == 2: a value outside fp16's range was produced (it saturates when the next layer splits it)
 
+  FPC_STAMP(0)
   // ---------------------------------------------------------------- phase 1: KxK conv
   load_chunk(0);
   uint4 bc[NB][NP];
@@ -195,6 +196,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
     if (chunk) FPC_LDS_BARRIER();
     store_chunk();
     FPC_LDS_BARRIER();
+    if (chunk == 0) { FPC_STAMP(1) }
     if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
     for (int tap = 0; tap < a.ntaps; ++tap) {
       const int toff = a.tapoff16[tap];
@@ -224,6 +226,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
     }
   }
 
+  FPC_STAMP(2)
   if (!a.conv_only) {
     // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (fp32)
     const uint4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
@@ -252,6 +255,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
       }
     }
     FPC_LDS_BARRIER();
+    FPC_STAMP(3)
     // -------------------------------------------------------------- phase 2a: K over h (LDS, split on read)
     const float4* hl4 = reinterpret_cast<const float4*>(lds16);
     int hbase[MB];
@@ -326,6 +330,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
     }
   }
 
+  FPC_STAMP(4)
   // ---------------------------------------------------------------- epilogue: fp32 tile -> LDS -> 8-channel vectors
   FPC_LDS_BARRIER();
   {
@@ -344,7 +349,6 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
         }
     }
   }
-  FPC_LDS_BARRIER();
   {
     constexpr int C4 = CMIDP / 4;
     constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
@@ -352,6 +356,21 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
     const int oyb = ty * TH, oxb = tx * TW;
     const bool ident = !a.conv_only && a.k16_x == 0;
     float* __restrict__ outp = static_cast<float*>(a.out);
+    // identity shortcut (same geometry as the output, stride 1): the global loads are issued BEFORE the barrier --
+    // the accumulators are dead after the LDS writes above, so their registers carry the loads across it
+    float4 idv[EIT];
+    if (ident) {
+#pragma unroll
+      for (int i = 0; i < EIT; ++i) {
+        const int e = tid + i * NT;
+        const int m = e / C4, c4 = e - m * C4;
+        const int py = m / TW, px = m - py * TW;
+        const int y = oyb + py, x = oxb + px;
+        const bool ok = (NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo;
+        idv[i] = *reinterpret_cast<const float4*>(xin + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4 : 0));
+      }
+    }
+    FPC_LDS_BARRIER();
 #pragma unroll
     for (int i = 0; i < EIT; ++i) {
       const int e = tid + i * NT;
@@ -360,9 +379,8 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
       const int y = oyb + py, x = oxb + px;
       if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
         float4 v = ol4[m * ROWO4 + c4];
-        if (ident) {  // identity shortcut: same geometry as the output (stride 1)
-          const float4 q = *reinterpret_cast<const float4*>(xin + ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4);
-          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        if (ident) {
+          v.x += idv[i].x; v.y += idv[i].y; v.z += idv[i].z; v.w += idv[i].w;
         }
         if (!a.norelu) {
           v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
@@ -373,6 +391,7 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
       }
     }
   }
+  FPC_STAMP(5)
   if (NP == 2 && bad && a.range_flag) atomicOr(a.range_flag, 1);
 }
 

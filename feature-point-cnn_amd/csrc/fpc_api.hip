@@ -1784,6 +1784,16 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         BlockBfArgs a = op.fargs;
         a.frame0 = f0;
         a.range_flag = c->split_f16 ? c->status + 1 : nullptr;
+#ifdef FPC_DIAG
+        a.stamps = nullptr;
+        if (const char* e = getenv("FPC_STAMP_OP"))
+          if (op.name.find(e) != std::string::npos) {
+            if (!c->diag_stamps) hipHostMalloc((void**)&c->diag_stamps, (size_t)65536 * 8 * sizeof(unsigned long long));
+            memset(c->diag_stamps, 0, (size_t)65536 * 8 * sizeof(unsigned long long));
+            a.stamps = c->diag_stamps;
+            c->diag_n = a.tiles_x * a.tiles_y * n;
+          }
+#endif
         g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
         break;
       }
