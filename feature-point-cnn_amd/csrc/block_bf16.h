@@ -294,13 +294,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         }
     }
   }
-  FPC_LDS_BARRIER();
   {
     constexpr int C8 = CMIDP / 8;
     constexpr int NE = TH * TW * C8, EIT = (NE + NT - 1) / NT;
     const float4* ol4 = reinterpret_cast<const float4*>(lds16);
     const int oyb = ty * TH, oxb = tx * TW;
     const bool ident = !a.conv_only && a.k16_x == 0;
+    // identity shortcut (same geometry as the output, stride 1; bf16, the only fp32 input feeds a projection block):
+    // the loads are issued BEFORE the barrier, in the registers the dead accumulators free
+    uint4 idq[EIT];
+    if (ident && !a.in_f32) {
+#pragma unroll
+      for (int i = 0; i < EIT; ++i) {
+        const int e = tid + i * NT;
+        const int m = e / C8, c8 = e - m * C8;
+        const int py = m / TW, px = m - py * TW;
+        const int y = oyb + py, x = oxb + px;
+        const bool ok = (NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo;
+        idq[i] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c8 * 8 : 0));
+      }
+    }
+    FPC_LDS_BARRIER();
 #pragma unroll
     for (int i = 0; i < EIT; ++i) {
       const int e = tid + i * NT;
@@ -309,14 +323,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       const int y = oyb + py, x = oxb + px;
       if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
         float4 v0 = ol4[m * ROWO4 + c8 * 2], v1 = ol4[m * ROWO4 + c8 * 2 + 1];
-        if (ident) {  // identity shortcut: same geometry as the output (stride 1), bf16 or fp32 input
-          const size_t ioff = ((size_t)(b * a.H + y) * a.W + x) * a.csx + c8 * 8;
+        if (ident) {
           if (a.in_f32) {
+            const size_t ioff = ((size_t)(b * a.H + y) * a.W + x) * a.csx + c8 * 8;
             const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + ioff);
             v0.x += p[0].x; v0.y += p[0].y; v0.z += p[0].z; v0.w += p[0].w;
             v1.x += p[1].x; v1.y += p[1].y; v1.z += p[1].z; v1.w += p[1].w;
           } else {
-            const uint4 q = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + ioff);
+            const uint4 q = idq[i];
             v0.x += bf2f(q.x & 0xffff); v0.y += bf2f(q.x >> 16); v0.z += bf2f(q.y & 0xffff); v0.w += bf2f(q.y >> 16);
             v1.x += bf2f(q.z & 0xffff); v1.y += bf2f(q.z >> 16); v1.z += bf2f(q.w & 0xffff); v1.w += bf2f(q.w >> 16);
           }
