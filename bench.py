@@ -259,7 +259,7 @@ def main():
     serial = None
     if use_events and rank == 0 and world == 1 and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
-        os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"] = "1", "0"
+        os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"], os.environ["FPC_NMS_ASIDE"] = "1", "0", "0"
         e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
@@ -279,6 +279,7 @@ def main():
         # the other fp32 arithmetic modes on the same frames (not part of `value`)
         os.environ.pop("FPC_STREAMS", None)
         os.environ.pop("FPC_SPLIT_HEADS", None)
+        os.environ.pop("FPC_NMS_ASIDE", None)
         for adt in ("f32", "f32_split", "f32_split_f16"):
             if adt == dtype:
                 continue
