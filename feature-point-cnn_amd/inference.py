@@ -160,6 +160,27 @@ class InferenceWrapper:
         pts, desc = self.run_batch(x)[0]
         return pts, desc
 
+    def trace(self, img, out_file_name):
+        """python/src/inferencewrapper.py:83-91.  The reference writes two files: a TorchScript trace (for its TRTorch
+        path -- no meaning here, the kernels ARE the compiled model, so it is not written) and "just weights for cpp":
+        the state dict as a flat {name: tensor} file `<out>_params.pt` with the first dotted component of every key
+        dropped, exactly as the reference does (`'.'.join(k.split('.')[1:])`).  Returns the path written."""
+        del img
+        sd = self.net._state_dict
+        flat = {".".join(k.split(".")[1:]): (v if torch.is_tensor(v) else torch.from_numpy(np.asarray(v)))
+                for k, v in sd.items()}
+        path = out_file_name + "_params.pt"
+        torch.save(flat, path, _use_new_zipfile_serialization=True)
+        return path
+
+    def export_state_dict(self, path):
+        """The loaded checkpoint as a flat {name: tensor} file with the FULL key names: the form
+        `superpoint::SuperPoint(file, false)` of cpp/superpoint.hpp (and fpc_load_weights) take besides the trainer's
+        checkpoint."""
+        sd = self.net._state_dict
+        torch.save({k: (v if torch.is_tensor(v) else torch.from_numpy(np.asarray(v))) for k, v in sd.items()}, path)
+        return path
+
     def run_batch(self, frames):
         """frames [n,3,H,W] -> list of (points [3,K], descriptors [D,K]), one per frame."""
         h, w = frames.shape[2], frames.shape[3]

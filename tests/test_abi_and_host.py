@@ -161,3 +161,26 @@ def test_cpp_checkpoint_reader_matches_torch(tmp_path):
     assert len(subprocess.check_output([demo, "--list", g]).decode().strip().split("\n")) == 163
     bad = subprocess.run([demo, "--list", str(tmp_path / "missing.pt")], capture_output=True)
     assert bad.returncode != 0 and b"Failed to open file" in bad.stderr
+
+
+def test_inference_wrapper_exports(tmp_path):
+    """InferenceWrapper.trace (python/src/inferencewrapper.py:83-91, the "just weights for cpp" half) and the
+    full-key flat export: no GPU involved (the engine is created at the first frame)."""
+    import torch
+    from fpc_amd.inference import InferenceWrapper, SuperPointSettings
+    sd = synth.make_state_dict(6)
+    ck = str(tmp_path / "super_point_1.pt")
+    torch.save({"epoch": 1, "model_state_dict": {k: torch.from_numpy(v.copy()) for k, v in sd.items()}}, ck)
+    net = InferenceWrapper(ck, SuperPointSettings())
+    out = net.trace(None, str(tmp_path / "exp"))
+    assert out.endswith("exp_params.pt") and os.path.exists(out)
+    flat = torch.load(out, map_location="cpu", weights_only=True)
+    # the reference drops the first dotted component of every key; colliding keys overwrite each other exactly as there
+    want = {".".join(k.split(".")[1:]): v for k, v in sd.items()}
+    assert list(flat.keys()) == list(want.keys())
+    assert all(np.array_equal(flat[k].numpy(), want[k]) for k in want)
+    full = torch.load(net.export_state_dict(str(tmp_path / "full.pt")), map_location="cpu", weights_only=True)
+    assert list(full.keys()) == list(sd.keys())
+    demo = os.path.join(ROOT, "feature-point-cnn_amd", "lib", "fpc_demo")
+    if os.path.exists(demo):
+        assert len(subprocess.check_output([demo, "--list", str(tmp_path / "full.pt")]).decode().strip().split("\n")) == 163
