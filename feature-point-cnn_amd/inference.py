@@ -32,6 +32,8 @@ class SuperPointSettings:
         self.nn_thresh = 0.7
         self.cell = 8
         self.border_remove = 4
+        # not in the reference: the arithmetic mode of the kernels (include/fpc.h FPC_F32 / FPC_F32_SPLIT / ...)
+        self.dtype = "f32"
 
 
 def load_checkpoint_for_inference(filename):
@@ -74,10 +76,13 @@ class SuperPoint:
             if e is not None:
                 e.close()
             s = self.settings
-            e = Engine(h, w, max(batch, self.max_batch), self.device, s.nms_dist, s.confidence_thresh,
-                       s.border_remove, self.is_descriptor_enabled)
             if self._state_dict is None:
                 raise RuntimeError("SuperPoint: no weights loaded")
+            # the flat dict of the reference's C++ network (cpp/src/model.cc) selects that architecture (gray frames)
+            vgg = "encoder_conv0_a.weight" in self._state_dict
+            e = Engine(h, w, max(batch, self.max_batch), self.device, s.nms_dist, s.confidence_thresh,
+                       s.border_remove, self.is_descriptor_enabled, in_channels=1 if vgg else 3,
+                       dtype=getattr(s, "dtype", "f32"), arch="vgg" if vgg else "resnet")
             e.load_state_dict(self._state_dict)
             self._engines[key] = e
         return e
@@ -187,6 +192,6 @@ class InferenceWrapper:
         e = self.net.engine(h, w, frames.shape[0])
         out = []
         for xy, conf, desc, _ in e.detect(frames):
-            d = desc.T.copy() if desc is not None else np.full((128, len(conf)), np.nan, np.float32)
+            d = desc.T.copy() if desc is not None else np.full((e.desc_dim, len(conf)), np.nan, np.float32)
             out.append((_points_array(xy, conf), d))
         return out

@@ -290,6 +290,17 @@ def test_reference_style_wrapper(torch_gpu, tmp_path):
                                   np.sort(g["points_y"].astype(np.int64) * 320 + g["points_x"]))
     with pytest.raises(FileNotFoundError):
         InferenceWrapper(str(tmp_path / "missing.pt"), SuperPointSettings())
+    # the same wrapper in the split-operand mode, and on the C++ network's flat dict (gray tensor in, 256-D out)
+    st = SuperPointSettings()
+    st.dtype = "f32_split_f16"
+    p2, d2 = InferenceWrapper(f, st).run(img)
+    np.testing.assert_array_equal(np.sort(p2[1].astype(np.int64) * 320 + p2[0].astype(np.int64)),
+                                  np.sort(points[1].astype(np.int64) * 320 + points[0].astype(np.int64)))
+    vf = str(tmp_path / "sp_vgg.pt")
+    torch.save({k: torch.from_numpy(v.copy()) for k, v in synth.make_vgg_state_dict(32, 3.0).items()}, vf)
+    gray = torch.from_numpy(synth.make_batch(401, 1, 240, 320, gray=True)[:, :1].copy())
+    pv, dv = InferenceWrapper(vf, SuperPointSettings()).run(gray)
+    assert dv.shape == (256, pv.shape[1]) and pv.shape[1] > 50
 
 
 def test_error_codes(torch_gpu):
