@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra one-stream pass that gives clean per-kernel durations")
     ap.add_argument("--no-timing-events", action="store_true",
                     help="do not bracket launches with HIP events (roofline then comes from a separate pass)")
-    ap.add_argument("--workload", choices=["vga32", "hd64-bf16"], default="vga32",
+    ap.add_argument("--workload", choices=["vga32", "hd64-bf16", "qvga32-magicpoint"], default="vga32",
                     help="vga32 = BASELINE.json configs[1] (the headline; default); hd64-bf16 = configs[4]: 64 frames of "
                          "1280x960 per step, bf16 activations / weights with fp32 accumulation")
     ap.add_argument("--dtype", choices=["f32", "f32_split", "f32_split_f16"], default="f32",
@@ -196,6 +196,10 @@ def main():
     if dtype in ("f32_split", "f32_split_f16"):
         PEAK_TFLOPS = PEAK_BF16_MFMA_TFLOPS / (6.0 if dtype == "f32_split" else 3.0)   # six bf16 / three fp16 MFMAs per product
         PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
+    magic = args.workload == "qvga32-magicpoint"   # configs[3]: detector only, 240x320, NMS r = 4
+    if magic:
+        H, W = 240, 320
+        args.no_host_fed = True
     if args.workload == "hd64-bf16":
         H, W, BATCH, dtype, PEAK_TFLOPS = 960, 1280, 64, "bf16", PEAK_BF16_MFMA_TFLOPS
         PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
@@ -213,11 +217,11 @@ def main():
         args.gray, args.no_host_fed, args.no_alt_pass = True, True, True
     sd = (synth.make_vgg_state_dict(0, dustbin_bias=5.5) if vgg else synth.make_state_dict(0, dustbin_bias=7.0)) if rank == 0 else None
     cin = 1 if args.gray else 3
-    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
+    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
     fdist.broadcast_packed_weights(eng, sd)
     engs = [eng]
     for _ in range(1, max(1, args.contexts)):
-        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
+        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
         e2.import_packed(eng.export_packed())
         engs.append(e2)
     # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
@@ -260,7 +264,7 @@ def main():
     if use_events and rank == 0 and world == 1 and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
         os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"], os.environ["FPC_NMS_ASIDE"] = "1", "0", "0"
-        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch)
+        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
             e1.detect_async(frames, BATCH)
@@ -307,7 +311,7 @@ def main():
 
     if rank == 0:
         value = total_frames / dt
-        flops_frame = 2.0 * (arch.vgg_conv_macs(H, W) if vgg else arch.conv_macs(H, W))
+        flops_frame = 2.0 * (arch.vgg_conv_macs(H, W) if vgg else arch.conv_macs(H, W, descriptor=not magic))
         wl = ("batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
               "(BASELINE.json configs[1]; configs[2] when n_gpus=8)" +
               ("; products as six bf16 MFMAs on exactly split fp32 operands" if dtype == "f32_split" else
@@ -315,10 +319,12 @@ def main():
               ) if dtype != "bf16" else (
               "batch=64 1280x960 frames per GPU, super_point checkpoint layout, bf16 activations/weights, fp32 "
               "accumulation, fp32 post-processing (BASELINE.json configs[4])")
+        if magic:
+            wl = "batch=32 240x320 frames per GPU, detector only (MagicPoint), NMS r=4, " + dtype + " (BASELINE.json configs[3])"
         if vgg:
             wl = "batch=32 640x480 gray frames per GPU, the cpp/ frontend's network (superpoint::SPModel, 256-D), " + dtype
         out = {
-            "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("VGA 640x480" if dtype != "bf16" else "HD 1280x960"),
+            "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("QVGA 320x240, detector only" if magic else "VGA 640x480" if dtype != "bf16" else "HD 1280x960"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
