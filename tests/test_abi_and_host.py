@@ -184,3 +184,12 @@ def test_inference_wrapper_exports(tmp_path):
     demo = os.path.join(ROOT, "feature-point-cnn_amd", "lib", "fpc_demo")
     if os.path.exists(demo):
         assert len(subprocess.check_output([demo, "--list", str(tmp_path / "full.pt")]).decode().strip().split("\n")) == 163
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/fpc.h is the drop-in boundary: it must compile as C99 (cgo / JNI / ctypes-style consumers) and as C++."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "fpc.h"\nint main(void) { fpc_config c; return (int)sizeof(c) * 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
