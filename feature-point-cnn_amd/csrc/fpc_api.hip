@@ -23,6 +23,7 @@
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "match.h"
+#include "homography.h"
 #include "weights.h"
 
 namespace fpc {
@@ -328,6 +329,7 @@ struct fpc_ctx {
   unsigned long long *rowbest, *colbest;  // descriptor matching workspace, `cap` entries each
 
   float* u8stage = nullptr;          // fpc_detect_u8: converted frames [B,cin,H,W], allocated on first use
+  char* ha_ws = nullptr;             // fpc_homography_adaptation: workspace, allocated on first use
 
   // packed weights
   float* blob = nullptr;
@@ -2129,6 +2131,7 @@ void fpc_destroy(fpc_ctx* c) {
   if (c->slab) hipFree(c->slab);
   if (c->blob) hipFree(c->blob);
   if (c->u8stage) hipFree(c->u8stage);
+  if (c->ha_ws) hipFree(c->ha_ws);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2261,6 +2264,73 @@ int fpc_detect_u8(fpc_ctx* c, const uint8_t* frames, int n, int layout) {
 }
 
 const float* fpc_u8_staging(fpc_ctx* c) { return c ? c->u8stage : nullptr; }
+
+// 3x3 inverse of a flat homography (h[8], implicit 1), normalised back to flat form -- invert_homography,
+// python/src/homographies.py:185-209 (torch.linalg.inv in fp32 there, double here)
+static bool invert_flat_homography(const float* h, float* out) {
+  const double m[9] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0};
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[2] * m[7] - m[1] * m[8], c02 = m[1] * m[5] - m[2] * m[4];
+  const double c10 = m[5] * m[6] - m[3] * m[8], c11 = m[0] * m[8] - m[2] * m[6], c12 = m[2] * m[3] - m[0] * m[5];
+  const double c20 = m[3] * m[7] - m[4] * m[6], c21 = m[1] * m[6] - m[0] * m[7], c22 = m[0] * m[4] - m[1] * m[3];
+  const double det = m[0] * c00 + m[1] * c10 + m[2] * c20;
+  if (!(std::fabs(det) > 1e-300) || !(std::fabs(c22) > 0.0)) return false;
+  const double inv[9] = {c00, c01, c02, c10, c11, c12, c20, c21, c22};  // adjugate; the 1/det cancels in mat2flat
+  for (int i = 0; i < 8; ++i) out[i] = (float)(inv[i] / inv[8]);
+  return true;
+}
+
+int fpc_homography_adaptation(fpc_ctx* c, const float* frames, int n, const float* homographies, const float* inverses,
+                              int num, int erosion_radius, int aggregation, float* prob_out) {
+  if (!c || !frames || !prob_out || n < 1 || n > c->B || num < 0 || (num > 0 && !homographies) || erosion_radius < 0 ||
+      erosion_radius > 64 || (aggregation != 0 && aggregation != 1))
+    return FPC_E_INVALID;
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  const bool de = c->cfg.descriptor_enabled != 0;
+  const size_t HW = (size_t)c->H * c->W, frame_elems = (size_t)c->cin * HW;
+  // workspace: warped frames [B,cin,HW] | warped prob [B,HW] | sum [B,HW] | max [B,HW] | cnt, count, mask, tmp [HW] each
+  if (!c->ha_ws)
+    HIPCHECK(hipMalloc((void**)&c->ha_ws, ((size_t)c->B * frame_elems + 3 * (size_t)c->B * HW + 4 * HW) * sizeof(float)));
+  float* wfr = reinterpret_cast<float*>(c->ha_ws);
+  float* wprob = wfr + (size_t)c->B * frame_elems;
+  float* sum = wprob + (size_t)c->B * HW;
+  float* mx = sum + (size_t)c->B * HW;
+  float* cnt = mx + (size_t)c->B * HW;
+  float* count = cnt + HW;
+  float* mask = count + HW;
+  float* tmp = mask + HW;
+  const dim3 gp((unsigned)((HW + 255) / 256)), bp(256);
+  hipStream_t st = c->stream;
+  auto forward = [&](const float* f) -> int {  // prob maps of n frames -> c->prob (the path up to depth-to-space)
+    return for_each_sub(c, n, [&](const Sub& sb) { run_path(c, f, sb, de, 0); });
+  };
+  int rc = forward(frames);  // all_probs = net(image), all_counts = 1   (homographies.py:269-270)
+  if (rc != FPC_OK) return rc;
+  WarpCoeffs none{};
+  hipLaunchKernelGGL(unwarp_accumulate_kernel, gp, bp, 0, st, c->prob, none, count, sum, mx, cnt, n, c->H, c->W, 1);
+  for (int i = 0; i < num; ++i) {
+    WarpCoeffs k{}, kinv{};
+    memcpy(k.c, homographies + (size_t)i * 8, sizeof(k.c));
+    if (inverses) memcpy(kinv.c, inverses + (size_t)i * 8, sizeof(kinv.c));
+    else if (!invert_flat_homography(k.c, kinv.c)) return FPC_E_INVALID;
+    // warped = transform(image, H); count = transform(ones, H_inv, nearest); mask = transform(ones, H, nearest)  :288-292
+    hipLaunchKernelGGL(warp_perspective_kernel, gp, bp, 0, st, frames, wfr, n * c->cin, c->H, c->W, k, 0, 0);
+    float* cdst = erosion_radius ? tmp : count;
+    hipLaunchKernelGGL(warp_perspective_kernel, gp, bp, 0, st, (const float*)nullptr, cdst, 1, c->H, c->W, kinv, 1, 1);
+    if (erosion_radius) hipLaunchKernelGGL(erode_ellipse_kernel, gp, bp, 0, st, tmp, count, c->H, c->W, erosion_radius);
+    float* mdst = erosion_radius ? tmp : mask;
+    hipLaunchKernelGGL(warp_perspective_kernel, gp, bp, 0, st, (const float*)nullptr, mdst, 1, c->H, c->W, k, 1, 1);
+    if (erosion_radius) hipLaunchKernelGGL(erode_ellipse_kernel, gp, bp, 0, st, tmp, mask, c->H, c->W, erosion_radius);
+    rc = forward(wfr);  // warped_prob = net(warped)   :297
+    if (rc != FPC_OK) return rc;
+    HIPCHECK(hipMemcpyAsync(wprob, c->prob, (size_t)n * HW * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(mul_mask_kernel, gp, bp, 0, st, wprob, mask, n, HW);                         // :298
+    hipLaunchKernelGGL(unwarp_accumulate_kernel, gp, bp, 0, st, wprob, kinv, count, sum, mx, cnt, n, c->H, c->W, 0);  // :299-305
+  }
+  hipLaunchKernelGGL(aggregate_kernel, gp, bp, 0, st, sum, mx, cnt, prob_out, n, HW, (float)(num / 3), aggregation);
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
 
 int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n) {
   if (!c || !prob || n < 1 || n > c->B) return FPC_E_INVALID;

@@ -182,6 +182,24 @@ class Engine:
         raw = torch.as_tensor(_DevArray(ptr, nbytes), device=self.torch_device)   # uint8 view of the library's buffer
         return raw.view(torch.float32).reshape(n, self.in_channels, self.h, self.w).clone()
 
+    def homography_adaptation(self, frames, homographies, inverses=None, erosion_radius=8, aggregation="sum"):
+        """homography_adaptation (python/src/homographies.py:250-324): frames [n,C,H,W], homographies [num,8] (flat,
+        the convention of sample_homography) -> aggregated probability maps [n,H,W] (CUDA tensor)."""
+        frames = self._frames(frames)
+        hs = np.ascontiguousarray(homographies, np.float32).reshape(-1, 8)
+        inv = None if inverses is None else np.ascontiguousarray(inverses, np.float32).reshape(-1, 8)
+        if inv is not None and inv.shape != hs.shape:
+            raise ValueError("inverses must match homographies")
+        if aggregation not in ("sum", "max"):
+            raise ValueError("Unknown aggregation method: %s" % aggregation)        # homographies.py:322
+        out = torch.empty((frames.shape[0], self.h, self.w), device=self.torch_device)
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_homography_adaptation(
+            self._ctx, frames.data_ptr(), frames.shape[0], hs.ctypes.data, None if inv is None else inv.ctypes.data,
+            hs.shape[0], int(erosion_radius), 1 if aggregation == "max" else 0, out.data_ptr()), "fpc_homography_adaptation")
+        self.sync()
+        return out
+
     def get_points(self, prob_map, desc_map=None):
         """Post-processing only, on caller-provided dense maps (netutils.py:78-121)."""
         prob_map = prob_map.to(self.torch_device, torch.float32).contiguous()

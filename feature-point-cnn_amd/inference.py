@@ -96,6 +96,89 @@ class SuperPoint:
     __call__ = forward
 
 
+class HomographyConfig:
+    """python/src/homographies.py:33-61 (same fields and defaults)."""
+
+    def __init__(self):
+        self.num = 15
+        self.perspective = True
+        self.scaling = True
+        self.rotation = True
+        self.translation = True
+        self.n_scales = 5
+        self.n_angles = 25
+        self.scaling_amplitude = 0.1
+        self.perspective_amplitude_x = 0.1
+        self.perspective_amplitude_y = 0.1
+        self.patch_ratio = 0.5
+        self.max_angle = np.pi / 2
+        self.allow_artifacts = False
+        self.translation_overflow = 0.
+        self.valid_border_margin = 8
+        self.aggregation = "sum"
+
+    def init_for_preprocess(self):
+        self.translation = self.rotation = self.scaling = self.perspective = True
+        self.scaling_amplitude = 0.2
+        self.perspective_amplitude_x = 0.2
+        self.perspective_amplitude_y = 0.2
+        self.allow_artifacts = True
+        self.patch_ratio = 0.85
+
+
+def sample_homography(shape, config=None, rng=None):
+    """sample_homography (python/src/homographies.py:78-182) step by step: a centred patch is perturbed
+    (perspective, scale, translation, rotation), each step keeping the corners inside the unit square unless
+    allow_artifacts, and the 8 coefficients mapping output points to input points are solved for.  Random numbers come
+    from `rng` (numpy Generator) instead of torch's / scipy's global state, so a run is reproducible from a seed but
+    not bit-identical to the reference's stream.  shape = (H, W).  -> float32 [8]."""
+    from scipy.stats import truncnorm
+    cfg = config or HomographyConfig()
+    rng = rng or np.random.default_rng()
+
+    def tn(n, mean, std):       # truncated_normal :64-67: +-2 sigma
+        return truncnorm(-2, 2, loc=mean, scale=std).rvs(n, random_state=rng).astype(np.float32) if std > 0 else np.full(n, mean, np.float32)
+
+    margin = (1 - cfg.patch_ratio) / 2
+    pts1 = margin + np.array([[0, 0], [0, cfg.patch_ratio], [cfg.patch_ratio, cfg.patch_ratio], [cfg.patch_ratio, 0]], np.float32)
+    pts2 = pts1.copy()
+    if cfg.perspective:
+        ax_, ay_ = cfg.perspective_amplitude_x, cfg.perspective_amplitude_y
+        if not cfg.allow_artifacts:
+            ax_, ay_ = min(ax_, margin), min(ay_, margin)
+        pd, hl, hr = tn(1, 0., ay_ / 2)[0], tn(1, 0., ax_ / 2)[0], tn(1, 0., ax_ / 2)[0]
+        pts2 += np.array([[hl, pd], [hl, -pd], [hr, pd], [hr, -pd]], np.float32)
+    if cfg.scaling:
+        scales = np.concatenate([[1.], tn(cfg.n_scales, 1, cfg.scaling_amplitude / 2)]).astype(np.float32)
+        center = pts2.mean(0, keepdims=True)
+        scaled = (pts2 - center)[None] * scales[:, None, None] + center
+        valid = np.arange(cfg.n_scales) if cfg.allow_artifacts else np.nonzero(((scaled >= 0.) & (scaled < 1.)).sum((1, 2)))[0]
+        pts2 = scaled[valid[rng.integers(len(valid))]]
+    if cfg.translation:
+        t_min, t_max = pts2.min(0), (1. - pts2).min(0)
+        if cfg.allow_artifacts:
+            t_min, t_max = t_min + cfg.translation_overflow, t_max + cfg.translation_overflow
+
+        def uni(lo, hi):        # random_uniform :70-75
+            lo, hi = (hi, lo) if lo > hi else (lo, hi)
+            return rng.uniform(lo, hi if hi > lo else lo + 0.00001)
+        pts2 = pts2 + np.array([[uni(-t_min[0], t_max[0]), uni(-t_min[1], t_max[1])]], np.float32)
+    if cfg.rotation:
+        angles = np.concatenate([[0.], np.linspace(-cfg.max_angle, cfg.max_angle, cfg.n_angles)]).astype(np.float32)
+        center = pts2.mean(0, keepdims=True)
+        rot = np.stack([np.cos(angles), -np.sin(angles), np.sin(angles), np.cos(angles)], 1).reshape(-1, 2, 2)
+        rotated = np.matmul(np.tile((pts2 - center)[None], (cfg.n_angles + 1, 1, 1)), rot) + center
+        valid = np.arange(cfg.n_angles) if cfg.allow_artifacts else np.nonzero(((rotated >= 0.) & (rotated < 1.)).sum((1, 2)))[0]
+        pts2 = rotated[valid[rng.integers(len(valid))]]
+    size = np.array(shape[::-1], np.float32)[None]      # (W, H)
+    p1, p2 = pts1 * size, pts2 * size
+    a_mat = np.array([f(p1[i], p2[i]) for i in range(4) for f in (
+        lambda p, q: [p[0], p[1], 1, 0, 0, 0, -p[0] * q[0], -p[1] * q[0]],
+        lambda p, q: [0, 0, 0, p[0], p[1], 1, -p[0] * q[1], -p[1] * q[1]])], np.float64)
+    p_mat = np.array([p2[i][j] for i in range(4) for j in range(2)], np.float64)
+    return np.linalg.solve(a_mat, p_mat).astype(np.float32)
+
+
 def get_points(prob_map, img_h, img_w, settings, engine=None):
     """netutils.py:78-100 for a [1,H,W] probability map -> float64 [3,K]."""
     if prob_map.dim() == 2:
@@ -164,6 +247,18 @@ class InferenceWrapper:
             raise ValueError("run() takes one frame; use run_batch() for several")
         pts, desc = self.run_batch(x)[0]
         return pts, desc
+
+    def run_with_homography_adaptation(self, img, config, homographies=None, rng=None):
+        """python/src/inferencewrapper.py:48-68: img [N,C,H,W] -> list of N point arrays [3,K] from the probability
+        maps aggregated over 1 + config.num views.  `homographies` [num,8] fixes the views; otherwise they are drawn
+        with sample_homography(rng)."""
+        x = self.prepare_input(img)
+        h, w = x.shape[2], x.shape[3]
+        e = self.net.engine(h, w, x.shape[0])
+        if homographies is None:
+            homographies = np.stack([sample_homography((h, w), config, rng) for _ in range(config.num)])
+        prob = e.homography_adaptation(x, homographies, None, config.valid_border_margin, config.aggregation)
+        return [_points_array(xy, conf) for xy, conf, _, _ in e.get_points(prob)]
 
     def trace(self, img, out_file_name):
         """python/src/inferencewrapper.py:83-91.  The reference writes two files: a TorchScript trace (for its TRTorch

@@ -167,6 +167,21 @@ int fpc_detect_u8(fpc_ctx* ctx, const uint8_t* frames_dev, int n, int layout);
 /* The converted float frames of the last fpc_detect_u8 call ([n,C,H,W], device) -- for tests. */
 const float* fpc_u8_staging(fpc_ctx* ctx);
 
+/* ~ homography_adaptation (python/src/homographies.py:250-324; the caller is
+ * InferenceWrapper.run_with_homography_adaptation, inferencewrapper.py:48-68 <- preprocess_coco.py:64-74): the
+ * probability maps of n frames aggregated over the un-warped view and `num` perspective views.  For view i the frames
+ * are warped by homographies[i] (8 coefficients, the flattened 3x3 with h22 = 1, in the convention of
+ * sample_homography :78-182), run through the network, masked, warped back with inverses[i] (NULL: computed here)
+ * and accumulated with the validity counts; masks are eroded by an ellipse of radius erosion_radius
+ * (config.valid_border_margin, 0 = off); aggregation 0 = 'sum' (count-normalised mean, the reference's default),
+ * 1 = 'max'; pixels seen by fewer than num / 3 views become 0.  prob_out_dev [n,H,W] can be fed to fpc_get_points.
+ * homographies / inverses are HOST arrays; frames and prob_out are device memory.  Asynchronous.
+ * The warps restate torchvision's perspective() and the erosion OpenCV's erode(): both libraries are absent from this
+ * build, see csrc/homography.h -- parity for this entry point is unpinned beyond torch's own grid_sample. */
+int fpc_homography_adaptation(fpc_ctx* ctx, const float* frames_dev, int n, const float* homographies_host,
+                              const float* inverses_host, int num, int erosion_radius, int aggregation,
+                              float* prob_out_dev);
+
 /* Runs only the post-processing of fpc_detect on a caller-provided probability map
  * [n,H,W] (device) -- get_points on its own (netutils.py:78-100). Descriptors are
  * sampled from desc_nchw_dev [n,128,H/8,W/8] when it is not NULL. */

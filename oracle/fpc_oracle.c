@@ -662,3 +662,75 @@ int oracle_vgg_forward(const float* image, const float* const* weights, int B, i
   free(lg);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Homography adaptation pieces (python/src/homographies.py:215-216, 238-247, 250-324) -- the checker of
+ * fpc_homography_adaptation.  The reference delegates to torchvision.transforms.functional_tensor.perspective and
+ * cv2.erode, neither present in /root/reference nor in this image:
+ *   - the warp restates torchvision 0.10's `_perspective_grid` (pixel centres at +0.5, coefficients rescaled by half
+ *     the output size, projective division, -1) followed by torch.nn.functional.grid_sample(mode, padding zeros,
+ *     align_corners False).  Its sampling arithmetic is pinned by fixture F8 (torch's own grid_sample run on a grid
+ *     built by this formula, tests/golden/make_golden.py: golden_warp); the grid formula itself is restated from the
+ *     library's published source -- PARITY UNPINNED for it;
+ *   - the erosion restates OpenCV 4.x getStructuringElement(MORPH_ELLIPSE) + erode(BORDER_CONSTANT, 0) --
+ *     PARITY UNPINNED.
+ * ------------------------------------------------------------------------------------------- */
+static void warp_source(const float* k, int x, int y, int W, int H, float* ix, float* iy) {
+  const float X = (float)x + 0.5f, Y = (float)y + 0.5f;
+  const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+  const float nx = fmaf(1.0f, k[2] / hw, fmaf(Y, k[1] / hw, X * (k[0] / hw)));
+  const float ny = fmaf(1.0f, k[5] / hh, fmaf(Y, k[4] / hh, X * (k[3] / hh)));
+  const float den = fmaf(1.0f, 1.0f, fmaf(Y, k[7], X * k[6]));
+  const float gx = nx / den - 1.0f, gy = ny / den - 1.0f;
+  *ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+  *iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+}
+
+void oracle_warp_perspective(const float* in, int planes, int H, int W, const float* coeffs, int nearest, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      float ix, iy;
+      warp_source(coeffs, x, y, W, H, &ix, &iy);
+      for (int p = 0; p < planes; ++p) {
+        const float* src = in + (size_t)p * H * W;
+        float v = 0.0f;
+        if (nearest) {
+          const float rx = nearbyintf(ix), ry = nearbyintf(iy);
+          if (rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1)) v = src[(size_t)(int)ry * W + (int)rx];
+        } else {
+          const float fx = floorf(ix), fy = floorf(iy);
+          if (fx >= -1.f && fx <= (float)W && fy >= -1.f && fy <= (float)H) {
+            const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            const float wx0 = (float)x1 - ix, wx1 = ix - (float)x0, wy0 = (float)y1 - iy, wy1 = iy - (float)y0;
+            if (y0 >= 0 && y0 < H && x0 >= 0 && x0 < W) v += src[(size_t)y0 * W + x0] * (wx0 * wy0);
+            if (y0 >= 0 && y0 < H && x1 >= 0 && x1 < W) v += src[(size_t)y0 * W + x1] * (wx1 * wy0);
+            if (y1 >= 0 && y1 < H && x0 >= 0 && x0 < W) v += src[(size_t)y1 * W + x0] * (wx0 * wy1);
+            if (y1 >= 0 && y1 < H && x1 >= 0 && x1 < W) v += src[(size_t)y1 * W + x1] * (wx1 * wy1);
+          }
+        }
+        out[(size_t)p * H * W + (size_t)y * W + x] = v;
+      }
+    }
+}
+
+void oracle_erode_ellipse(const float* in, int H, int W, int r, float* out) {
+  const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      float m = INFINITY;
+      for (int a = 0; a < 2 * r; ++a) {
+        const int dy = a - r;
+        const int dx = (int)rint((double)r * sqrt(((double)r * r - (double)dy * dy) * inv_r2));
+        const int j1 = r - dx > 0 ? r - dx : 0, j2 = r + dx + 1 < 2 * r ? r + dx + 1 : 2 * r;
+        const int yy = y + dy;
+        for (int j = j1; j < j2; ++j) {
+          const int xx = x + j - r;
+          const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[(size_t)yy * W + xx] : 0.0f;
+          if (v < m) m = v;
+        }
+      }
+      out[(size_t)y * W + x] = m;
+    }
+}

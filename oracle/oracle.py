@@ -175,3 +175,52 @@ def vgg_forward(image, state_dict, spec):
         raise ValueError("oracle_vgg_forward: H and W must be multiples of 8")
     del keep
     return prob, desc, logits
+
+
+def warp_perspective(planes, coeffs, nearest=False):
+    """functional_tensor.perspective restated (homographies.py:215-216): planes float32 [P,H,W], coeffs 8 floats."""
+    a = np.ascontiguousarray(planes, np.float32)
+    p, h, w = a.shape
+    k = np.ascontiguousarray(coeffs, np.float32).ravel()
+    out = np.empty_like(a)
+    lib().oracle_warp_perspective(_p(a), p, h, w, _p(k), int(bool(nearest)), _p(out))
+    return out
+
+
+def erode_ellipse(plane, r):
+    """cv2.erode with the MORPH_ELLIPSE (2r, 2r) element, constant border 0 (homographies.py:238-247) restated."""
+    a = np.ascontiguousarray(plane, np.float32)
+    h, w = a.shape
+    out = np.empty_like(a)
+    lib().oracle_erode_ellipse(_p(a), h, w, int(r), _p(out))
+    return out
+
+
+def invert_homography(h):
+    """invert_homography (homographies.py:185-209) in double."""
+    m = np.append(np.asarray(h, np.float64).ravel(), 1.0).reshape(3, 3)
+    inv = np.linalg.inv(m)
+    return (inv / inv[2, 2]).ravel()[:8].astype(np.float32)
+
+
+def homography_adaptation(frames, forward_fn, homographies, inverses=None, erosion_radius=8, aggregation="sum"):
+    """homography_adaptation (homographies.py:250-324) restated; forward_fn(frames [n,C,H,W]) -> prob maps [n,H,W]."""
+    frames = np.ascontiguousarray(frames, np.float32)
+    n, c, h, w = frames.shape
+    probs = [forward_fn(frames)]
+    counts = [np.ones((h, w), np.float32)]
+    ones = np.ones((1, h, w), np.float32)
+    for i, hm in enumerate(homographies):
+        hinv = inverses[i] if inverses is not None else invert_homography(hm)
+        warped = warp_perspective(frames.reshape(n * c, h, w), hm).reshape(n, c, h, w)
+        count = warp_perspective(ones, hinv, nearest=True)[0]
+        mask = warp_perspective(ones, hm, nearest=True)[0]
+        if erosion_radius:
+            count, mask = erode_ellipse(count, erosion_radius), erode_ellipse(mask, erosion_radius)
+        wp = forward_fn(warped) * mask[None]
+        probs.append(warp_perspective(wp, hinv) * count[None])
+        counts.append(count)
+    total = np.sum(np.stack(counts, -1), -1, dtype=np.float32)
+    stack = np.stack(probs, -1)
+    agg = stack.max(-1) if aggregation == "max" else stack.sum(-1, dtype=np.float32) / total[None]
+    return np.where(total[None] >= len(homographies) // 3, agg, 0.0).astype(np.float32)

@@ -278,6 +278,47 @@ def golden_get_points_random():
           [int(cases["c%02d_out" % i].shape[1]) for i in range(48)])
 
 
+def _perspective_grid_as_torchvision(coeffs, ow, oh):
+    """torchvision 0.10 functional_tensor._perspective_grid, restated op by op (torchvision itself is not installed;
+    python/src/homographies.py:215-216 calls functional_tensor.perspective -> this grid -> F.grid_sample)."""
+    dtype = torch.float32
+    theta1 = torch.tensor([[[coeffs[0], coeffs[1], coeffs[2]], [coeffs[3], coeffs[4], coeffs[5]]]], dtype=dtype)
+    theta2 = torch.tensor([[[coeffs[6], coeffs[7], 1.0], [coeffs[6], coeffs[7], 1.0]]], dtype=dtype)
+    d = 0.5
+    base_grid = torch.empty(1, oh, ow, 3, dtype=dtype)
+    x_grid = torch.linspace(d, ow * 1.0 + d - 1.0, steps=ow)
+    base_grid[..., 0].copy_(x_grid)
+    y_grid = torch.linspace(d, oh * 1.0 + d - 1.0, steps=oh).unsqueeze_(-1)
+    base_grid[..., 1].copy_(y_grid)
+    base_grid[..., 2].fill_(1)
+    rescaled_theta1 = theta1.transpose(1, 2) / torch.tensor([0.5 * ow, 0.5 * oh], dtype=dtype)
+    output_grid1 = base_grid.view(1, oh * ow, 3).bmm(rescaled_theta1)
+    output_grid2 = base_grid.view(1, oh * ow, 3).bmm(theta2.transpose(1, 2))
+    return (output_grid1 / output_grid2 - 1.0).view(1, oh, ow, 2)
+
+
+def golden_warp():
+    """F8: torch's own grid_sample (bilinear and nearest, zeros padding, align_corners=False) on grids built by the
+    restated torchvision formula, for four homographies incl. strong perspective and out-of-frame regions.  Pins the
+    SAMPLING arithmetic of oracle_warp_perspective; the grid formula itself stays a restatement (unpinned)."""
+    rng = np.random.Generator(np.random.PCG64(88))
+    h, w = 40, 56
+    img = rng.uniform(0.0, 1.0, (1, 3, h, w)).astype(np.float32)
+    hs = np.array([[1, 0, 0, 0, 1, 0, 0, 0],
+                   [0.9, 0.08, 3.0, -0.05, 1.1, -2.0, 0.0008, -0.0005],
+                   [1.2, -0.2, -6.0, 0.15, 0.85, 4.0, -0.0012, 0.0015],
+                   [0.7, 0.3, 10.0, -0.3, 0.7, 12.0, 0.002, 0.001]], np.float32)
+    out = dict(img=img[0], homographies=hs)
+    for i, hm in enumerate(hs):
+        grid = _perspective_grid_as_torchvision([float(v) for v in hm], w, h)
+        for mode in ("bilinear", "nearest"):
+            o = torch.nn.functional.grid_sample(torch.from_numpy(img), grid, mode=mode, padding_mode="zeros",
+                                                align_corners=False)
+            out["%s_%d" % (mode, i)] = o[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "f8_warp_perspective.npz"), **out)
+    print("F8 warp cases:", len(hs))
+
+
 def golden_u8():
     """F6: the reference's 8-bit -> float conversion, evaluated by the libraries the reference calls, for all
     256 byte values: `frame.astype('float32') / 255.0` (python/src/camera.py:31; dataset_utils.py:23 is the
@@ -301,6 +342,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         golden_u8()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "f8":
+        golden_warp()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f4b":
         golden_get_descriptors_random()
         sys.exit(0)
@@ -315,5 +359,6 @@ if __name__ == "__main__":
     golden_u8()
     golden_get_points_random()
     golden_get_descriptors_random()
+    golden_warp()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

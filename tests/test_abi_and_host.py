@@ -193,3 +193,25 @@ def test_public_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+
+
+def test_sample_homography_restatement():
+    """sample_homography (python/src/homographies.py:78-182) restated: invertible matrices, reproducible from a seed,
+    the perspective row independent of the affine steps (c7 = 0 for the reference's symmetric perturbation), and the
+    centre of the patch staying in the frame.  (The reference keeps a scale / angle if ANY corner coordinate is inside
+    the unit square -- `nonzero(sum(...))`, :133, :164 -- so single corners may leave the frame; restated as is.)"""
+    from fpc_amd.inference import HomographyConfig, sample_homography
+    cfg = HomographyConfig()
+    h, w = 240, 320
+    a = [sample_homography((h, w), cfg, np.random.default_rng(1)) for _ in range(2)]
+    np.testing.assert_array_equal(a[0], a[1])
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        k = sample_homography((h, w), cfg, rng).astype(np.float64)
+        m = np.append(k, 1.0).reshape(3, 3)
+        assert abs(np.linalg.det(m)) > 1e-6 and abs(k[7]) < 1e-6
+        c = m @ np.array([w / 2, h / 2, 1.0])
+        c = c[:2] / c[2]
+        assert -0.25 * w <= c[0] <= 1.25 * w and -0.25 * h <= c[1] <= 1.25 * h
+    cfg.init_for_preprocess()          # preprocess_coco.py:57-58
+    assert sample_homography((h, w), cfg, rng).shape == (8,)

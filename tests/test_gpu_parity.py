@@ -832,3 +832,46 @@ def test_f4b_descriptor_sampling_geometries_on_gpu(torch_gpu, golden_dir):
         want = np.stack([ref[:, col[int(y) * w + int(x)]] for x, y in xy])
         np.testing.assert_allclose(d, want, rtol=0, atol=2e-6)
         e.close()
+
+
+def test_homography_adaptation_against_oracle_flow(torch_gpu):
+    """fpc_homography_adaptation (python/src/homographies.py:250-324) vs the oracle's restatement of the same flow
+    (oracle network, oracle warps / erosion / aggregation) on two small frames, four views, both aggregations.
+    The two forwards differ by fp32 noise and a validity mask can flip where a source coordinate lands within fp32
+    noise of a pixel boundary, so the comparison tolerates a handful of pixels."""
+    from fpc_amd.inference import HomographyConfig, sample_homography, InferenceWrapper, SuperPointSettings  # noqa: F401
+    oracle = oracle_mod()
+    h, w, n = 64, 96, 2
+    sd = synth.make_state_dict(3, dustbin_bias=2.0)
+    frames = synth.make_batch(5, n, h, w)
+    rng = np.random.default_rng(11)
+    hs = np.stack([sample_homography((h, w), HomographyConfig(), rng) for _ in range(4)])
+    e = engine(h, w, n)
+    e.load_state_dict(sd)
+    fwd = lambda f: oracle.forward(f, sd, SPEC)[0]                       # noqa: E731
+    for agg, radius in (("sum", 4), ("max", 0)):
+        got = e.homography_adaptation(frames, hs, None, radius, agg).cpu().numpy()
+        want = oracle.homography_adaptation(frames, fwd, hs, None, radius, agg)
+        bad = np.abs(got - want) > 1e-4
+        assert bad.mean() < 5e-3, (agg, float(bad.mean()))
+        assert got.shape == (n, h, w) and got.max() > 0.01
+    # the reference-style entry point (inferencewrapper.py:48-68): one point array per frame, as get_points on the maps
+    import torch
+    wrap = InferenceWrapper.__new__(InferenceWrapper)
+    wrap.name, wrap.settings = "SuperPoint", SuperPointSettings()
+    from fpc_amd.inference import SuperPoint as _SP
+    wrap.net = _SP(wrap.settings, 0, n)
+    wrap.net.load_state_dict(sd)
+    cfg = HomographyConfig()
+    cfg.num, cfg.valid_border_margin = 4, 4
+    pts = wrap.run_with_homography_adaptation(torch.from_numpy(frames), cfg, homographies=hs)
+    want = oracle.homography_adaptation(frames, fwd, hs, None, 4, "sum")
+    assert len(pts) == n
+    for i in range(n):
+        oxs, oys, oconf, _ = oracle.get_points(want[i])
+        so, sg = set(zip(oxs.tolist(), oys.tolist())), set(zip(pts[i][0].astype(int).tolist(), pts[i][1].astype(int).tolist()))
+        assert len(so & sg) >= 0.95 * max(len(so), len(sg)) and pts[i].shape[0] == 3
+    # zero views: the plain probability map
+    p0 = e.homography_adaptation(frames, np.zeros((0, 8), np.float32), None, 0, "sum").cpu().numpy()
+    np.testing.assert_allclose(p0, e.forward(frames)[0].cpu().numpy(), rtol=0, atol=1e-7)
+    e.close()

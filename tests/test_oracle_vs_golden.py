@@ -216,3 +216,22 @@ def test_f4b_get_descriptors_geometries(golden_dir):
         pts = g["c%d_pts" % i]
         out = oracle.get_descriptors(g["c%d_map" % i][0], pts[0], pts[1], h, w)
         np.testing.assert_allclose(out.T, g["c%d_out" % i], rtol=0, atol=2e-6)
+
+
+def test_f8_perspective_warp_against_torch_grid_sample(golden_dir):
+    """Fixture F8: torch.nn.functional.grid_sample on grids built by the restated torchvision perspective formula
+    (homographies.py:215-216).  Bilinear within fp32 noise; nearest identical except where the source coordinate
+    lands within fp32 noise of a pixel boundary (the grid comes out of a BLAS product in torch)."""
+    g = np.load(os.path.join(golden_dir, "f8_warp_perspective.npz"))
+    img = g["img"]
+    for i, hm in enumerate(g["homographies"]):
+        got = oracle.warp_perspective(img, hm)
+        np.testing.assert_allclose(got, g["bilinear_%d" % i], rtol=0, atol=2e-5)
+        gn = oracle.warp_perspective(img, hm, nearest=True)
+        assert np.mean(gn != g["nearest_%d" % i]) < 2e-3
+    # identity homography: the identity up to the fp32 noise of the grid arithmetic (as in torch: case 0 above)
+    np.testing.assert_allclose(oracle.warp_perspective(img, g["homographies"][0]), img, rtol=0, atol=1e-5)
+    # erosion of an all-ones plane only eats the border (constant border 0), by the ellipse's extent
+    er = oracle.erode_ellipse(np.ones((40, 56), np.float32), 4)
+    assert er[4:-4, 4:-4].all() and not er[0].any() and not er[:, 0].any()
+    assert er.sum() == (40 - 4 - 3) * (56 - 4 - 3)      # even-sized element, anchor (r, r): r rows/cols on one side, r - 1 on the other
