@@ -25,7 +25,7 @@ SYMBOLS = [
     "fpc_export_packed", "fpc_import_packed", "fpc_mark_weights_loaded", "fpc_set_stream",
     "fpc_get_stream", "fpc_sync", "fpc_forward", "fpc_detect", "fpc_get_points", "fpc_results",
     "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
-    "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation",
+    "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation", "fpc_detect_u8_resized",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     l.fpc_get_points.argtypes = [vp, vp, vp, ci]
     l.fpc_detect_u8.argtypes = [vp, vp, ci, ci]
     l.fpc_u8_staging.argtypes = [vp]
+    l.fpc_detect_u8_resized.argtypes = [vp, vp, ci, ci, ci, ci]
     l.fpc_homography_adaptation.argtypes = [vp, vp, ci, vp, vp, ci, ci, ci, vp]
     l.fpc_u8_staging.restype = vp
     l.fpc_results.argtypes = [vp, ctypes.POINTER(FpcDeviceResults)]

@@ -2265,6 +2265,34 @@ int fpc_detect_u8(fpc_ctx* c, const uint8_t* frames, int n, int layout) {
 
 const float* fpc_u8_staging(fpc_ctx* c) { return c ? c->u8stage : nullptr; }
 
+int fpc_detect_u8_resized(fpc_ctx* c, const uint8_t* frames, int n, int src_h, int src_w, int layout) {
+  if (!c || !frames || n < 1 || n > c->B || src_h < 2 || src_w < 2 || src_h > 16384 || src_w > 16384 ||
+      (layout != FPC_U8_RGB_HWC && layout != FPC_U8_BGR_HWC) || c->cin != 3)
+    return FPC_E_INVALID;
+  if (!c->weights_loaded) return FPC_E_NO_WEIGHTS;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  const size_t HW = (size_t)c->H * c->W;
+  if (!c->u8stage) HIPCHECK(hipMalloc((void**)&c->u8stage, (size_t)c->B * c->cin * HW * sizeof(float)));
+  ResizeArgs a{};
+  a.in = frames;
+  a.out = c->u8stage;
+  a.n = n; a.src_h = src_h; a.src_w = src_w; a.H = c->H; a.W = c->W;
+  // make_query_image, python/src/inference.py:72-85 (Python float = double; int() truncates)
+  const double scale_h = (double)c->H / src_h, scale_w = (double)c->W / src_w;
+  const double scale_max = scale_h > scale_w ? scale_h : scale_w;
+  a.new_w = (int)(src_w * scale_max);
+  a.new_h = (int)(src_h * scale_max);
+  if (a.new_w < c->W || a.new_h < c->H) return FPC_E_INVALID;  // the reference's crop would come out short
+  a.x0 = a.new_w / 2 - c->W / 2;
+  a.y0 = a.new_h / 2 - c->H / 2;
+  a.scale_x = 1.0 / ((double)a.new_w / src_w);   // cv::resize: inv_scale = dsize / ssize, scale = 1 / inv_scale
+  a.scale_y = 1.0 / ((double)a.new_h / src_h);
+  a.swap_rb = layout == FPC_U8_BGR_HWC;
+  const size_t tot = (size_t)n * HW;
+  hipLaunchKernelGGL(resize_crop_u8_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, a);
+  return fpc_detect(c, c->u8stage, n);
+}
+
 // 3x3 inverse of a flat homography (h[8], implicit 1), normalised back to flat form -- invert_homography,
 // python/src/homographies.py:185-209 (torch.linalg.inv in fp32 there, double here)
 static bool invert_flat_homography(const float* h, float* out) {

@@ -760,6 +760,60 @@ __global__ __launch_bounds__(256) void u8_to_float_kernel(const unsigned char* _
 }
 
 // ---------------------------------------------------------------------------------
+// Camera frame -> network input in one pass (python/src/inference.py:72-85 make_query_image after camera.py:31):
+// float32(u8) / 255, optional BGR -> RGB, ratio-preserving bilinear resize to cover the target, centre crop,
+// HWC -> CHW.  Geometry exactly as the reference computes it:
+//   scale = max(H / src_h, W / src_w);  new_w = int(src_w * scale), new_h = int(src_h * scale)   (host, double)
+//   resized = cv2.resize(img, (new_w, new_h), INTER_LINEAR);  crop at x0 = new_w // 2 - W // 2, y0 = new_h // 2 - H // 2
+// cv2.resize on float32 data (OpenCV resize.cpp, INTER_LINEAR): fx = float((dx + 0.5) * (src_w / new_w) - 0.5) with the
+// ratio in double, sx = floor(fx), clamped at both edges with weight 0; horizontal interpolation first, then vertical,
+// all in fp32.  OpenCV is absent from this image: the restatement is pinned against torch's
+// F.interpolate(bilinear, align_corners=False) -- the same sampling rule with the scale in fp32 -- within 1e-5
+// (fixture F9); PARITY with cv2 itself is unpinned.
+// ---------------------------------------------------------------------------------
+struct ResizeArgs {
+  const unsigned char* in;   // [n][src_h][src_w][3] u8
+  float* out;                // [n][3 or 1][H][W]
+  int n, src_h, src_w, H, W;
+  int new_w, new_h, x0, y0;  // resized size and crop origin
+  double scale_x, scale_y;   // src_w / new_w, src_h / new_h
+  int swap_rb;               // 1: BGR input -> RGB planes
+};
+
+__global__ __launch_bounds__(256) void resize_crop_u8_kernel(const ResizeArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t HW = (size_t)a.H * a.W;
+  if (i >= (size_t)a.n * HW) return;
+  const int f = i / HW;
+  const int r = i - (size_t)f * HW;
+  const int oy = r / a.W, ox = r - oy * a.W;
+  const int dx = ox + a.x0, dy = oy + a.y0;
+  float fx = (float)(((double)dx + 0.5) * a.scale_x - 0.5), fy = (float)(((double)dy + 0.5) * a.scale_y - 0.5);
+  int sx = (int)floorf(fx), sy = (int)floorf(fy);
+  fx -= (float)sx;
+  fy -= (float)sy;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= a.src_w - 1) { fx = 0.f; sx = a.src_w - 1; }
+  if (sy < 0) { fy = 0.f; sy = 0; }
+  if (sy >= a.src_h - 1) { fy = 0.f; sy = a.src_h - 1; }
+  const int sx1 = sx + 1 < a.src_w ? sx + 1 : sx, sy1 = sy + 1 < a.src_h ? sy + 1 : sy;
+  const unsigned char* base = a.in + (size_t)f * a.src_h * a.src_w * 3;
+  const unsigned char* p00 = base + ((size_t)sy * a.src_w + sx) * 3;
+  const unsigned char* p01 = base + ((size_t)sy * a.src_w + sx1) * 3;
+  const unsigned char* p10 = base + ((size_t)sy1 * a.src_w + sx) * 3;
+  const unsigned char* p11 = base + ((size_t)sy1 * a.src_w + sx1) * 3;
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = a.swap_rb ? 2 - c : c;
+    const float v00 = (float)p00[sc] / 255.0f, v01 = (float)p01[sc] / 255.0f;
+    const float v10 = (float)p10[sc] / 255.0f, v11 = (float)p11[sc] / 255.0f;
+    const float r0 = __fmaf_rn(v01, a1, v00 * a0), r1 = __fmaf_rn(v11, a1, v10 * a0);   // HResizeLinear
+    a.out[((size_t)f * 3 + c) * HW + r] = __fmaf_rn(r1, b1, r0 * b0);                      // VResizeLinear
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Kernels only the reference's C++ network needs (superpoint::SPModel, cpp/src/model.cc).
 // ---------------------------------------------------------------------------------
 // encoder_conv0_a: Conv2d(1, 64, 3, padding 1) + bias + ReLU on a gray frame (model.cc:66-68).  K = 9 is no

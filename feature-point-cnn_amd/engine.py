@@ -174,6 +174,19 @@ class Engine:
         self.detect_u8_async(f, f.shape[0], layout)
         return self.fetch(f.shape[0])
 
+    def detect_u8_resized(self, frames_u8, layout="bgr_hwc"):
+        """make_query_image (python/src/inference.py:72-85) + camera.py:31 on the device: uint8 [n,h,w,3] camera frames
+        of any size -> resized to cover this engine's H x W, centre-cropped, converted, detected."""
+        if not isinstance(frames_u8, torch.Tensor):
+            frames_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8, dtype=np.uint8))
+        f = frames_u8.to(self.torch_device, torch.uint8).contiguous()
+        if f.dim() != 4 or f.shape[3] != 3 or f.shape[0] > self.max_batch or layout not in ("rgb_hwc", "bgr_hwc"):
+            raise ValueError("frames must be uint8 [n<=%d,h,w,3] in rgb_hwc / bgr_hwc layout" % self.max_batch)
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_detect_u8_resized(self._ctx, f.data_ptr(), f.shape[0], f.shape[1], f.shape[2],
+                                                 self.U8_LAYOUTS[layout]), "fpc_detect_u8_resized")
+        return self.fetch(f.shape[0])
+
     def u8_staging(self, n):
         """The float frames [n,C,H,W] the last detect_u8 call fed to the network (a copy)."""
         self.sync()

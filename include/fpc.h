@@ -164,7 +164,14 @@ int fpc_detect(fpc_ctx* ctx, const float* frames_dev, int n);
  * Resizing (cv2.resize, inference.py:72-85) is not done here. */
 enum { FPC_U8_GRAY = 0, FPC_U8_RGB_HWC = 1, FPC_U8_BGR_HWC = 2, FPC_U8_BGR_HWC_GRAY = 3 };
 int fpc_detect_u8(fpc_ctx* ctx, const uint8_t* frames_dev, int n, int layout);
-/* The converted float frames of the last fpc_detect_u8 call ([n,C,H,W], device) -- for tests. */
+/* Camera frames of another size: make_query_image (python/src/inference.py:72-85) on the device, fused with the
+ * conversion above -- ratio-preserving bilinear resize so that the frame covers the ctx's H x W (new size
+ * int(src * max(H/src_h, W/src_w)) per axis), centre crop, /255, optional BGR -> RGB, HWC -> CHW -- then fpc_detect.
+ * frames_dev [n,src_h,src_w,3] u8; layout FPC_U8_RGB_HWC or FPC_U8_BGR_HWC; a 3-channel ctx.  The bilinear rule
+ * restates cv2.resize(INTER_LINEAR) on float32 data; pinned against torch's F.interpolate (same rule), not against
+ * OpenCV (absent from this build). */
+int fpc_detect_u8_resized(fpc_ctx* ctx, const uint8_t* frames_dev, int n, int src_h, int src_w, int layout);
+/* The converted float frames of the last fpc_detect_u8 / fpc_detect_u8_resized call ([n,C,H,W], device) -- for tests. */
 const float* fpc_u8_staging(fpc_ctx* ctx);
 
 /* ~ homography_adaptation (python/src/homographies.py:250-324; the caller is

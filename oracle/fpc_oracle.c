@@ -734,3 +734,46 @@ void oracle_erode_ellipse(const float* in, int H, int W, int r, float* out) {
       out[(size_t)y * W + x] = m;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * make_query_image (python/src/inference.py:72-85) applied to a camera.py:31 frame: the checker of
+ * fpc_detect_u8_resized.  u8 HWC frame -> /255 -> optional BGR->RGB -> cv2.resize(INTER_LINEAR) to
+ * (new_w, new_h) = (int(w s), int(h s)), s = max(H/h, W/w) -> centre crop H x W -> CHW.
+ * cv2.resize on float32 (OpenCV 4.x resize.cpp: coordinates from the size ratio in double, floor, both edges clamped
+ * with weight 0, horizontal pass then vertical pass in fp32) is restated; OpenCV is absent here, so the restatement
+ * is pinned against torch.nn.functional.interpolate(bilinear, align_corners=False) -- the same sampling rule --
+ * within 1e-5 (fixture F9) and PARITY WITH cv2 ITSELF IS UNPINNED.
+ * ------------------------------------------------------------------------------------------- */
+int oracle_resize_crop_u8(const uint8_t* in, int n, int src_h, int src_w, int H, int W, int swap_rb, float* out) {
+  const double scale_h = (double)H / src_h, scale_w = (double)W / src_w;
+  const double scale_max = scale_h > scale_w ? scale_h : scale_w;
+  const int new_w = (int)(src_w * scale_max), new_h = (int)(src_h * scale_max);
+  if (new_w < W || new_h < H) return -1;
+  const int x0 = new_w / 2 - W / 2, y0 = new_h / 2 - H / 2;
+  const double sx_ = 1.0 / ((double)new_w / src_w), sy_ = 1.0 / ((double)new_h / src_h);
+  for (int f = 0; f < n; ++f)
+    for (int oy = 0; oy < H; ++oy)
+      for (int ox = 0; ox < W; ++ox) {
+        float fx = (float)(((double)(ox + x0) + 0.5) * sx_ - 0.5), fy = (float)(((double)(oy + y0) + 0.5) * sy_ - 0.5);
+        int sx = (int)floorf(fx), sy = (int)floorf(fy);
+        fx -= (float)sx;
+        fy -= (float)sy;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= src_w - 1) { fx = 0.f; sx = src_w - 1; }
+        if (sy < 0) { fy = 0.f; sy = 0; }
+        if (sy >= src_h - 1) { fy = 0.f; sy = src_h - 1; }
+        const int sx1 = sx + 1 < src_w ? sx + 1 : sx, sy1 = sy + 1 < src_h ? sy + 1 : sy;
+        const uint8_t* base = in + (size_t)f * src_h * src_w * 3;
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        for (int c = 0; c < 3; ++c) {
+          const int sc = swap_rb ? 2 - c : c;
+          const float v00 = (float)base[((size_t)sy * src_w + sx) * 3 + sc] / 255.0f;
+          const float v01 = (float)base[((size_t)sy * src_w + sx1) * 3 + sc] / 255.0f;
+          const float v10 = (float)base[((size_t)sy1 * src_w + sx) * 3 + sc] / 255.0f;
+          const float v11 = (float)base[((size_t)sy1 * src_w + sx1) * 3 + sc] / 255.0f;
+          const float r0 = fmaf(v01, a1, v00 * a0), r1 = fmaf(v11, a1, v10 * a0);
+          out[(((size_t)f * 3 + c) * H + oy) * W + ox] = fmaf(r1, b1, r0 * b0);
+        }
+      }
+  return 0;
+}

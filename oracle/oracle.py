@@ -224,3 +224,14 @@ def homography_adaptation(frames, forward_fn, homographies, inverses=None, erosi
     stack = np.stack(probs, -1)
     agg = stack.max(-1) if aggregation == "max" else stack.sum(-1, dtype=np.float32) / total[None]
     return np.where(total[None] >= len(homographies) // 3, agg, 0.0).astype(np.float32)
+
+
+def resize_crop_u8(frames_u8, h, w, swap_rb=False):
+    """make_query_image (inference.py:72-85) on camera.py:31 frames: uint8 [n,sh,sw,3] -> float32 [n,3,h,w]."""
+    a = np.ascontiguousarray(frames_u8, np.uint8)
+    n, sh, sw, _ = a.shape
+    out = np.empty((n, 3, h, w), np.float32)
+    rc = lib().oracle_resize_crop_u8(a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n, sh, sw, h, w, int(bool(swap_rb)), _p(out))
+    if rc != 0:
+        raise ValueError("target larger than the resized frame")
+    return out

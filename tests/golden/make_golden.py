@@ -319,6 +319,32 @@ def golden_warp():
     print("F8 warp cases:", len(hs))
 
 
+def golden_query_image():
+    """F9: make_query_image (python/src/inference.py:72-85) on camera.py:31 frames with torch's
+    F.interpolate(mode='bilinear', align_corners=False) standing in for cv2.resize(INTER_LINEAR) (cv2 is not installed;
+    on float32 data both apply the same rule: source = (dst + 0.5) * ratio - 0.5, edges clamped) -- geometry, colour
+    swap, crop and layout exactly as the reference's code."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    out = {}
+    for i, (sh, sw, th, tw) in enumerate([(72, 96, 48, 64), (60, 128, 48, 64), (100, 90, 64, 48), (37, 53, 32, 48)]):
+        frame_u8 = rng.integers(0, 256, size=(sh, sw, 3), dtype=np.uint8)           # BGR as cv2.VideoCapture delivers
+        frame = frame_u8.astype('float32') / 255.0                                   # camera.py:31
+        img_h, img_w, _ = frame.shape                                                # inference.py:74-85, img_size = (tw, th)
+        scale_max = max(th / img_h, tw / img_w)
+        new_size = [int(img_w * scale_max), int(img_h * scale_max)]
+        query = frame[..., ::-1]                                                     # cv2.COLOR_BGR2RGB
+        t = torch.from_numpy(np.ascontiguousarray(query.transpose(2, 0, 1))[None])
+        resized = torch.nn.functional.interpolate(t, size=(new_size[1], new_size[0]), mode="bilinear", align_corners=False)
+        x = new_size[0] // 2 - tw // 2
+        y = new_size[1] // 2 - th // 2
+        crop = resized[0, :, y:y + th, x:x + tw].numpy()                             # CHW, as prepare_input makes it
+        out["c%d_frame" % i] = frame_u8
+        out["c%d_hw" % i] = np.array([th, tw], np.int32)
+        out["c%d_out" % i] = crop
+    np.savez_compressed(os.path.join(HERE, "f9_query_image.npz"), **out)
+    print("F9 query image cases: 4")
+
+
 def golden_u8():
     """F6: the reference's 8-bit -> float conversion, evaluated by the libraries the reference calls, for all
     256 byte values: `frame.astype('float32') / 255.0` (python/src/camera.py:31; dataset_utils.py:23 is the
@@ -342,6 +368,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         golden_u8()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "f9":
+        golden_query_image()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f8":
         golden_warp()
         sys.exit(0)
@@ -360,5 +389,6 @@ if __name__ == "__main__":
     golden_get_points_random()
     golden_get_descriptors_random()
     golden_warp()
+    golden_query_image()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

@@ -875,3 +875,35 @@ def test_homography_adaptation_against_oracle_flow(torch_gpu):
     p0 = e.homography_adaptation(frames, np.zeros((0, 8), np.float32), None, 0, "sum").cpu().numpy()
     np.testing.assert_allclose(p0, e.forward(frames)[0].cpu().numpy(), rtol=0, atol=1e-7)
     e.close()
+
+
+def test_resized_camera_frames_on_device(torch_gpu, golden_dir):
+    """fpc_detect_u8_resized: make_query_image (inference.py:72-85) fused with the 8-bit conversion -- bit-exact against
+    the oracle (itself held to torch's F.interpolate by fixture F9), on the fixture's frames and on a 720p-like frame
+    resized to the engine's VGA; keypoints equal fpc_detect on the converted frames."""
+    oracle = oracle_mod()
+    g = np.load(os.path.join(golden_dir, "f9_query_image.npz"))
+    sd = synth.make_state_dict(3, dustbin_bias=2.0)
+    for i in (0, 1, 2, 3):
+        th, tw = [int(v) for v in g["c%d_hw" % i]]
+        if th % 16 or tw % 16:
+            continue
+        e = engine(th, tw, 2)
+        e.load_state_dict(sd)
+        fr = np.stack([g["c%d_frame" % i], g["c%d_frame" % i][::-1].copy()])
+        res = e.detect_u8_resized(fr, "bgr_hwc")
+        want = oracle.resize_crop_u8(fr, th, tw, swap_rb=True)
+        np.testing.assert_array_equal(e.u8_staging(2).cpu().numpy(), want)
+        np.testing.assert_allclose(want[0], g["c%d_out" % i], rtol=0, atol=1e-5)
+        ref = e.detect(want)
+        for a, b in zip(res, ref):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+        e.close()
+    rng = np.random.Generator(np.random.PCG64(4))
+    cam = rng.integers(0, 256, size=(1, 360, 640, 3), dtype=np.uint8)        # 16:9 camera frame -> 4:3 network input
+    e = engine(240, 320, 1)
+    e.load_state_dict(sd)
+    e.detect_u8_resized(cam, "rgb_hwc")
+    np.testing.assert_array_equal(e.u8_staging(1).cpu().numpy(), oracle.resize_crop_u8(cam, 240, 320, swap_rb=False))
+    e.close()

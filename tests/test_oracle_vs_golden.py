@@ -235,3 +235,14 @@ def test_f8_perspective_warp_against_torch_grid_sample(golden_dir):
     er = oracle.erode_ellipse(np.ones((40, 56), np.float32), 4)
     assert er[4:-4, 4:-4].all() and not er[0].any() and not er[:, 0].any()
     assert er.sum() == (40 - 4 - 3) * (56 - 4 - 3)      # even-sized element, anchor (r, r): r rows/cols on one side, r - 1 on the other
+
+
+def test_f9_query_image_resize_crop(golden_dir):
+    """Fixture F9: make_query_image (inference.py:72-85) with torch's F.interpolate as the bilinear resize: geometry,
+    BGR->RGB, crop and CHW layout of oracle_resize_crop_u8; values within the fp32 noise of the coordinate arithmetic
+    (OpenCV forms the size ratio in double, torch in fp32)."""
+    g = np.load(os.path.join(golden_dir, "f9_query_image.npz"))
+    for i in range(4):
+        th, tw = [int(v) for v in g["c%d_hw" % i]]
+        got = oracle.resize_crop_u8(g["c%d_frame" % i][None], th, tw, swap_rb=True)[0]
+        np.testing.assert_allclose(got, g["c%d_out" % i], rtol=0, atol=1e-5, err_msg="case %d" % i)
