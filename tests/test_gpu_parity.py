@@ -907,3 +907,77 @@ def test_resized_camera_frames_on_device(torch_gpu, golden_dir):
     e.detect_u8_resized(cam, "rgb_hwc")
     np.testing.assert_array_equal(e.u8_staging(1).cpu().numpy(), oracle.resize_crop_u8(cam, 240, 320, swap_rb=False))
     e.close()
+
+
+def test_random_geometries_and_settings(torch_gpu):
+    """Seeded sweep over frame sizes that do not divide into the kernels' tiles (8x16, 6x20, 3x20 pixels; 1/8 and
+    1/16 resolution maps down to 2 x 3 cells), batch sizes, arithmetic modes and post-processing settings: dense maps
+    within 1e-4 of the oracle, post-processing exact on the engine's own maps."""
+    oracle = oracle_mod()
+    rng = np.random.Generator(np.random.PCG64(2718))
+    sizes = [(32, 48), (48, 80), (80, 48), (112, 176), (96, 320), (176, 64), (144, 208), (64, 336)]
+    for case in range(16):
+        h, w = sizes[case % len(sizes)]
+        n = int(rng.integers(1, 6))
+        dtype = ["f32", "f32_split", "f32_split_f16"][case % 3]
+        de = bool(case % 4 != 3)
+        nms, border = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+        thr = float(rng.choice([0.005, 0.015, 0.05]))
+        sd = synth.make_state_dict(100 + case, dustbin_bias=float(rng.choice([2.0, 4.0])))
+        frames = synth.make_batch(1000 + 10 * case, n, h, w)
+        e = engine(h, w, n, dtype=dtype, descriptor_enabled=de, nms_dist=nms, border_remove=border, conf_thresh=thr)
+        e.load_state_dict(sd if de else {k: v for k, v in sd.items() if not k.startswith("descriptor.")})
+        prob, desc, logits = e.forward(frames)
+        res = e.detect(frames)
+        i = int(rng.integers(0, n))
+        o_prob, o_desc, o_logits = oracle.forward(frames[i:i + 1], sd, SPEC, descriptor_enabled=de)
+        tag = "case %d: %dx%d n=%d %s de=%d" % (case, h, w, n, dtype, de)
+        assert np.max(np.abs(logits[i].cpu().numpy() - o_logits[0])) < ATOL, tag
+        assert np.max(np.abs(prob[i].cpu().numpy() - o_prob[0])) < ATOL, tag
+        if de:
+            assert np.max(np.abs(desc[i].cpu().numpy() - o_desc[0])) < ATOL, tag
+        pm = prob[i].cpu().numpy()
+        oxs, oys, oconf, oncand = oracle.get_points(pm, conf_thresh=thr, nms_dist=nms, border_remove=border)
+        xy, conf, d, ncand = res[i]
+        assert ncand == oncand, tag
+        np.testing.assert_array_equal(xy[:, 0], oxs, err_msg=tag)
+        np.testing.assert_array_equal(xy[:, 1], oys, err_msg=tag)
+        np.testing.assert_array_equal(conf, oconf, err_msg=tag)
+        if de and len(oxs):
+            od = oracle.get_descriptors(desc[i].cpu().numpy(), oxs, oys, h, w)
+            finite = np.isfinite(od).all(axis=1)          # an all-zero sampled vector normalises to NaN, as in the reference
+            np.testing.assert_allclose(d[finite], od[finite], rtol=0, atol=2e-6, err_msg=tag)
+        e.close()
+
+
+def test_random_geometries_other_networks_and_modes(torch_gpu):
+    """The same sweep for the C++ network (all three fp32-class modes, against oracle_vgg_forward) and, for bounds
+    safety, the bf16 mode (agreement with the fp32 path at bf16 accuracy)."""
+    oracle = oracle_mod()
+    vspec = arch.vgg_state_dict_spec()
+    for case, (h, w) in enumerate([(40, 56), (72, 136), (104, 48), (24, 200)]):
+        sd = synth.make_vgg_state_dict(40 + case, 3.0)
+        fr = _gray(600 + case, 2, h, w)
+        o_prob, o_desc, o_logits = oracle.vgg_forward(fr[1:2], sd, vspec)
+        for dtype in ("f32", "f32_split", "f32_split_f16"):
+            e = engine(h, w, 2, in_channels=1, arch="vgg", dtype=dtype)
+            e.load_state_dict(sd)
+            prob, desc, logits = e.forward(fr)
+            tag = "vgg %dx%d %s" % (h, w, dtype)
+            assert np.max(np.abs(logits[1].cpu().numpy() - o_logits[0])) < ATOL, tag
+            assert np.max(np.abs(desc[1].cpu().numpy() - o_desc[0])) < ATOL, tag
+            res = e.detect(fr)
+            _check_frame_against_oracle_postproc(oracle, prob[1].cpu().numpy(), desc[1].cpu().numpy(), res[1], h, w)
+            e.close()
+    for case, (h, w) in enumerate([(48, 80), (112, 176), (176, 64)]):
+        sd = synth.make_state_dict(70 + case, dustbin_bias=2.0)
+        fr = synth.make_batch(800 + case, 3, h, w)
+        a = engine(h, w, 3)
+        a.load_state_dict(sd)
+        b = engine(h, w, 3, dtype="bf16")
+        b.load_state_dict(sd)
+        la, lb = a.forward(fr)[2], b.forward(fr)[2]
+        assert float((la - lb).abs().max()) < BF16_LOGIT_MAX, (h, w)
+        assert len(b.detect(fr)) == 3
+        a.close()
+        b.close()
