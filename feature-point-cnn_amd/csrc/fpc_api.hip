@@ -253,6 +253,7 @@ struct Op {
   FKind fkind = FK_COUNT;
   BlockBfArgs fargs{};
   int phase = -1;              // ConvTranspose output-parity phase of a bf16 conv-only op
+  int when = 0;                // 0: always; 1: only in calls of a few frames; 2: only in larger calls
   bool wconv = false;          // conv-only Winograd launch: 3x3 conv + (BN or bias) + ReLU, output channels n0 .. n0+127
   int n0 = 0;
   bool plain_conv = false;     // a Conv2d + bias (+ ReLU) of the C++ network: weights `prefix`.weight / .bias, no BN
@@ -1183,6 +1184,12 @@ static int build_plan(fpc_ctx* c) {
       t.out = c->y16b; t.cso = 256; t.cout = 256; t.nstore = 256; t.Ho = H16; t.Wo = W16; t.relu = 1;
       t.desc_branch = true;
       add_conv(c, t, &bo);
+      for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
+      // a call of a few frames has 12 tiles per frame here: three dependent launches cost more latency than they save
+      // work, so small calls take the fused direct block instead (its weights sit in the blob next to the others)
+      block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
+            c->h16, 256, 256, 256, c->y16b, 256, false, true, BK_B320_s1_K64_C256);
+      c->ops.back().when = 1;
     } else
     block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
           c->h16, 256, 256, 256, c->y16b, 256, false, true, BK_B320_s1_K64_C256);
@@ -1640,6 +1647,7 @@ static hipEvent_t next_event(fpc_ctx* c) {
 
 struct Sub {
   int f0, n;
+  bool small = false;              // the whole call is a few frames: the latency plan (heads side by side, fused layer_in.1)
   hipStream_t st;                  // encoder, descriptor head, descriptor sampling
   hipStream_t side = nullptr;      // detector head + NMS, concurrent with the descriptor head
   hipEvent_t ev_enc = nullptr, ev_det = nullptr;
@@ -1681,6 +1689,8 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
     const Op& op = c->ops[i];
     const int br = op.descriptor_branch ? 2 : (op.name.compare(0, 8, "detector") == 0 ? 1 : 0);
     if (br != which) continue;
+    if (op.when == 1 && !sb.small) continue;   // variants of a layer for small / large calls
+    if (op.when == 2 && sb.small) continue;
     switch (op.type) {
       case OP_STEM: {
         if (c->fuse_stem_pool || c->cin == 1 || c->bf16) {
@@ -1900,8 +1910,14 @@ static int for_each_sub(fpc_ctx* c, int n, F&& body) {
     Sub sb;
     sb.f0 = f0;
     sb.n = cnt;
+    sb.small = n < 2 * c->min_sub;
     sb.st = p == 0 ? c->stream : c->aux[p - 1];
     sb.side = c->side[p];
+    // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES) in creation order, and two
+    // streams on one queue run in order: with main, aux1, aux2, side0 the side stream shared the main stream's queue
+    // and a single frame's heads no longer overlapped (0.81 instead of 0.62 ms in the split mode).  A call of a few
+    // frames has one sub-batch, so the first aux stream -- created right behind the main stream -- is idle: use it.
+    if (sb.small && !c->aux.empty()) sb.side = c->aux[0];
     sb.ev_enc = c->ev_enc[p];
     sb.ev_det = c->ev_det[p];
     if (p) HIPCHECK(hipStreamWaitEvent(sb.st, c->ev_fork, 0));
@@ -1921,7 +1937,7 @@ static int for_each_sub(fpc_ctx* c, int n, F&& body) {
 // encoder output.  `upto`: 0 = dense maps only (fpc_forward), 1 = keypoints + descriptors.
 static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, int upto) {
   run_network(c, frames, sb, 0, sb.st);
-  if (de && upto && c->nms_aside) {
+  if (de && upto && c->nms_aside && !sb.small && sb.side) {
     // detector head and softmax in line; the (latency-bound, few-CU) NMS on the side stream next to the descriptor head
     run_network(c, frames, sb, 1, sb.st);
     run_softmax(c, sb);
@@ -1934,7 +1950,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, in
     run_desc(c, sb, c->desc_map);
     return;
   }
-  if (!de || !c->split_heads) {
+  if (!de || !(c->split_heads || sb.small) || !sb.side) {
     run_network(c, frames, sb, 1, sb.st);
     run_softmax(c, sb);
     if (upto) run_nms(c, sb);
@@ -2071,10 +2087,12 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->nms_aside = !c->split;  // measured: +1.5 % with two sub-batches (fp32-MFMA kernels), nothing with three (split modes)
     if (const char* e = getenv("FPC_NMS_ASIDE")) c->nms_aside = atoi(e) != 0;
     if (c->split_heads) c->nms_aside = false;
+    // one side stream per sub-batch only while main + aux + side <= 4 streams, otherwise just the first
+    const int nside = 2 * nsub <= 4 ? nsub : 1;
     for (int i = 0; i < nsub; ++i) {
-      hipStream_t st;
+      hipStream_t st = nullptr;
       hipEvent_t e1, e2;
-      HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      if (i < nside) HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
       c->side.push_back(st);
@@ -2124,7 +2142,8 @@ void fpc_destroy(fpc_ctx* c) {
   for (auto e : c->event_pool) hipEventDestroy(e);
   for (auto e : c->ev_join) hipEventDestroy(e);
   for (auto st : c->aux) hipStreamDestroy(st);
-  for (auto st : c->side) hipStreamDestroy(st);
+  for (auto st : c->side)
+    if (st) hipStreamDestroy(st);
   for (auto e : c->ev_enc) hipEventDestroy(e);
   for (auto e : c->ev_det) hipEventDestroy(e);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
