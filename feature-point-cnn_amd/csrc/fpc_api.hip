@@ -301,7 +301,7 @@ struct fpc_ctx {
   bool nms_aside = true;             // FPC_NMS_ASIDE=0: NMS in line on the sub-batch stream
   bool split_heads = false;          // FPC_SPLIT_HEADS=1: detector head + NMS of a sub-batch on a side stream next to its descriptor head
   hipEvent_t ev_fork = nullptr;
-  int min_sub = 4;                   // smallest sub-batch worth its own stream
+  int min_sub = 8;                   // smallest sub-batch worth its own stream (FPC_MIN_SUB); calls below twice this take the latency plan
   int num_cus = 256;
   int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
   int nms_passes = 2;
@@ -2068,6 +2068,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
+    if (const char* e = getenv("FPC_MIN_SUB")) c->min_sub = std::max(1, atoi(e));
     if (const char* e = getenv("FPC_PERSIST_MIN")) c->persist_min_tiles = atoi(e);
     if (const char* e = getenv("FPC_WINOGRAD_DET")) c->winograd_det = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD_IN1")) c->winograd_in1 = atoi(e) != 0;
