@@ -7,7 +7,9 @@
  *
  * Parity pin: the restatement is checked against golden vectors produced by
  * importing the reference's own python modules (tests/golden/make_golden.py,
- * fixtures under tests/golden/); see tests/test_oracle_vs_golden.py.
+ * fixtures under tests/golden/); see tests/test_oracle_vs_golden.py.  The few pieces whose arithmetic lives in
+ * libraries absent from the reference tree and from this image (OpenCV's matcher / cvtColor / resize / erode,
+ * torchvision's perspective grid) say PARITY UNPINNED at their definition, with what they ARE checked against.
  *
  * Every function cites the reference lines (relative to /root/reference) whose
  * arithmetic it restates.  Tensors are NCHW float32 exactly as the reference

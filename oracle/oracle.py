@@ -1,7 +1,7 @@
 """ctypes binding of oracle/fpc_oracle.c -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
-module; the product package never does (tests/test_no_oracle_in_product.py).
+module; the product package never does (tests/test_abi_and_host.py::test_product_never_imports_the_oracle).
 """
 import ctypes
 import os
