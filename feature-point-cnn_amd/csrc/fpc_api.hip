@@ -304,6 +304,7 @@ struct fpc_ctx {
   int min_sub = 8;                   // smallest sub-batch worth its own stream (FPC_MIN_SUB); calls below twice this take the latency plan
   int num_cus = 256;
   int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
+  bool xcd_order = true;             // FPC_XCD_ORDER=0: plain tile order in the persistent Winograd kernel
   int nms_passes = 2;
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
@@ -1768,6 +1769,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
           }
 #endif
         a.total = a.tiles_x * a.tiles_y * n;
+        a.xcd_order = c->xcd_order ? 1 : 0;
         // persistent (one workgroup per CU walking the tiles) when a workgroup gets enough tiles to
         // amortise; otherwise one workgroup per tile
         const int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
@@ -2068,6 +2070,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
+    if (const char* e = getenv("FPC_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
     if (const char* e = getenv("FPC_MIN_SUB")) c->min_sub = std::max(1, atoi(e));
     if (const char* e = getenv("FPC_PERSIST_MIN")) c->persist_min_tiles = atoi(e);
     if (const char* e = getenv("FPC_WINOGRAD_DET")) c->winograd_det = atoi(e) != 0;

@@ -30,6 +30,7 @@ struct WBlockArgs {
   float* out;
   int cso, tiles_x, tiles_y, frame0;
   int total;             // tiles_x * tiles_y * frames of this launch; the grid is persistent
+  int xcd_order;         // 1: XCD-aware tile order (see the kernel)
   int conv_only;         // 1: stop after h = relu(conv3x3(x) + b1) and store it (a plain Conv2d + bias/BN + ReLU:
                          // the layers of the C++ network, conv1 of a block too wide to fuse); w2 / b2 unused
 #ifdef FPC_DIAG
@@ -113,8 +114,17 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     return wbase + (size_t)(chunk * 16 * K8 + ls) * stepstride;
   };
 
-  if ((int)blockIdx.x < a.total) load_chunk(blockIdx.x, 0);
-  for (int wg = blockIdx.x; wg < a.total; wg += gridDim.x) {
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2.
+  // XCD k walks the contiguous tile range [k * chunk, (k + 1) * chunk): neighbouring tiles -- which share halo rows
+  // -- and the frames' weights stay in ONE L2 instead of being fetched by all eight.  (Only when the grid is a
+  // multiple of 8, i.e. in the persistent case; otherwise the plain order.)
+  const bool xcd_order = a.xcd_order && (gridDim.x & 7) == 0;
+  const int wg_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int xchunk = (a.total + 7) >> 3;
+  const int wg_first = xcd_order ? (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int wg_end = xcd_order ? min(a.total, ((int)(blockIdx.x & 7) + 1) * xchunk) : a.total;
+  if (wg_first < wg_end) load_chunk(wg_first, 0);
+  for (int wg = wg_first; wg < wg_end; wg += wg_step) {
   const int bl = wg / tiles;
   const int b = a.frame0 + bl;
   const int t = wg - bl * tiles;
@@ -148,9 +158,9 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     FPC_LDS_BARRIER();   // previous chunk's GEMM is done with V / previous tile's epilogue with the LDS
     store_chunk();
     FPC_LDS_BARRIER();
-    if (chunk == 0 && wg == (int)blockIdx.x) { FPC_STAMP(6) }
+    if (chunk == 0 && wg == wg_first) { FPC_STAMP(6) }
     if (chunk + 1 < a.nchunk) load_chunk(wg, chunk + 1);
-    else if (wg + (int)gridDim.x < a.total) load_chunk(wg + gridDim.x, 0);
+    else if (wg + wg_step < wg_end) load_chunk(wg + wg_step, 0);
     {
       // input transform V = B^T d B for (tile, channel pair): 512 items = 32 tiles x KC/2 pairs (KC = 32)
       const float2* halo2 = reinterpret_cast<const float2*>(halo4);
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
     FPC_LDS_BARRIER();
-    if (chunk == 0 && wg == (int)blockIdx.x) { FPC_STAMP(1) }
+    if (chunk == 0 && wg == wg_first) { FPC_STAMP(1) }
     // 16 GEMMs, one 32-row block each: this wave's PX positions x NBW channel blocks
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
@@ -217,9 +227,9 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
         }
       }
     }
-    if (chunk == 0 && wg == (int)blockIdx.x) { FPC_STAMP(7) }
+    if (chunk == 0 && wg == wg_first) { FPC_STAMP(7) }
   }
-  if (wg == (int)blockIdx.x) { FPC_STAMP(2) }
+  if (wg == wg_first) { FPC_STAMP(2) }
 
   // ---------------------------------------------------------------- output transform -> h (LDS)
   const int lane_t = tid_t & 63, l31_t = lane_t & 31, half_t = lane_t >> 5, wave_t = tid_t >> 6;
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     }
   }
   FPC_LDS_BARRIER();
-  if (wg == (int)blockIdx.x) { FPC_STAMP(3) }
+  if (wg == wg_first) { FPC_STAMP(3) }
   if (a.conv_only) {  // h is the result: [128 px][CMID] in LDS -> 16-byte stores
     constexpr int C4S = CMID / 4;
     constexpr int NES = TH * TW * C4S, EITS = (NES + NT - 1) / NT;
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
   }
-  if (wg == (int)blockIdx.x) { FPC_STAMP(4) }
+  if (wg == wg_first) { FPC_STAMP(4) }
 
   // ---------------------------------------------------------------- epilogue (as block_mfma.h)
   FPC_LDS_BARRIER();  // every wave_t is done reading h
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
   }
-  if (wg == (int)blockIdx.x) { FPC_STAMP(5) }
+  if (wg == wg_first) { FPC_STAMP(5) }
   }  // persistent tile loop
 }
 
