@@ -78,9 +78,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bl = blockIdx.x / tiles;
+  const int bidx = fpc_xcd_tile_index();
+  const int bl = bidx / tiles;
   const int b = a.frame0 + bl;
-  const int t = blockIdx.x - bl * tiles;
+  const int t = bidx - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
 
   int abase[MB];

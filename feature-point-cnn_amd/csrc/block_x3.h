@@ -126,9 +126,10 @@ __device__ __forceinline__ void block_split_body(const BlockBfArgs& a) {
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bl = blockIdx.x / tiles;
+  const int bidx = fpc_xcd_tile_index();
+  const int bl = bidx / tiles;
   const int b = a.frame0 + bl;
-  const int t = blockIdx.x - bl * tiles;
+  const int t = bidx - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   const float* __restrict__ xin = static_cast<const float*>(a.x);
 

@@ -24,6 +24,15 @@
 
 namespace fpc {
 
+// XCD-aware workgroup order for one-tile-per-workgroup launches: the dispatcher deals workgroups round-robin to the
+// 8 XCDs (blockIdx.x & 7), each with its own L2.  Returning (blockIdx.x & 7) * (grid / 8) + (blockIdx.x >> 3) gives
+// XCD k the contiguous tile range [k * grid / 8, (k + 1) * grid / 8): neighbouring tiles -- which share halo rows --
+// meet in one L2.  A bijection when the grid is a multiple of 8; otherwise the plain order.
+__device__ __forceinline__ int fpc_xcd_tile_index() {
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  return (g & 7u) == 0u ? (int)((b & 7u) * (g >> 3) + (b >> 3)) : (int)b;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, not for its global
@@ -89,9 +98,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArg
   const int half = lane >> 5, l31 = lane & 31;
 
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bl = blockIdx.x / tiles;
+  const int bidx = fpc_xcd_tile_index();
+  const int bl = bidx / tiles;
   const int b = a.frame0 + bl;
-  const int t = blockIdx.x - bl * tiles;
+  const int t = bidx - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   // sub-problems (ConvTranspose parity phases) are dispatched heaviest first: blockIdx.z = 0 is
   // the last sub-problem (4 taps), so the short ones fill the tail of the launch
