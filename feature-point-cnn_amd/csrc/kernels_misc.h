@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int b = blockIdx.x / tiles;
-  const int t = blockIdx.x - b * tiles;
+  const int bidx = fpc_xcd_tile_index();   // neighbouring tiles complete each other's border windows with atomics: keep them in one L2
+  const int b = bidx / tiles;
+  const int t = bidx - b * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
 
