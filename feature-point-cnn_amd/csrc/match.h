@@ -27,6 +27,19 @@ struct MatchArgs {
 };
 
 __global__ __launch_bounds__(256) void match_gemm_kernel(const MatchArgs a) {
+  // per-workgroup arg-min tables: the four waves of a 128 x 128 tile reduce into LDS first, then ONE global 64-bit
+  // atomicMin per row and per column of the tile
+  __shared__ unsigned long long s_row[128], s_col[128];
+  __shared__ unsigned int s_first[128];
+  // each wave's 64 x 64 tile of squared distances (pitch 68 floats): the arg-min over a row / a column is then a
+  // plain loop of one lane over LDS instead of a 64-bit butterfly of cross-lane shuffles per accumulator row
+  __shared__ __attribute__((aligned(16))) float s_d2[4][64 * 68];
+  if (threadIdx.x < 128) {
+    s_row[threadIdx.x] = ~0ull;
+    s_col[threadIdx.x] = ~0ull;
+    s_first[threadIdx.x] = ~0u;
+  }
+  __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int q0 = blockIdx.x * 128 + (wave >> 1) * 64, t0 = blockIdx.y * 128 + (wave & 1) * 64;
@@ -82,63 +95,73 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(const MatchArgs a) {
     qn[i] += __shfl_xor(qn[i], 32);
     tn[i] += __shfl_xor(tn[i], 32);
   }
-  // C/D map: column (t) = lane & 31, row (q) = (r&3) + 8*(r>>2) + 4*half.
+  // C/D map: column (t) = lane & 31, row (q) = (r&3) + 8*(r>>2) + 4*half.  d2 -> this wave's LDS tile
+  float* tile = s_d2[wave];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rowl = (r & 3) + 8 * (r >> 2) + 4 * half;            // row within the 32-block
-      const int qi = q0 + mi * 32 + rowl;
+      const int rowl = (r & 3) + 8 * (r >> 2) + 4 * half;
       const float qnr = __shfl(qn[mi], rowl);                         // |q|^2 of that row lives in lane `rowl`
-      unsigned long long best = ~0ull;
-      unsigned int firstj = ~0u;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int tj = t0 + ni * 32 + l31;
         float d2 = qnr + tn[ni] - 2.f * acc[mi][ni][r];
-        d2 = d2 > 0.f ? d2 : 0.f;
-        if (tj < a.nt) {
-          const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)tj;
-          best = key < best ? key : best;
-          if (a.tol2 >= 0.f && d2 < a.tol2) firstj = min(firstj, (unsigned)tj);
+        tile[(mi * 32 + rowl) * 68 + ni * 32 + l31] = d2 > 0.f ? d2 : 0.f;
+      }
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is private to this wave: no workgroup barrier needed
+  {  // lane = row of the tile: arg-min (lowest column index on ties) and first-within over its 64 columns
+    const int qi = q0 + lane;
+    const int ncol = min(64, a.nt - t0);                 // valid columns of this tile (may be <= 0)
+    float best = INFINITY;
+    int bj = -1;
+    unsigned int firstj = ~0u;
+    const float4* rowp = reinterpret_cast<const float4*>(tile + lane * 68);
+#pragma unroll 4
+    for (int j4 = 0; j4 < 16; ++j4) {
+      const float4 v = rowp[j4];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = j4 * 4 + k;
+        if (j < ncol) {
+          if (e[k] < best) { best = e[k]; bj = j; }
+          if (a.tol2 >= 0.f && e[k] < a.tol2 && firstj == ~0u) firstj = (unsigned)(t0 + j);
         }
       }
-      // row arg-min over the 32 lanes of this half
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        const unsigned long long ob = __shfl_xor(best, o);
-        best = ob < best ? ob : best;
-        firstj = min(firstj, (unsigned)__shfl_xor((int)firstj, o));
-      }
-      if (l31 == 0 && qi < a.nq) {
-        if (a.tol2 < 0.f) atomicMin(a.rowbest + qi, best);
-        else if (firstj != ~0u) atomicMin(a.first + qi, firstj);
-      }
+    }
+    if (qi < a.nq && bj >= 0) {
+      const int rl = (wave >> 1) * 64 + lane;
+      if (a.tol2 < 0.f) atomicMin(&s_row[rl], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(t0 + bj));
+      else if (firstj != ~0u) atomicMin(&s_first[rl], firstj);
     }
   }
-  if (a.tol2 < 0.f) {  // column arg-min (for the cross check)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int tj = t0 + ni * 32 + l31;
-      unsigned long long best = ~0ull;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowl = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int qi = q0 + mi * 32 + rowl;
-          const float qnr = __shfl(qn[mi], rowl);
-          float d2 = qnr + tn[ni] - 2.f * acc[mi][ni][r];
-          d2 = d2 > 0.f ? d2 : 0.f;
-          if (qi < a.nq) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
-            best = key < best ? key : best;
-          }
-        }
-      const unsigned long long ob = __shfl_xor(best, 32);
-      best = ob < best ? ob : best;
-      if (half == 0 && tj < a.nt) atomicMin(a.colbest + tj, best);
+  if (a.tol2 < 0.f) {  // lane = column of the tile: arg-min over its 64 rows (for the cross check)
+    const int tj = t0 + lane;
+    const int nrow = min(64, a.nq - q0);
+    float best = INFINITY;
+    int bi = -1;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      const float e = tile[i * 68 + lane];
+      if (i < nrow && e < best) { best = e; bi = i; }
     }
+    if (tj < a.nt && bi >= 0)
+      atomicMin(&s_col[(wave & 1) * 64 + lane], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(q0 + bi));
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int qi = blockIdx.x * 128 + tid;
+    if (qi < a.nq) {
+      if (a.tol2 < 0.f) {
+        if (s_row[tid] != ~0ull) atomicMin(a.rowbest + qi, s_row[tid]);
+      } else if (s_first[tid] != ~0u) {
+        atomicMin(a.first + qi, s_first[tid]);
+      }
+    }
+  } else if (a.tol2 < 0.f) {
+    const int tj = blockIdx.y * 128 + tid - 128;
+    if (tj < a.nt && s_col[tid - 128] != ~0ull) atomicMin(a.colbest + tj, s_col[tid - 128]);
   }
 }
 
