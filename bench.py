@@ -37,16 +37,16 @@ BATCH = 32
 # dispatch / 32 frames, averaged over the layers that share the symbol (the x2 on FETCH_SIZE is the gfx950
 # correction of MI355X_MICROARCH.md for 16 B/lane reads; FETCH_SIZE and WRITE_SIZE in separate passes).
 TRAFFIC_BYTES_PER_FRAME = {
-    "wblock_mfma_kernel<32, 4, 128>": 301728102 / 32.0,
-    "wblock_mfma_kernel<32, 2, 64>": 327120384 / 32.0,
-    "wblock_mfma_kernel<32, 3, 72>": 175527040 / 32.0,
-    "stem_pool_kernel": 589089568 / 32.0,
+    "wblock_mfma_kernel<32, 4, 128>": 301818662 / 32.0,
+    "wblock_mfma_kernel<32, 2, 64>": 326914224 / 32.0,
+    "wblock_mfma_kernel<32, 3, 72>": 175443104 / 32.0,
+    "stem_pool_kernel": 315071104 / 32.0,
     # split-operand kernels (profiles/r01i_pmc_summary_serial_f32_split_f16.csv; the bf16-term twins move the same bytes)
-    "block_h2_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 351156523 / 32.0,
-    "block_h2_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 522565856 / 32.0,
-    "block_x3_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 351156523 / 32.0,
-    "block_x3_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 522565856 / 32.0,
-    "stem_pool_x3_kernel": 589399264 / 32.0,
+    "block_h2_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 307176736 / 32.0,
+    "block_h2_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 460159776 / 32.0,
+    "block_x3_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 307176736 / 32.0,
+    "block_x3_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 460159776 / 32.0,
+    "stem_pool_x3_kernel": 315311808 / 32.0,
 }
 H, W = 480, 640
 
