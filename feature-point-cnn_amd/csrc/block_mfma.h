@@ -146,6 +146,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
     float4 av[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[abase[mb] + a.tapoff4[0]];
+#pragma unroll   // rolled, the B ring was rotated by register moves that wait for the load just issued
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = a.tapoff4[tap];
       const int toffn = a.tapoff4[tap < 8 ? tap + 1 : 8];
@@ -182,14 +183,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
 
   FPC_STAMP(2)
   // ---------------------------------------------------------------- h = relu(acc + b1) -> LDS
-  // start streaming phase 2's weights while the tile is being turned around
+  // start streaming phase 2's weights while the tile is being turned around: a ring of four K steps with STATIC slot
+  // indices (the loop over h is unrolled, the one over x runs four steps per iteration) -- in a rolled loop the ring
+  // is rotated by register moves, and a move of the fragment just requested waits for its whole L2 round trip
+  constexpr int KH = CMIDP / 8, RING = 4;   // a.k8_h == KH
+  const int nsteps2 = KH + a.k8_x;           // the fragment array is padded by two steps
   const float4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
+  float4 cb[RING][NB];
+  auto load_b = [&](int slot, int step) {
+    const float4* pw = wq + (size_t)min(step, nsteps2 + 1) * stepstride;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) b0[nb] = wq[nb * 64];
-  wq += stepstride;
+    for (int nb = 0; nb < NB; ++nb) cb[slot][nb] = pw[nb * 64];
+  };
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) b1[nb] = wq[nb * 64];
-  wq += stepstride;
+  for (int s_ = 0; s_ < RING - 1; ++s_) load_b(s_, s_);
   FPC_LDS_BARRIER();  // every wave is done reading the halo: its LDS becomes the h tile
   {
     float* hl = reinterpret_cast<float*>(lds4);
@@ -215,41 +222,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   int hbase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH4 + half;
-  {
-    float4 av[MB];
+  auto mfma_step = [&](const float4 (&av)[MB], int slot) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[hbase[mb]];
-    for (int k8 = 0; k8 < a.k8_h; ++k8) {
-      float4 b2[NB], an[MB];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
-      wq += stepstride;
-      const int kn = k8 + 1 < a.k8_h ? k8 + 1 : k8;
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) an[mb] = lds4[hbase[mb] + kn * 2];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
-            const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
-          }
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        b0[nb] = b1[nb];
-        b1[nb] = b2[nb];
-      }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
-    }
-  }
-
-  // ---------------------------------------------------------------- phase 2b: K over x (projection)
-  // A operand straight from global: lane (pixel, half) reads 4 channels of its own pixel per step.
+        for (int nb = 0; nb < NB; ++nb) {
+          const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
+          const float bf = j == 0 ? cb[slot][nb].x : j == 1 ? cb[slot][nb].y : j == 2 ? cb[slot][nb].z : cb[slot][nb].w;
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
+        }
+  };
+  // ---------------------------------------------------------------- phase 2b operands: K over x (projection)
+  // A operand straight from global: lane (pixel, half) reads 4 channels of its own pixel per step; the first four
+  // steps are requested before the GEMM over h, the next four during each group of four.
   const float* xrow[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -261,37 +248,53 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
     x = x < a.W ? x : a.W - 1;
     xrow[mb] = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 4;
   }
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  auto ldx = [&](int mb, int k8) {
+    const f4v v = *reinterpret_cast<const f4v*>(xrow[mb] + (k8 < a.k8_x ? k8 : 0) * 8);
+    return make_float4(v.x, v.y, v.z, v.w);
+  };
+  float4 xa[4][MB];
   if (a.k8_x > 0) {
-    float4 an[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const float4*>(xrow[mb]);
-    for (int k8 = 0; k8 < a.k8_x; ++k8) {
-      float4 b2[NB], av[MB];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
-      wq += stepstride;
+      for (int mb = 0; mb < MB; ++mb) xa[u][mb] = ldx(mb, u);
+  }
+  {
+    float4 av[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        av[mb] = an[mb];
-        const int kn = k8 + 1 < a.k8_x ? k8 + 1 : k8;
-        an[mb] = *reinterpret_cast<const float4*>(xrow[mb] + kn * 8);
-      }
+    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[hbase[mb]];
+#pragma unroll
+    for (int k8 = 0; k8 < KH; ++k8) {
+      float4 an[MB];
+      load_b((k8 + RING - 1) % RING, k8 + RING - 1);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) an[mb] = lds4[hbase[mb] + (k8 + 1 < KH ? k8 + 1 : k8) * 2];
       __builtin_amdgcn_sched_barrier(0);
+      mfma_step(av, k8 % RING);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
+    }
+  }
+
+  // ---------------------------------------------------------------- phase 2b: K over x (projection)
+  for (int k8 = 0; k8 < a.k8_x; k8 += 8) {   // k8_x is a multiple of 8 (checked when the plan is built)
+    float4 xb[4][MB];                         // two groups of four per iteration: no register moves at the back edge
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+    for (int u = 0; u < 4; ++u) {
+      load_b((KH + u + RING - 1) % RING, KH + k8 + u + RING - 1);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
-            const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
-          }
+      for (int mb = 0; mb < MB; ++mb) xb[u][mb] = ldx(mb, k8 + 4 + u);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(xa[u], (KH + u) % RING);
+    }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        b0[nb] = b1[nb];
-        b1[nb] = b2[nb];
-      }
+    for (int u = 0; u < 4; ++u) {
+      load_b((KH + u + RING - 1) % RING, KH + k8 + 4 + u + RING - 1);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) xa[u][mb] = ldx(mb, k8 + 8 + u);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(xb[u], (KH + u) % RING);
     }
   }
 

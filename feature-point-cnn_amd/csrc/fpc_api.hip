@@ -499,7 +499,8 @@ static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) a.tapoff4[ky * 3 + kx] = (ky * HWp + kx) * ROW4;
   a.k8_h = k.CMIDP / 8;
-  a.k8_x = s.proj ? s.cin_pad / 8 : 0;
+  a.k8_x = s.proj ? s.cin_pad / 8 : 0;   // the kernel walks the projection eight K steps at a time
+  if (a.k8_x % 8) { fprintf(stderr, "fpc: fused block %s: projection over %d channels is not a multiple of 64\n", s.prefix.c_str(), s.cin_pad); abort(); }
   a.out = s.out;
   a.cso = s.cso;
   a.Ho = s.H / k.S;
@@ -541,7 +542,8 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   a.H = s.H;
   a.W = s.W;
   a.k8_h = k.CMID / 8;
-  a.k8_x = s.proj ? s.cin_pad / 8 : 0;
+  a.k8_x = s.proj ? s.cin_pad / 8 : 0;   // the kernel walks the projection four K steps at a time
+  if (a.k8_x % 4) { fprintf(stderr, "fpc: winograd block %s: projection over %d channels is not a multiple of 32\n", s.prefix.c_str(), s.cin_pad); abort(); }
   a.out = s.out;
   a.cso = s.cso;
   a.tiles_x = (s.W + 15) / 16;

@@ -56,6 +56,19 @@ struct WBlockCfg {
   static constexpr int NBW = NBT / GN;                          // N blocks per wave
 };
 
+// Uniform base (SGPR pair) + 32-bit per-lane byte offset.  The asm pins the uniform part in SGPRs; otherwise the
+// compiler folds it into 64-bit per-lane addresses, hoists one per K step out of the tile loop and spills them.
+__device__ __forceinline__ float4 fpc_ldg_su(const float4* ubase, unsigned lane_bytes) {
+  typedef const char __attribute__((address_space(1))) * gptr;
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  gptr b = (gptr) reinterpret_cast<const char*>(ubase);
+#ifndef FPC_NO_PIN
+  asm("" : "+s"(b));
+#endif
+  const f4v v = *reinterpret_cast<const f4v __attribute__((address_space(1)))*>(b + lane_bytes);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 template <int KC, int NBT, int CMID_>
 __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a) {
   using C = WBlockCfg<KC, NBT, CMID_>;
@@ -66,7 +79,9 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
   float4* halo4 = lds4;
   float4* v4 = lds4 + C::HALO_BYTES / 16;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: what derives from it stays in SGPRs
   const int gx = wave / GN, gn = wave % GN;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -108,7 +123,11 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
   // [chunk][xi][k8][nb][lane]; consecutive (p, k8) of one chunk are contiguous.
   constexpr int STEPS = PX * K8;                  // per chunk
   constexpr int stepstride = NBT * 64;
-  const float4* wbase = a.w1 + (size_t)(gx * PX * K8 * NBT + gn * NBW) * 64 + lane;
+  // Weight pointers: a uniform base (SGPR pair) plus the lane offset per load, or -- for the three-block kernels, where
+  // it measures 5 % faster -- per-lane 64-bit pointers that the compiler hoists out of the tile loop.
+  constexpr bool PIN = NBT != 3;
+  const float4* wbase = a.w1 + (size_t)(gx * PX * K8 * NBT + gn * NBW) * 64 + (PIN ? 0 : lane);
+  auto ldw = [&](const float4* pw) { return PIN ? fpc_ldg_su(pw, lane16) : *pw; };
   auto wptr = [&](int s) {                        // s = step index of this wave within a tile
     const int chunk = s / STEPS, ls = s - chunk * STEPS;
     return wbase + (size_t)(chunk * 16 * K8 + ls) * stepstride;
@@ -124,11 +143,14 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
   const int wg_first = xcd_order ? (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int wg_end = xcd_order ? min(a.total, ((int)(blockIdx.x & 7) + 1) * xchunk) : a.total;
   if (wg_first < wg_end) load_chunk(wg_first, 0);
+  // diagnostic stamps describe a workgroup's THIRD tile (steady state: weights in L2, halo prefetched)
+  const int wg_stamp = wg_first + 2 * wg_step < wg_end ? wg_first + 2 * wg_step : wg_first;
   for (int wg = wg_first; wg < wg_end; wg += wg_step) {
   const int bl = wg / tiles;
   const int b = a.frame0 + bl;
   const int t = wg - bl * tiles;
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  if (wg == wg_stamp && wg != wg_first) { FPC_STAMP(0) }
   // per-thread index math below is cheap; recompute it per tile rather than let the compiler hoist it
   // out of the persistent loop and keep dozens of values alive (they spilled to scratch)
   int tid_t = tid;
@@ -149,8 +171,8 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     const float4* p1 = wptr(1);
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-      b0[nb] = p0[nb * 64];
-      b1[nb] = p1[nb * 64];
+      b0[nb] = ldw(p0 + nb * 64);
+      b1[nb] = ldw(p1 + nb * 64);
     }
   }
   int gs = 0;
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     FPC_LDS_BARRIER();   // previous chunk's GEMM is done with V / previous tile's epilogue with the LDS
     store_chunk();
     FPC_LDS_BARRIER();
-    if (chunk == 0 && wg == wg_first) { FPC_STAMP(6) }
+    if (chunk == 0 && wg == wg_stamp) { FPC_STAMP(6) }
     if (chunk + 1 < a.nchunk) load_chunk(wg, chunk + 1);
     else if (wg + wg_step < wg_end) load_chunk(wg + wg_step, 0);
     {
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
     FPC_LDS_BARRIER();
-    if (chunk == 0 && wg == wg_first) { FPC_STAMP(1) }
+    if (chunk == 0 && wg == wg_stamp) { FPC_STAMP(1) }
     // 16 GEMMs, one 32-row block each: this wave's PX positions x NBW channel blocks
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
         float4 b2[NBW];
         const float4* pn = wptr(gs + 2);
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) b2[nb] = pn[nb * 64];
+        for (int nb = 0; nb < NBW; ++nb) b2[nb] = ldw(pn + nb * 64);
         ++gs;
         __builtin_amdgcn_sched_barrier(0);
         const float4 av = v4[abase + k8 * 2];
@@ -227,14 +249,14 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
         }
       }
     }
-    if (chunk == 0 && wg == wg_first) { FPC_STAMP(7) }
+    if (chunk == 0 && wg == wg_stamp) { FPC_STAMP(7) }
   }
-  if (wg == wg_first) { FPC_STAMP(2) }
+  if (wg == wg_stamp) { FPC_STAMP(2) }
 
   // ---------------------------------------------------------------- output transform -> h (LDS)
-  const int lane_t = tid_t & 63, l31_t = lane_t & 31, half_t = lane_t >> 5, wave_t = tid_t >> 6;
+  const int lane_t = tid_t & 63, l31_t = lane_t & 31, half_t = lane_t >> 5, wave_t = __builtin_amdgcn_readfirstlane(tid_t >> 6);
   // per 32-channel quarter: M[xi][tile][c] of all 16 positions -> LDS, then Y = A^T M A, + bias, ReLU
-  const float4* wq = a.w2 + lane_t;
+  const float4* wq = a.w2;
   float* mreg = reinterpret_cast<float*>(lds4);                       // [16][32][36]
   float4* h4w = lds4 + C::M_BYTES / 16;                               // [128][ROWH4] float4
   for (int q = 0; q < NBT; ++q) {
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     }
   }
   FPC_LDS_BARRIER();
-  if (wg == wg_first) { FPC_STAMP(3) }
+  if (wg == wg_stamp) { FPC_STAMP(3) }
   if (a.conv_only) {  // h is the result: [128 px][CMID] in LDS -> 16-byte stores
     constexpr int C4S = CMID / 4;
     constexpr int NES = TH * TW * C4S, EITS = (NES + NT - 1) / NT;
@@ -312,97 +334,128 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
 
   // ---------------------------------------------------------------- phase 2: 1x1 over h (+ projection over x)
   // 4 M blocks (128 pixels) x NBT channel blocks over 8 waves
-  // identity shortcut: fetch this thread's share of x now, it is consumed in the epilogue
-  constexpr int C4E = CMID / 4;
-  constexpr int NEE = TH * TW * C4E, EITE = (NEE + NT - 1) / NT;
-  float4 idv[EITE];
-  if (a.k8_x == 0) {
-#pragma unroll
-    for (int i = 0; i < EITE; ++i) {
-      const int e = tid_t + i * NT;
-      const int m = e / C4E, c4 = e - m * C4E;
-      const int py = m / TW, px = m - py * TW;
-      const int y = ty * TH + py, x = tx * TW + px;
-      const bool ok = (NEE % NT == 0 || e < NEE) && y < a.H && x < a.W;
-      idv[i] = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4 : 0));
-    }
-  }
   constexpr int NB2 = (NBT + 1) / 2;             // channel blocks per wave_t: M block mw, blocks nb0..nb0+NB2-1 (< NBT)
   const int mw = wave_t & 3, nb0 = (wave_t >> 2) * NB2;
+  // The accumulators of the 1x1 start from the identity shortcut (or zero when the shortcut is a projection, which
+  // is more K below): x is read in the accumulator layout -- register r of lanes 0..31 is 128 contiguous bytes of one
+  // pixel -- straight into the registers the MFMAs need anyway.  Held in separate registers until the epilogue, the
+  // identity was spilled value by value (load, wait, scratch store) and fetched back one round trip at a time.
   f32x16 acc2[NB2];
+  if (a.k8_x == 0) {
 #pragma unroll
-  for (int nb = 0; nb < NB2; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
-  const float4* h4 = lds4 + C::M_BYTES / 16;
-  const int hbase = (mw * 32 + l31_t) * ROWH4 + half_t;
-  const float4* wq2 = wq + (size_t)nb0 * 64;
-  float4 c0[NB2], c1[NB2];
-#pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) {
-    c0[nb] = wq2[nb * 64];
-    c1[nb] = wq2[stepstride + nb * 64];
-  }
-  wq2 += 2 * stepstride;
-  {
-    float4 av = h4[hbase];
-    for (int k8 = 0; k8 < a.k8_h; ++k8) {
-      float4 c2[NB2];
-#pragma unroll
-      for (int nb = 0; nb < NB2; ++nb) c2[nb] = wq2[nb * 64];
-      wq2 += stepstride;
-      const float4 an = h4[hbase + (k8 + 1 < a.k8_h ? k8 + 1 : k8) * 2];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) {
-          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave_t group has one block less
-          const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
-          const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
-          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int py = mw * 2 + (r >> 3), px = 8 * ((r >> 2) & 1) + 4 * half_t + (r & 3);
+      int y = ty * TH + py, x = tx * TW + px;
+      y = y < a.H ? y : a.H - 1;
+      x = x < a.W ? x : a.W - 1;
+      const float* xp = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx;
 #pragma unroll
       for (int nb = 0; nb < NB2; ++nb) {
-        c0[nb] = c1[nb];
-        c1[nb] = c2[nb];
+        const int n = (nb0 + nb) * 32 + l31_t;
+        acc2[nb][r] = xp[n < CMID ? n : 0];
+        if (n >= CMID) acc2[nb][r] = 0.f;
       }
+    }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+  }
+  const float4* h4 = lds4 + C::M_BYTES / 16;
+  const int hbase = (mw * 32 + l31_t) * ROWH4 + half_t;
+  // B fragments of the 1x1: a ring of four steps with STATIC slot indices (the K loop over h is unrolled, the one
+  // over x runs four steps per iteration).  A ring rotated by register moves in a rolled loop made every step
+  // wait for the load it had just issued -- a full L2 round trip per 8 MFMAs, 2 to 4 times the MFMA time.
+  constexpr int KH = CMID / 8, RING = 4;           // a.k8_h == KH
+  const int nsteps2 = KH + a.k8_x;                 // the fragment array is padded by two steps
+  const float4* wq2 = wq + (size_t)nb0 * 64;
+  float4 cb[RING][NB2];
+  auto load_b = [&](int slot, int step) {          // step is clamped into the padded array (uniform)
+    const float4* pw = wq2 + (size_t)min(step, nsteps2 + 1) * stepstride;
+#pragma unroll
+    for (int nb = 0; nb < NB2; ++nb) cb[slot][nb] = fpc_ldg_su(pw + nb * 64, lane16);
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < RING - 1; ++s_) load_b(s_, s_);
+  auto mfma_step = [&](const float4& av, int slot) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) {
+        if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave_t group has one block less
+        const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
+        const float bf = j == 0 ? cb[slot][nb].x : j == 1 ? cb[slot][nb].y : j == 2 ? cb[slot][nb].z : cb[slot][nb].w;
+        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
+      }
+  };
+  // projection shortcut: this thread's share of the first 128 channels of the centre pixels, consumed after the
+  // GEMM over h (see below)
+  constexpr int XROW4 = 33, XIT = 128 * 32 / NT;
+  static_assert(128 * XROW4 * 16 <= C::M_BYTES, "x staging fits the M region");
+  float4* xs4 = lds4;
+  float4 xst[XIT];
+  auto load_x = [&](int pass) {
+    const int kx4 = min(32, a.k8_x * 2 - pass * 32);   // float4 per pixel in this pass
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int e = tid_t + i * NT;
+      const int m = e >> 5, c4 = e & 31;
+      const int py = m / TW, px = m - py * TW;
+      int y = ty * TH + py, x = tx * TW + px;
+      y = y < a.H ? y : a.H - 1;
+      x = x < a.W ? x : a.W - 1;
+      const bool ok = c4 < kx4;
+      // (through a vector value: a struct-to-struct copy becomes a memcpy into a private array that is never promoted)
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v v = *reinterpret_cast<const f4v*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + (ok ? pass * 128 + c4 * 4 : 0));
+      xst[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  if (a.k8_x > 0) load_x(0);
+  {
+    float4 av = h4[hbase];
+#pragma unroll
+    for (int k8 = 0; k8 < KH; ++k8) {
+      load_b((k8 + RING - 1) % RING, k8 + RING - 1);
+      const float4 an = h4[hbase + (k8 + 1 < KH ? k8 + 1 : k8) * 2];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(av, k8 % RING);
       av = an;
     }
   }
-  if (a.k8_x > 0) {  // projection shortcut: A straight from global (centre pixels of x)
-    int m = mw * 32 + l31_t;
-    const int py = m / TW, px = m - py * TW;
-    int y = ty * TH + py, x = tx * TW + px;
-    y = y < a.H ? y : a.H - 1;
-    x = x < a.W ? x : a.W - 1;
-    const float* xrow = a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + half_t * 4;
-    float4 an = *reinterpret_cast<const float4*>(xrow);
-    for (int k8 = 0; k8 < a.k8_x; ++k8) {
-      float4 c2[NB2];
+  if (a.k8_x > 0) {
+    // Projection shortcut: more K into the same accumulators, A = the tile's centre pixels of x.  Reading them
+    // straight into the MFMA layout (lane = pixel) touches 64 different cache lines per load; instead 128 channels
+    // at a time are loaded as whole pixels (coalesced, requested before the GEMM over h), go through the dead M
+    // region of the LDS and come back as ds_read_b128.
+    const int npass = (a.k8_x + 15) >> 4;
+    for (int pass = 0; pass < npass; ++pass) {
+      if (pass > 0) FPC_LDS_BARRIER();   // the previous pass's fragments have been read
 #pragma unroll
-      for (int nb = 0; nb < NB2; ++nb) c2[nb] = wq2[nb * 64];
-      wq2 += stepstride;
-      const float4 av = an;
-      an = *reinterpret_cast<const float4*>(xrow + (k8 + 1 < a.k8_x ? k8 + 1 : k8) * 8);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < XIT; ++i) {
+        const int e = tid_t + i * NT;
+        xs4[(e >> 5) * XROW4 + (e & 31)] = xst[i];
+      }
+      FPC_LDS_BARRIER();
+      if (pass + 1 < npass) load_x(pass + 1);
+      const int steps = min(16, a.k8_x - pass * 16);   // a multiple of 4
+      const int xbase = (mw * 32 + l31_t) * XROW4 + half_t;
+      for (int k8 = 0; k8 < steps; k8 += 4) {
+        const int sg = KH + pass * 16 + k8;            // global step of this group; sg - KH is a multiple of 4
+        float4 av[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < 4; ++u) av[u] = xs4[xbase + (k8 + u) * 2];
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) {
-          if (NBT % 2 && nb0 + nb >= NBT) continue;  // odd NBT: the last wave_t group has one block less
-          const float af = j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w;
-          const float bf = j == 0 ? c0[nb].x : j == 1 ? c0[nb].y : j == 2 ? c0[nb].z : c0[nb].w;
-          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc2[nb], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          load_b((KH + u + RING - 1) % RING, sg + u + RING - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_step(av[u], (KH + u) % RING);
         }
-#pragma unroll
-      for (int nb = 0; nb < NB2; ++nb) {
-        c0[nb] = c1[nb];
-        c1[nb] = c2[nb];
       }
     }
   }
-  if (wg == wg_first) { FPC_STAMP(4) }
+  if (wg == wg_stamp) { FPC_STAMP(4) }
 
   // ---------------------------------------------------------------- epilogue (as block_mfma.h)
   FPC_LDS_BARRIER();  // every wave_t is done reading h
@@ -425,8 +478,6 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
     constexpr int C4 = CMID / 4;
     constexpr int NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
     const int oyb = ty * TH, oxb = tx * TW;
-    const bool ident = a.k8_x == 0;
-    static_assert(EIT == EITE, "epilogue partition");
 #pragma unroll
     for (int i = 0; i < EIT; ++i) {
       const int e = tid_t + i * NT;
@@ -435,12 +486,6 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       const int y = oyb + py, x = oxb + px;
       if ((NE % NT == 0 || e < NE) && y < a.H && x < a.W) {
         float4 v = lds4[m * ROWH4 + c4];
-        if (ident) {
-          v.x += idv[i].x;
-          v.y += idv[i].y;
-          v.z += idv[i].z;
-          v.w += idv[i].w;
-        }
         v.x = v.x > 0.f ? v.x : 0.f;
         v.y = v.y > 0.f ? v.y : 0.f;
         v.z = v.z > 0.f ? v.z : 0.f;
@@ -449,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void wblock_mfma_kernel(const WBlockArgs a)
       }
     }
   }
-  if (wg == wg_first) { FPC_STAMP(5) }
+  if (wg == wg_stamp) { FPC_STAMP(5) }
   }  // persistent tile loop
 }
 

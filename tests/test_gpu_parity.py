@@ -396,7 +396,14 @@ def test_descriptor_matching(torch_gpu):
         for cross, md in ((True, 0.0), (False, 0.0), (True, 0.7)):
             m, d = e.match(q, t, cross, md)
             om, od = oracle.match(q, t, cross, md)
-            np.testing.assert_array_equal(m, om)
+            # real descriptors are not guaranteed tie-free: where the index differs, the two candidates must be
+            # equidistant to within the tolerance the distances themselves are held to (checked in double; the
+            # kernel forms |q|^2 + |t|^2 - 2 q.t in fp32, a few ulps of 2.0 on d^2)
+            for i in np.nonzero(m != om)[0]:
+                assert m[i] >= 0 and om[i] >= 0
+                dd = np.linalg.norm(q[i].astype(np.float64) - t[[m[i], om[i]]].astype(np.float64), axis=1)
+                assert abs(dd[0] - dd[1]) < 2e-5, (i, m[i], om[i], dd)
+            assert (m != om).sum() <= 2
             np.testing.assert_allclose(d, od, rtol=0, atol=2e-5)
         np.testing.assert_array_equal(e.first_within(q, t, 0.8), oracle.first_within(q, t, 0.8))
         np.testing.assert_array_equal(e.first_within(q, t, 0.3), oracle.first_within(q, t, 0.3))
