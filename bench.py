@@ -33,15 +33,15 @@ PEAK_TFLOPS = PEAK_F32_MFMA_TFLOPS     # ceiling for ALGORITHMIC flops in the se
 PEAK_ISSUED_TFLOPS = PEAK_F32_MFMA_TFLOPS  # ceiling for the MFMA instructions really issued
 BATCH = 32
 # HBM bytes per FRAME of each kernel symbol from the rocprofv3 PMC passes in
-# profiles/r01i_pmc_summary_serial.csv (one stream, default plan): (2*FETCH_SIZE + WRITE_SIZE) KiB per
+# profiles/r01j_pmc_summary_serial.csv (one stream, default plan): (2*FETCH_SIZE + WRITE_SIZE) KiB per
 # dispatch / 32 frames, averaged over the layers that share the symbol (the x2 on FETCH_SIZE is the gfx950
 # correction of MI355X_MICROARCH.md for 16 B/lane reads; FETCH_SIZE and WRITE_SIZE in separate passes).
 TRAFFIC_BYTES_PER_FRAME = {
-    "wblock_mfma_kernel<32, 4, 128>": 301818662 / 32.0,
-    "wblock_mfma_kernel<32, 2, 64>": 326914224 / 32.0,
-    "wblock_mfma_kernel<32, 3, 72>": 175443104 / 32.0,
-    "stem_pool_kernel": 315071104 / 32.0,
-    # split-operand kernels (profiles/r01i_pmc_summary_serial_f32_split_f16.csv; the bf16-term twins move the same bytes)
+    "wblock_mfma_kernel<32, 4, 128>": 254242720 / 32.0,
+    "wblock_mfma_kernel<32, 2, 64>": 326846528 / 32.0,
+    "wblock_mfma_kernel<32, 3, 72>": 174261248 / 32.0,
+    "stem_pool_kernel": 315067808 / 32.0,
+    # split-operand kernels (profiles/r01j_pmc_summary_serial_f32_split_f16.csv; the bf16-term twins move the same bytes)
     "block_h2_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 307176736 / 32.0,
     "block_h2_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 460159776 / 32.0,
     "block_x3_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 307176736 / 32.0,

@@ -299,7 +299,7 @@ struct fpc_ctx {
   std::vector<hipStream_t> side;     // per sub-batch: detector head + NMS next to the descriptor head
   std::vector<hipEvent_t> ev_enc, ev_det;
   bool nms_aside = true;             // FPC_NMS_ASIDE=0: NMS in line on the sub-batch stream
-  bool split_heads = false;          // FPC_SPLIT_HEADS: detector head + NMS of a sub-batch on a side stream next to its descriptor head (default: fp32-MFMA mode)
+  bool split_heads = false;          // FPC_SPLIT_HEADS=1: detector head + NMS of a sub-batch on a side stream next to its descriptor head
   hipEvent_t ev_fork = nullptr;
   int min_sub = 8;                   // smallest sub-batch worth its own stream (FPC_MIN_SUB); calls below twice this take the latency plan
   int num_cus = 256;
@@ -2089,9 +2089,10 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
       c->aux.push_back(st);
       c->ev_join.push_back(ev);
     }
-    // fp32-MFMA kernels, two sub-batches: the detector head + NMS of a sub-batch on a side stream next to its descriptor
-    // head measures +1 % (8 200 vs 8 120 frames/s, same box) since the block kernels' second phase got shorter
-    c->split_heads = !c->split && !c->bf16 && !c->vgg && nsub == 2;   // (the C++ network measures 2 % slower with it)
+    // FPC_SPLIT_HEADS=1 (detector head + NMS of a sub-batch on a side stream next to its descriptor head) measures +1 %
+    // frames/s for the Python network in the fp32-MFMA mode (8 200 vs 8 120, same box) and -2 % for the C++ network; it
+    // stays off by default: with three kernels sharing the GPU every launch stretches (the dominant kernel's mean launch
+    // 0.26 -> 0.30 ms), which is all a per-kernel roofline measured inside the timed region would show of it.
     if (const char* e = getenv("FPC_SPLIT_HEADS")) c->split_heads = atoi(e) != 0;
     c->nms_aside = !c->split;  // measured: +1.5 % with two sub-batches (fp32-MFMA kernels), nothing with three (split modes)
     if (const char* e = getenv("FPC_NMS_ASIDE")) c->nms_aside = atoi(e) != 0;
