@@ -54,21 +54,25 @@ def broadcast_packed_weights(engine, state_dict, src=0):
     if rank == src:
         engine.load_state_dict(state_dict)
     if dist.get_backend() == "nccl":
-        # RCCL broadcast over xGMI, device to device.  Preferred: straight into the library's blob
-        # (zero copies); if aliasing library memory as a tensor is not possible in this torch build,
-        # through a torch-owned device buffer and one host round trip (start-up only).
-        try:
+        # RCCL broadcast over xGMI, device to device, of a torch-owned buffer (16 MB, start-up only), then one copy
+        # into the library.  FPC_DIST_ZERO_COPY=1 broadcasts straight into the library's blob instead (a tensor view
+        # of memory the library allocated): it saves that copy, but a failure on SOME ranks only would leave the ranks
+        # in different collectives, so it is opt-in and every rank must set it.
+        done = False
+        if os.environ.get("FPC_DIST_ZERO_COPY") == "1":
             view = engine.packed_view()
             dist.broadcast(view, src=src)
             torch.cuda.synchronize()
             if rank != src:
                 engine.mark_weights_loaded()
-        except (RuntimeError, TypeError, ValueError):
+            done = True
+        if not done:
             n = engine.packed_size()
             dev = torch.device("cuda", torch.cuda.current_device())
             buf = (torch.from_numpy(engine.export_packed()).to(dev) if rank == src
                    else torch.empty(n, dtype=torch.uint8, device=dev))
             dist.broadcast(buf, src=src)
+            torch.cuda.synchronize()
             if rank != src:
                 engine.import_packed(buf.cpu().numpy())
     else:
