@@ -26,7 +26,17 @@ SYMBOLS = [
     "fpc_get_stream", "fpc_sync", "fpc_forward", "fpc_detect", "fpc_get_points", "fpc_results",
     "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
     "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation", "fpc_detect_u8_resized",
+    "fpc_sample_descriptors", "fpc_plan_hash", "fpc_broadcast_weights", "fpc_read_activation",
 ]
+
+ABI_VERSION = 2
+
+# fpc_config.plan_flags (include/fpc.h, FPC_PLAN_*)
+PLAN_FLAGS = {
+    "no_fused_blocks": 1 << 0, "no_winograd": 1 << 1, "no_winograd_detector": 1 << 2, "no_winograd_layer_in1": 1 << 3,
+    "no_xcd_order": 1 << 4, "no_fused_stem_pool": 1 << 5, "split_heads": 1 << 6, "nms_in_line": 1 << 7,
+    "no_persistent_grid": 1 << 8, "layer1_tile_8x16": 1 << 9,
+}
 
 
 class FpcConfig(ctypes.Structure):
@@ -35,7 +45,8 @@ class FpcConfig(ctypes.Structure):
                 ("conf_thresh", ctypes.c_float), ("border_remove", ctypes.c_int),
                 ("descriptor_enabled", ctypes.c_int), ("max_keypoints", ctypes.c_int),
                 ("in_channels", ctypes.c_int), ("dtype", ctypes.c_int), ("arch", ctypes.c_int),
-                ("reserved", ctypes.c_int * 4)]
+                ("num_streams", ctypes.c_int), ("plan_flags", ctypes.c_uint), ("nms_round_launches", ctypes.c_int),
+                ("min_sub_batch", ctypes.c_int)]
 
 
 class FpcTensor(ctypes.Structure):
@@ -112,14 +123,20 @@ def load():
     l.fpc_get_keypoints.argtypes = [vp, ci, ci, vp, vp, vp]
     l.fpc_match.argtypes = [vp, vp, ci, vp, ci, ci, ctypes.c_float, vp, vp]
     l.fpc_first_within.argtypes = [vp, vp, ci, vp, ci, ctypes.c_float, vp]
+    l.fpc_sample_descriptors.argtypes = [vp, vp, vp, ci, vp]
+    l.fpc_read_activation.argtypes = [vp, ctypes.c_char_p, ci, ci, vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    l.fpc_plan_hash.argtypes = [vp]
+    l.fpc_plan_hash.restype = ctypes.c_uint64
+    l.fpc_broadcast_weights.argtypes = [vp, vp, ci]
     l.fpc_set_timing.argtypes = [vp, ci]
     l.fpc_get_timings.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double),
                                   ctypes.POINTER(ctypes.c_double)]
     for s in SYMBOLS:
         getattr(l, s)  # AttributeError if the library lacks a declared symbol
-    if l.fpc_abi_version() != 1:
-        raise ImportError("libfpc.so ABI version mismatch")
+    if l.fpc_abi_version() != ABI_VERSION:
+        raise ImportError("libfpc.so has ABI version %d, this binding is for %d: rebuild (make -C %s)"
+                          % (l.fpc_abi_version(), ABI_VERSION, CSRC))
     _lib = l
     return l
 

@@ -49,8 +49,11 @@ inline uint64_t rd64(const char* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 struct ZipEntry { uint64_t offset = 0, size = 0; };
 
 // name -> (offset of the entry's data, size) for STORED entries
+// All offsets and lengths below come from the file: every range check is of the form `len <= n && off <= n - len`
+// (no sum of untrusted values that could wrap).
 inline std::map<std::string, ZipEntry> zip_directory(const std::vector<char>& f) {
   const size_t n = f.size();
+  auto in_range = [n](uint64_t off, uint64_t len) { return len <= n && off <= n - len; };
   if (n < 22) throw std::runtime_error("not a zip file (too short)");
   size_t eocd = std::string::npos;
   for (size_t i = n - 22;; --i) {
@@ -62,35 +65,44 @@ inline std::map<std::string, ZipEntry> zip_directory(const std::vector<char>& f)
   if (count == 0xffff || cd_off == 0xffffffffu || cd_size == 0xffffffffu) {  // ZIP64
     if (eocd < 20 || rd32(&f[eocd - 20]) != 0x07064b50u) throw std::runtime_error("zip64 locator missing");
     const uint64_t z = rd64(&f[eocd - 20 + 8]);
-    if (z + 56 > n || rd32(&f[z]) != 0x06064b50u) throw std::runtime_error("zip64 record missing");
+    if (!in_range(z, 56) || rd32(&f[z]) != 0x06064b50u) throw std::runtime_error("zip64 record missing");
     count = rd64(&f[z + 32]);
     cd_size = rd64(&f[z + 40]);
     cd_off = rd64(&f[z + 48]);
   }
   std::map<std::string, ZipEntry> dir;
-  size_t p = cd_off;
+  uint64_t p = cd_off;
   for (uint64_t i = 0; i < count; ++i) {
-    if (p + 46 > n || rd32(&f[p]) != 0x02014b50u) throw std::runtime_error("bad central directory entry");
+    if (!in_range(p, 46) || rd32(&f[p]) != 0x02014b50u) throw std::runtime_error("bad central directory entry");
     const uint16_t method = rd16(&f[p + 10]);
     uint64_t csize = rd32(&f[p + 20]), usize = rd32(&f[p + 24]), lho = rd32(&f[p + 42]);
     const uint16_t nlen = rd16(&f[p + 28]), xlen = rd16(&f[p + 30]), clen = rd16(&f[p + 32]);
+    // name, extra field and comment follow the 46 fixed bytes; p + 46 <= n was just checked and the three lengths are
+    // 16-bit, so these sums cannot wrap
+    if (!in_range(p + 46, (uint64_t)nlen + xlen + clen)) throw std::runtime_error("central directory entry runs past the file");
     std::string name(&f[p + 46], nlen);
-    size_t x = p + 46 + nlen;
-    const size_t xend = x + xlen;
+    uint64_t x = p + 46 + nlen;
+    const uint64_t xend = x + xlen;
     while (x + 4 <= xend) {  // zip64 extended information
       const uint16_t id = rd16(&f[x]), sz = rd16(&f[x + 2]);
       if (id == 0x0001) {
-        size_t q = x + 4;
-        if (usize == 0xffffffffu) { usize = rd64(&f[q]); q += 8; }
-        if (csize == 0xffffffffu) { csize = rd64(&f[q]); q += 8; }
-        if (lho == 0xffffffffu) { lho = rd64(&f[q]); q += 8; }
+        uint64_t q = x + 4;
+        const uint64_t qend = x + 4 + sz < xend ? x + 4 + sz : xend;
+        auto take64 = [&](uint64_t* dst) {
+          if (q + 8 > qend) throw std::runtime_error("zip64 extra field of '" + name + "' is too short");
+          *dst = rd64(&f[q]);
+          q += 8;
+        };
+        if (usize == 0xffffffffu) take64(&usize);
+        if (csize == 0xffffffffu) take64(&csize);
+        if (lho == 0xffffffffu) take64(&lho);
       }
-      x += 4 + sz;
+      x += 4 + (uint64_t)sz;
     }
     if (method != 0) throw std::runtime_error("zip entry '" + name + "' is compressed; torch.save stores entries raw");
-    if (lho + 30 > n || rd32(&f[lho]) != 0x04034b50u) throw std::runtime_error("bad local header for " + name);
-    const uint64_t data = lho + 30 + rd16(&f[lho + 26]) + rd16(&f[lho + 28]);
-    if (data + usize > n) throw std::runtime_error("zip entry out of range: " + name);
+    if (!in_range(lho, 30) || rd32(&f[lho]) != 0x04034b50u) throw std::runtime_error("bad local header for " + name);
+    const uint64_t data = lho + 30 + rd16(&f[lho + 26]) + rd16(&f[lho + 28]);   // lho + 30 <= n: no wrap
+    if (!in_range(data, usize)) throw std::runtime_error("zip entry out of range: " + name);
     dir[name] = ZipEntry{data, usize};
     p = xend + clen;
   }
@@ -133,13 +145,14 @@ inline VP reduce(const VP& fn, const VP& args) {
   if (fn->k == Val::GLOBAL) {
     const std::string& g = fn->s;
     if (g == "collections OrderedDict") return mk(Val::DICT);
-    if (g == "torch._utils _rebuild_tensor_v2" && args->items.size() >= 4 && args->items[0]->k == Val::STORAGE) {
+    if (g == "torch._utils _rebuild_tensor_v2" && args->items.size() >= 4 && args->items[0]->k == Val::STORAGE &&
+        args->items[1]->k == Val::INT) {
       VP t = mk(Val::TENSOR);
       t->s = args->items[0]->s;
       t->dtype = args->items[0]->dtype;
       t->offset = args->items[1]->i;
-      for (auto& e : args->items[2]->items) t->shape.push_back(e->i);
-      for (auto& e : args->items[3]->items) t->stride.push_back(e->i);
+      for (auto& e : args->items[2]->items) { if (e->k != Val::INT) throw std::runtime_error("tensor shape entry is not an integer"); t->shape.push_back(e->i); }
+      for (auto& e : args->items[3]->items) { if (e->k != Val::INT) throw std::runtime_error("tensor stride entry is not an integer"); t->stride.push_back(e->i); }
       return t;
     }
     if (g == "torch._utils _rebuild_parameter" && !args->items.empty()) return args->items[0];
@@ -156,10 +169,13 @@ inline VP unpickle(const char* p, size_t n) {
   size_t i = 0;
   auto need = [&](size_t k) { if (i + k > n) throw std::runtime_error("truncated pickle"); };
   auto pop = [&]() { if (stack.empty()) throw std::runtime_error("pickle stack underflow"); VP v = stack.back(); stack.pop_back(); return v; };
+  auto top = [&]() -> VP& { if (stack.empty()) throw std::runtime_error("pickle stack underflow"); return stack.back(); };
+  auto memo_at = [&](uint32_t k) -> VP { auto it = memo.find(k); if (it == memo.end()) throw std::runtime_error("pickle: unknown memo key"); return it->second; };
   auto pop_mark = [&]() {
     if (marks.empty()) throw std::runtime_error("pickle: no mark");
     const size_t m = marks.back();
     marks.pop_back();
+    if (m > stack.size()) throw std::runtime_error("pickle: mark above the stack");
     std::vector<VP> v(stack.begin() + m, stack.end());
     stack.resize(m);
     return v;
@@ -190,19 +206,19 @@ inline VP unpickle(const char* p, size_t n) {
       case 'U': case 0x8c: { need(1); const uint32_t len = (unsigned char)p[i++]; need(len); VP v = mk(Val::STR);
                              v->s.assign(p + i, len); i += len; stack.push_back(v); break; }
       case 'c': { VP v = mk(Val::GLOBAL); const std::string m = line(); v->s = m + " " + line(); stack.push_back(v); break; }
-      case 'q': need(1); memo[(unsigned char)p[i]] = stack.back(); i += 1; break;
-      case 'r': need(4); memo[rd32(p + i)] = stack.back(); i += 4; break;
-      case 'h': need(1); stack.push_back(memo.at((unsigned char)p[i])); i += 1; break;
-      case 'j': need(4); stack.push_back(memo.at(rd32(p + i))); i += 4; break;
+      case 'q': need(1); memo[(unsigned char)p[i]] = top(); i += 1; break;
+      case 'r': need(4); memo[rd32(p + i)] = top(); i += 4; break;
+      case 'h': need(1); stack.push_back(memo_at((unsigned char)p[i])); i += 1; break;
+      case 'j': need(4); stack.push_back(memo_at(rd32(p + i))); i += 4; break;
       case 0x85: { VP t = mk(Val::TUPLE); t->items = {pop()}; stack.push_back(t); break; }
       case 0x86: { VP b = pop(), a = pop(); VP t = mk(Val::TUPLE); t->items = {a, b}; stack.push_back(t); break; }
       case 0x87: { VP c = pop(), b = pop(), a = pop(); VP t = mk(Val::TUPLE); t->items = {a, b, c}; stack.push_back(t); break; }
       case 't': { VP t = mk(Val::TUPLE); t->items = pop_mark(); stack.push_back(t); break; }
       case 'l': { VP t = mk(Val::LIST); t->items = pop_mark(); stack.push_back(t); break; }
-      case 'a': { VP v = pop(); stack.back()->items.push_back(v); break; }
-      case 'e': { auto v = pop_mark(); for (auto& e : v) stack.back()->items.push_back(e); break; }
-      case 's': { VP v = pop(), k = pop(); stack.back()->dict.push_back({k, v}); break; }
-      case 'u': { auto v = pop_mark(); for (size_t k = 0; k + 1 < v.size(); k += 2) stack.back()->dict.push_back({v[k], v[k + 1]}); break; }
+      case 'a': { VP v = pop(); top()->items.push_back(v); break; }
+      case 'e': { auto v = pop_mark(); for (auto& e : v) top()->items.push_back(e); break; }
+      case 's': { VP v = pop(), k = pop(); top()->dict.push_back({k, v}); break; }
+      case 'u': { auto v = pop_mark(); for (size_t k = 0; k + 1 < v.size(); k += 2) top()->dict.push_back({v[k], v[k + 1]}); break; }
       case 'Q': {  // BINPERSID: ('storage', StorageType, key, location, numel)
         VP pid = pop();
         VP s = mk(Val::STORAGE);
@@ -260,15 +276,21 @@ inline Checkpoint load_checkpoint(const std::string& path) {
     Tensor out;
     out.dtype = t.dtype;
     out.shape = t.shape;
-    out.numel = 1;
-    int64_t expect = 1;
-    for (size_t d = t.shape.size(); d-- > 0;) {  // must be contiguous (state_dict tensors are)
-      if (t.shape[d] != 1 && t.stride[d] != expect) throw std::runtime_error("non-contiguous tensor " + kv.first->s);
-      expect *= t.shape[d];
-      out.numel *= (size_t)t.shape[d];
-    }
+    // offset, shape and stride are pickled integers: refuse negative values and anything whose byte range, computed
+    // without wrapping, leaves the storage entry
+    if (t.stride.size() != t.shape.size()) throw std::runtime_error("tensor " + kv.first->s + ": stride rank differs from shape rank");
+    if (t.offset < 0) throw std::runtime_error("tensor " + kv.first->s + ": negative storage offset");
     const size_t es = dtype_size(t.dtype);
-    if (((size_t)t.offset + out.numel) * es > it->second.size) throw std::runtime_error("tensor out of storage: " + kv.first->s);
+    const uint64_t cap_elems = it->second.size / es;           // elements the storage entry holds
+    uint64_t numel = 1;
+    for (size_t d = t.shape.size(); d-- > 0;) {  // must be contiguous (state_dict tensors are)
+      if (t.shape[d] < 0) throw std::runtime_error("tensor " + kv.first->s + ": negative dimension");
+      if (t.shape[d] != 1 && t.stride[d] != (int64_t)numel) throw std::runtime_error("non-contiguous tensor " + kv.first->s);
+      if (t.shape[d] != 0 && numel > cap_elems / (uint64_t)t.shape[d]) throw std::runtime_error("tensor out of storage: " + kv.first->s);
+      numel *= (uint64_t)t.shape[d];
+    }
+    if ((uint64_t)t.offset > cap_elems || numel > cap_elems - (uint64_t)t.offset) throw std::runtime_error("tensor out of storage: " + kv.first->s);
+    out.numel = (size_t)numel;
     out.data = &ck.bytes[it->second.offset + (size_t)t.offset * es];
     ck.tensors.push_back({kv.first->s, out});
   }

@@ -7,6 +7,8 @@
 // live in one packed blob (BN folded, MFMA fragment order) that stays L2-resident.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +29,9 @@
 #include "weights.h"
 
 namespace fpc {
+
+constexpr int BLOB_HEADER_FLOATS = 16;
+constexpr uint32_t BLOB_MAGIC = 0x57435046u;   // "FPCW"
 
 static thread_local std::string g_hip_err;
 
@@ -308,6 +313,7 @@ struct fpc_ctx {
   int nms_passes = 2;
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
+  bool layer1_t816 = false;          // direct (non-Winograd) layer1 blocks on 8x16 tiles instead of 16x16
 #ifdef FPC_DIAG
   unsigned long long* diag_stamps = nullptr;
   int diag_n = 0;
@@ -317,6 +323,7 @@ struct fpc_ctx {
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
+  bool plan_error = false;           // a layer asked for a kernel instance that does not exist (fpc_create -> FPC_E_INVALID)
 
   // one slab for all activations / results; carved below
   char* slab = nullptr;
@@ -619,6 +626,7 @@ struct FBlockSpec {
 };
 
 static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
+  if (s.kind >= FK_COUNT) { c->plan_error = true; return; }
   const FKindInfo& k = g_fkinds[s.kind];
   Op op;
   op.type = OP_BF16;
@@ -674,6 +682,7 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
 // ConvTranspose2d(k3, s2, p1, op1) + bn + relu as four output-parity phases, one launch each
 static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, int H, int W, void* out, int cso,
                        int cout, size_t* blob_off) {
+  if (kind >= FK_COUNT) { c->plan_error = true; return; }
   const FKindInfo& k = g_fkinds[kind];
   const int nbt = k.WN * k.NB, K16 = k.KC / 16;
   const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
@@ -790,6 +799,7 @@ static void build_x3_ops(fpc_ctx* c, size_t* bo) {
 static void add_fconv(fpc_ctx* c, FKind kind, const std::string& prefix, const float* x, int csx, int cin, int cin_pad,
                       int H, int W, float* out, int cso, int cout, int ksize, bool relu, bool desc_branch,
                       size_t* blob_off) {
+  if (kind >= FK_COUNT) { c->plan_error = true; return; }
   const FKindInfo& k = g_fkinds[kind];
   const int nbt = k.WN * k.NB, K16 = k.KC / 16;
   const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
@@ -876,7 +886,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   c->rowbest = reinterpret_cast<unsigned long long*>(c->slab + o_rowbest);
   c->colbest = reinterpret_cast<unsigned long long*>(c->slab + o_colbest);
 
-  size_t bo = 0;
+  size_t bo = BLOB_HEADER_FLOATS;
   c->ops.clear();
   c->convw.clear();
   auto conv = [&](const std::string& prefix, const float* x, int cin, int Hx, int Wx, float* out, int cso, int cout,
@@ -1000,9 +1010,15 @@ static int build_vgg_plan(fpc_ctx* c) {
   return FPC_OK;
 }
 
+// Rows H* of FPC_BF16_KINDS must mirror rows S* one for one.  (Round 1, gdb.log: with the two H*_1x1 rows still
+// missing, the C++ network's 1x1 layers in FPC_F32_SPLIT_F16 mode indexed past the end of g_fkinds, read TW = KC = 0 and
+// build_vgg_plan died with SIGFPE in `(W + TW - 1) / TW`.)
+static_assert((int)FK_COUNT - (int)FK_H816_s1_K64_C64 == (int)FK_H816_s1_K64_C64 - (int)FK_S816_s1_K64_C64,
+              "every S* (bf16x3) instance needs its H* (fp16x2) twin, in the same order");
 static FKind split_kind(const fpc_ctx* c, FKind s) {
   if (!c->split_f16) return s;
-  return (FKind)((int)s + ((int)FK_H816_s1_K64_C64 - (int)FK_S816_s1_K64_C64));
+  const int h = (int)s + ((int)FK_H816_s1_K64_C64 - (int)FK_S816_s1_K64_C64);
+  return h >= (int)FK_H816_s1_K64_C64 && h < (int)FK_COUNT ? (FKind)h : FK_COUNT;
 }
 
 static int build_plan(fpc_ctx* c) {
@@ -1056,7 +1072,7 @@ static int build_plan(fpc_ctx* c) {
   c->colbest = reinterpret_cast<unsigned long long*>(c->slab + o_colbest);
 
   // ---- ops
-  size_t bo = 0;  // blob offset in floats
+  size_t bo = BLOB_HEADER_FLOATS;  // blob offset in floats (the tag of the packed format comes first)
   c->ops.clear();
   c->convw.clear();
   {
@@ -1126,7 +1142,7 @@ static int build_plan(fpc_ctx* c) {
     goto postproc;
   }
   {
-  const BKind l1kind = getenv("FPC_L1_T816") ? BK_B816_s1_K64_C64 : BK_B1616_s1_K32_C64;
+  const BKind l1kind = c->layer1_t816 ? BK_B816_s1_K64_C64 : BK_B1616_s1_K32_C64;
   block("encoder.layer1.0", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x0, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
         c->x1, 64, true, false, l1kind);
   block("encoder.layer1.1", K_T816_3x3_K64_N64, K_T816_1x1_K64_N64, 1, c->x1, 64, 64, 64, H4, W4, c->h4, 64, 64, 64,
@@ -1261,6 +1277,55 @@ postproc:
   return FPC_OK;
 }
 
+// ---- the packed blob's tag ----------------------------------------------------------------
+// The first 16 words of the blob describe what packed it, so that a blob that travels (fpc_export_packed ->
+// fpc_import_packed, the RCCL broadcast) is never interpreted with another layout: magic, ABI version, dtype, arch,
+// a hash of the launch plan (kernel instances and fragment offsets of every layer), the blob size.
+static uint64_t plan_hash(const fpc_ctx* c) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    for (int i = 0; i < 8; ++i) {
+      h ^= (v >> (8 * i)) & 0xff;
+      h *= 1099511628211ull;
+    }
+  };
+  mix(FPC_ABI_VERSION); mix((uint64_t)c->cfg.dtype); mix((uint64_t)c->cfg.arch); mix((uint64_t)c->cin);
+  mix((uint64_t)(c->cfg.descriptor_enabled != 0)); mix(c->blob_floats); mix(c->stem_w_off); mix(c->stem_b_off);
+  mix(c->vconv0_off);
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    const Op& op = c->ops[i];
+    mix((uint64_t)op.type); mix((uint64_t)op.kind); mix((uint64_t)op.bkind); mix((uint64_t)op.wkind); mix((uint64_t)op.fkind);
+    mix((uint64_t)(op.phase + 1)); mix((uint64_t)op.n0);
+    for (char ch : op.prefix) mix((uint64_t)(unsigned char)ch);
+    const fpc_ctx::ConvW& cw = c->convw[i];
+    for (int z = 0; z < 4; ++z) mix(cw.w_off[z]);
+    mix(cw.b_off); mix(cw.b2_off);
+  }
+  return h;
+}
+
+static void fill_blob_header(const fpc_ctx* c, uint32_t* h) {
+  memset(h, 0, BLOB_HEADER_FLOATS * sizeof(uint32_t));
+  const uint64_t ph = plan_hash(c);
+  h[0] = BLOB_MAGIC; h[1] = FPC_ABI_VERSION; h[2] = (uint32_t)c->cfg.dtype; h[3] = (uint32_t)c->cfg.arch;
+  h[4] = (uint32_t)ph; h[5] = (uint32_t)(ph >> 32);
+  h[6] = (uint32_t)c->blob_floats; h[7] = (uint32_t)((uint64_t)c->blob_floats >> 32);
+  h[8] = 1;  // holds weights
+}
+
+static bool check_blob_header(const fpc_ctx* c, const uint32_t* h, std::string* why) {
+  uint32_t want[BLOB_HEADER_FLOATS];
+  fill_blob_header(c, want);
+  static const char* what[9] = {"magic", "ABI version", "dtype", "arch", "launch plan", "launch plan", "size", "size", "weights-present flag"};
+  for (int i = 0; i < 9; ++i)
+    if (h[i] != want[i]) {
+      *why = std::string("packed weights do not match this context: ") + what[i] + " differs (the blob was packed by another "
+             "build, dtype, arch or plan, or holds no weights)";
+      return false;
+    }
+  return true;
+}
+
 // ---- checkpoint -> blob -----------------------------------------------------------------
 static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, bool& range_bad);
 static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
@@ -1270,6 +1335,7 @@ static int pack_all(fpc_ctx* c, const TensorMap& m, std::string* missing) {
     *missing = "a BatchNorm-folded weight exceeds fp16's range (|w| > 65504): FPC_F32_SPLIT_F16 cannot represent it";
     return FPC_E_RANGE;
   }
+  if (rc == FPC_OK) fill_blob_header(c, reinterpret_cast<uint32_t*>(c->host_blob.data()));
   return rc;
 }
 static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, bool& range_bad) {
@@ -2029,6 +2095,9 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   if (cfg->arch != FPC_ARCH_RESNET && cfg->arch != FPC_ARCH_VGG) return FPC_E_INVALID;
   // the C++ network takes one gray plane (cpp/src/settings.h:19) and has no bf16 plan
   if (cfg->arch == FPC_ARCH_VGG && (cfg->in_channels != 1 || cfg->dtype == FPC_BF16)) return FPC_E_INVALID;
+  // conf_thresh: finite and >= 0.  The maps are probabilities (>= 0), so a negative threshold means the same as 0; it
+  // is refused rather than silently clamped.  (The reference compares `prob >= thresh` with any float: netutils.py:59.)
+  if (!(cfg->conf_thresh >= 0.f) || !(cfg->conf_thresh <= 3.0e38f)) return FPC_E_INVALID;
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30) ||
@@ -2068,7 +2137,22 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
   {
-    int nsub = c->split ? 3 : 2;   // measured: 2 sub-batches for the fp32-MFMA kernels, 3 for the (shorter) split-operand ones
+    // Launch-plan knobs: fpc_config fields (include/fpc.h, FPC_PLAN_*) first, then the FPC_* environment variables as
+    // overrides for A/B runs of an unmodified caller.
+    int nsub = cfg->num_streams > 0 ? std::min(8, cfg->num_streams) : (c->split ? 3 : 2);   // measured: 2 sub-batches for the fp32-MFMA kernels, 3 for the (shorter) split-operand ones
+    const unsigned pf = cfg->plan_flags;
+    c->fuse_blocks = !(pf & FPC_PLAN_NO_FUSED_BLOCKS);
+    c->winograd = !(pf & FPC_PLAN_NO_WINOGRAD);
+    c->winograd_det = !(pf & FPC_PLAN_NO_WINOGRAD_DETECTOR);
+    c->winograd_in1 = !(pf & FPC_PLAN_NO_WINOGRAD_LAYER_IN1);
+    c->xcd_order = !(pf & FPC_PLAN_NO_XCD_ORDER);
+    c->fuse_stem_pool = !(pf & FPC_PLAN_NO_FUSED_STEM_POOL);
+    c->split_heads = (pf & FPC_PLAN_SPLIT_HEADS) != 0;
+    if (pf & FPC_PLAN_NO_PERSISTENT_GRID) c->persist_min_tiles = 0;
+    c->layer1_t816 = (pf & FPC_PLAN_LAYER1_TILE_8x16) != 0;
+    if (cfg->min_sub_batch > 0) c->min_sub = cfg->min_sub_batch;
+    if (cfg->nms_round_launches > 0) c->nms_passes = std::min(64, cfg->nms_round_launches);
+    else if (cfg->nms_round_launches < 0) c->nms_passes = 0;
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
@@ -2080,6 +2164,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_FUSE_STEM")) c->fuse_stem_pool = atoi(e) != 0;
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("FPC_NMS_G")) c->nms_g = std::max(0, std::min(64, atoi(e)));
+    if (getenv("FPC_L1_T816")) c->layer1_t816 = true;
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < nsub; ++i) {
       hipStream_t st;
@@ -2095,6 +2180,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     // 0.26 -> 0.30 ms), which is all a per-kernel roofline measured inside the timed region would show of it.
     if (const char* e = getenv("FPC_SPLIT_HEADS")) c->split_heads = atoi(e) != 0;
     c->nms_aside = !c->split;  // measured: +1.5 % with two sub-batches (fp32-MFMA kernels), nothing with three (split modes)
+    if (pf & FPC_PLAN_NMS_IN_LINE) c->nms_aside = false;
     if (const char* e = getenv("FPC_NMS_ASIDE")) c->nms_aside = atoi(e) != 0;
     if (c->split_heads) c->nms_aside = false;
     // one side stream per sub-batch only while main + aux + side <= 4 streams, otherwise just the first
@@ -2137,6 +2223,10 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   }
 #endif
   int rc = build_plan(c.get());
+  if (rc == FPC_OK && c->plan_error) {
+    g_hip_err = "no kernel instance for a layer of this dtype / arch combination";
+    rc = FPC_E_INVALID;
+  }
   if (rc != FPC_OK) {
     fpc_destroy(c.release());  // streams, events and whatever build_plan had allocated
     return rc;
@@ -2200,7 +2290,12 @@ int fpc_export_packed(fpc_ctx* c, void* dst, size_t cap) {
 }
 
 int fpc_import_packed(fpc_ctx* c, const void* src, size_t n) {
-  if (!c || !src || n != c->blob_floats * sizeof(float)) return FPC_E_INVALID;
+  if (!c || !src) return FPC_E_INVALID;
+  if (n != c->blob_floats * sizeof(float)) {
+    g_hip_err = "packed weights: " + std::to_string(n) + " bytes, this context's plan packs " + std::to_string(c->blob_floats * sizeof(float));
+    return FPC_E_INVALID;
+  }
+  if (!check_blob_header(c, static_cast<const uint32_t*>(src), &g_hip_err)) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   HIPCHECK(hipMemcpy(c->blob, src, n, hipMemcpyHostToDevice));
   c->weights_loaded = true;
@@ -2209,6 +2304,106 @@ int fpc_import_packed(fpc_ctx* c, const void* src, size_t n) {
 
 int fpc_mark_weights_loaded(fpc_ctx* c) {
   if (!c) return FPC_E_INVALID;
+  // the blob was written in place (a collective into fpc_packed_device_ptr): it must carry this context's tag
+  uint32_t h[BLOB_HEADER_FLOATS];
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipMemcpy(h, c->blob, sizeof(h), hipMemcpyDeviceToHost));
+  if (!check_blob_header(c, h, &g_hip_err)) {
+    c->weights_loaded = false;
+    return FPC_E_INVALID;
+  }
+  c->weights_loaded = true;
+  return FPC_OK;
+}
+
+uint64_t fpc_plan_hash(const fpc_ctx* c) { return c ? plan_hash(c) : 0; }
+
+// RCCL is resolved at run time: first among the libraries the process already holds (a torch host has
+// torch/lib/librccl.so mapped; the communicator the caller passes came from THAT copy), then the system's.
+namespace {
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_rank_fn)(void*, int*);
+struct RcclApi {
+  nccl_bcast_fn bcast = nullptr;
+  nccl_rank_fn user_rank = nullptr;
+  bool tried = false;
+};
+static RcclApi g_rccl;
+static bool load_rccl() {
+  if (g_rccl.tried) return g_rccl.bcast && g_rccl.user_rank;
+  g_rccl.tried = true;
+  void* h = nullptr;
+  void* f = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+  if (!f) {
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    f = dlsym(h, "ncclBroadcast");
+  }
+  g_rccl.bcast = reinterpret_cast<nccl_bcast_fn>(f);
+  void* r = h ? dlsym(h, "ncclCommUserRank") : dlsym(RTLD_DEFAULT, "ncclCommUserRank");
+  g_rccl.user_rank = reinterpret_cast<nccl_rank_fn>(r);
+  return g_rccl.bcast && g_rccl.user_rank;
+}
+}  // namespace
+
+int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
+  if (!c || !nccl_comm || root < 0) return FPC_E_INVALID;
+  if (!load_rccl()) {
+    g_hip_err = "librccl.so (ncclBroadcast / ncclCommUserRank) could not be resolved";
+    return FPC_E_HIP;
+  }
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  int rank = -1;
+  if (g_rccl.user_rank(nccl_comm, &rank) != 0 || rank < 0) {
+    g_hip_err = "ncclCommUserRank failed";
+    return FPC_E_HIP;
+  }
+  const bool is_root = rank == root;
+  // Step 1: the 64-byte tag alone, into scratch -- every rank learns what the root is about to send BEFORE the
+  // collective whose size depends on it.  A root without weights sends a tag with the weights-present flag clear.
+  uint32_t* tag_dev = nullptr;
+  HIPCHECK(hipMalloc((void**)&tag_dev, sizeof(uint32_t) * BLOB_HEADER_FLOATS));
+  uint32_t tag[BLOB_HEADER_FLOATS];
+  if (is_root) {
+    fill_blob_header(c, tag);
+    if (!c->weights_loaded) tag[8] = 0;
+    hipMemcpyAsync(tag_dev, tag, sizeof(tag), hipMemcpyHostToDevice, c->stream);
+  }
+  int nrc = g_rccl.bcast(tag_dev, tag_dev, sizeof(tag), /*ncclUint8*/ 1, root, nccl_comm, c->stream);
+  hipError_t he = hipMemcpyAsync(tag, tag_dev, sizeof(tag), hipMemcpyDeviceToHost, c->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+  hipFree(tag_dev);
+  if (nrc != 0 || he != hipSuccess) {
+    g_hip_err = nrc ? "ncclBroadcast(tag) failed: ncclResult " + std::to_string(nrc) : std::string("tag copy: ") + hipGetErrorString(he);
+    return FPC_E_HIP;
+  }
+  if (tag[0] != BLOB_MAGIC || tag[8] != 1) {   // every rank sees the same tag: all return here, no rank is left in step 2
+    g_hip_err = "the root rank holds no packed weights (load them on the root before fpc_broadcast_weights)";
+    return FPC_E_NO_WEIGHTS;
+  }
+  // Step 2: the blob, `root_bytes` long on EVERY rank.  A rank whose own plan differs still takes part (into scratch), so
+  // that no rank is left waiting in the collective; it then reports the mismatch.
+  const size_t root_bytes = (((size_t)tag[7] << 32) | tag[6]) * sizeof(float);
+  std::string why;
+  const bool match = check_blob_header(c, tag, &why);
+  void* dst = c->blob;
+  void* scratch = nullptr;
+  if (!match) {
+    HIPCHECK(hipMalloc(&scratch, root_bytes));
+    dst = scratch;
+  }
+  nrc = g_rccl.bcast(dst, dst, root_bytes, 1, root, nccl_comm, c->stream);
+  he = hipStreamSynchronize(c->stream);
+  if (scratch) hipFree(scratch);
+  if (nrc != 0 || he != hipSuccess) {
+    g_hip_err = nrc ? "ncclBroadcast(weights) failed: ncclResult " + std::to_string(nrc) : std::string("broadcast: ") + hipGetErrorString(he);
+    return FPC_E_HIP;
+  }
+  if (!match) {
+    g_hip_err = why;
+    return FPC_E_INVALID;
+  }
   c->weights_loaded = true;
   return FPC_OK;
 }
@@ -2266,6 +2461,51 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
   }
   HIPCHECK(hipGetLastError());
   return FPC_OK;
+}
+
+// Tensors the last forward left in the workspace, by the reference module that produced them.
+int fpc_read_activation(fpc_ctx* c, const char* name, int frame0, int n, float* out, int* channels, int* height, int* width) {
+  if (!c || !name || frame0 < 0 || n < 0 || frame0 + n > c->B) return FPC_E_INVALID;
+  if (c->vgg) return FPC_E_INVALID;   // the C++ network's layers are read through fpc_forward only
+  const int H4 = c->H / 4, W4 = c->W / 4, Hc = c->Hc, Wc = c->Wc, H16 = c->H / 16, W16 = c->W / 16;
+  const bool lowp = c->bf16;          // bf16 tensors (all but the pooled stem output, the logits and the descriptor map)
+  struct Tap { const char* name; const void* p; int cs, C, H, W; bool bf; int off; };
+  const Tap taps[] = {
+      {"pool", c->x0, 64, 64, H4, W4, false, 0},
+      {"layer1.0", c->x1, 64, 64, H4, W4, lowp, 0},
+      {"layer1.1", c->x2, 64, 64, H4, W4, lowp, 0},
+      {"layer2.0", c->x3, 128, 128, Hc, Wc, lowp, 0},
+      {"layer2.1", c->cat, 256, 128, Hc, Wc, lowp, 128},
+      {"det.0", c->d0, (c->bf16 || c->split) ? 80 : 72, 65, Hc, Wc, lowp, 0},
+      {"det.1", c->lg, c->lgcs, 65, Hc, Wc, false, 0},
+      {"desc_in.0", c->y16a, 256, 256, H16, W16, lowp, 0},
+      {"desc_in.1", c->y16b, 256, 256, H16, W16, lowp, 0},
+      {"up", c->cat, 256, 128, Hc, Wc, lowp, 0},
+      {"desc_out.0", c->lo0, 128, 128, Hc, Wc, lowp, 0},
+      {"desc_out.1", c->desc_map, 128, 128, Hc, Wc, false, 0},
+  };
+  for (const Tap& t : taps) {
+    if (strcmp(t.name, name)) continue;
+    if (!c->cfg.descriptor_enabled && (!strncmp(name, "desc", 4) || !strcmp(name, "up"))) return FPC_E_INVALID;
+    if (channels) *channels = t.C;
+    if (height) *height = t.H;
+    if (width) *width = t.W;
+    if (!out || n == 0) return FPC_OK;
+    HIPCHECK(hipSetDevice(c->cfg.device));
+    const int HW = t.H * t.W;
+    const size_t tot = (size_t)n * t.C * HW;
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    if (t.bf) {
+      const unsigned short* src = static_cast<const unsigned short*>(t.p) + t.off + (size_t)frame0 * HW * t.cs;
+      hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, grid, dim3(256), 0, c->stream, src, t.cs, t.C, HW, n, out);
+    } else {
+      const float* src = static_cast<const float*>(t.p) + t.off + (size_t)frame0 * HW * t.cs;
+      hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, c->stream, src, t.cs, t.C, HW, n, out);
+    }
+    HIPCHECK(hipGetLastError());
+    return FPC_OK;
+  }
+  return FPC_E_INVALID;
 }
 
 int fpc_detect(fpc_ctx* c, const float* frames, int n) {
@@ -2408,6 +2648,23 @@ int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n)
                        c->D, c->Hc * c->Wc, n, c->desc_in_nhwc);
     run_desc(c, all, c->desc_in_nhwc);
   }
+  HIPCHECK(hipGetLastError());
+  return FPC_OK;
+}
+
+int fpc_sample_descriptors(fpc_ctx* c, const float* desc_nchw, const double* xy, int k, float* out) {
+  if (!c || !desc_nchw || k < 0 || (k > 0 && (!xy || !out))) return FPC_E_INVALID;
+  if (k == 0) return FPC_OK;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  const size_t tot = (size_t)c->D * c->Hc * c->Wc;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, desc_nchw, c->D,
+                     c->Hc * c->Wc, 1, c->desc_in_nhwc);
+  if (c->D == 256)
+    hipLaunchKernelGGL(descriptor_at_points_kernel<4>, dim3((k + 3) / 4), dim3(256), 0, c->stream, c->desc_in_nhwc, 256,
+                       c->Hc, c->Wc, c->H, c->W, xy, k, out);
+  else
+    hipLaunchKernelGGL(descriptor_at_points_kernel<2>, dim3((k + 3) / 4), dim3(256), 0, c->stream, c->desc_in_nhwc, 128,
+                       c->Hc, c->Wc, c->H, c->W, xy, k, out);
   HIPCHECK(hipGetLastError());
   return FPC_OK;
 }

@@ -318,6 +318,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* 
 // (float bits of p where p >= thresh, else 0) and appends candidates to the
 // frame's list (order irrelevant: NMS below is order-free, the sort is total).
 // ---------------------------------------------------------------------------------
+// NMS state word of a candidate with probability p >= 0: float bits + 1, so that an undecided candidate is never the
+// word 0 ("empty / suppressed") -- with conf_thresh == 0 a candidate may have p == +0.0 -- and never has the sign bit
+// ("kept").  -0.0 counts as +0.0.  Bits of non-negative floats order like the floats, and so do bits + 1.
+__device__ __forceinline__ uint32_t nms_state_word(float p) { return (p == 0.f ? 0u : __float_as_uint(p)) + 1u; }
+__device__ __forceinline__ float nms_state_conf(uint32_t word) { return __uint_as_float((word & 0x7fffffffu) - 1u); }
+
 __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
                                                           float thresh, float* prob, uint32_t* nmsmap,
                                                           uint32_t* cand, int32_t* ncand) {
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
     const float p = strip[k];
     const bool c = p >= thresh;
     prob[fbase + k] = p;
-    nmsmap[fbase + k] = c ? __float_as_uint(p) : 0u;
+    nmsmap[fbase + k] = c ? nms_state_word(p) : 0u;
     const unsigned long long mask = __ballot(c);
     if (mask) {
       int off = 0;
@@ -376,7 +382,8 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
   for (int k = tid; k < n; k += 256) dst[k] = (uint32_t)(i * 8 * W) + s_list[k];
 }
 
-// Same outputs from a caller-provided dense probability map (fpc_get_points).
+// Same outputs from a caller-provided dense probability map (fpc_get_points).  The map is a probability map: entries
+// must be >= 0 (fpc_create rejects conf_thresh < 0; with conf_thresh == 0 every non-negative pixel is a candidate).
 __global__ __launch_bounds__(256) void threshold_kernel(const float* prob, int B, int HW, float thresh,
                                                         uint32_t* nmsmap, uint32_t* cand, int32_t* ncand) {
   const int lane = threadIdx.x & 63;
@@ -387,8 +394,8 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float* prob, int B
   if (b >= B) return;
   const bool in = idx < HW;
   const float p = in ? prob[(size_t)b * HW + idx] : 0.f;
-  const bool c = in && p >= thresh;
-  if (in) nmsmap[(size_t)b * HW + idx] = c ? __float_as_uint(p) : 0u;
+  const bool c = in && p >= thresh && p >= 0.f;   // probabilities: negative entries (and NaN) never become candidates
+  if (in) nmsmap[(size_t)b * HW + idx] = c ? nms_state_word(p) : 0u;
   const unsigned long long mask = __ballot(c);
   if (mask) {
     int base = 0;
@@ -414,8 +421,8 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float* prob, int B
 // Priority = (confidence, then smaller row-major index) -- the tie order this
 // build defines (the reference's is unspecified: numpy's unstable argsort).
 //
-// State map word: 0 = empty / suppressed, float bits (> 0) = undecided candidate,
-// float bits | 0x80000000 = kept.
+// State map word: 0 = empty / suppressed, float bits + 1 (> 0, see nms_state_word) = undecided
+// candidate, that | 0x80000000 = kept.
 // ---------------------------------------------------------------------------------
 struct NmsArgs {
   uint32_t* nmsmap;        // [B][H*W]
@@ -582,14 +589,15 @@ __device__ __forceinline__ void nms_sort_body(const NmsArgs& a, KeyPtr keys, int
       }
       __syncthreads();
     }
-  if (tid == 0) a.count[b] = K;
+  // a caller-chosen capacity (fpc_config.max_keypoints) below K keeps the `cap` most confident points
+  if (tid == 0) a.count[b] = K < a.cap ? K : a.cap;
   for (int i = tid; i < K && i < a.cap; i += 1024) {
     const unsigned long long k = keys[i];
     const uint32_t ci = 0xffffffffu - (uint32_t)(k & 0xffffffffu);
     const int y = ci / W, x = ci - y * W;
     a.xy[((size_t)b * a.cap + i) * 2 + 0] = x;
     a.xy[((size_t)b * a.cap + i) * 2 + 1] = y;
-    a.conf[(size_t)b * a.cap + i] = __uint_as_float((uint32_t)(k >> 32));
+    a.conf[(size_t)b * a.cap + i] = nms_state_conf((uint32_t)(k >> 32));
   }
 }
 
@@ -642,25 +650,15 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
 // division by the L2 norm (no epsilon).  One wave per keypoint, lane = 2 channels of
 // the NHWC descriptor map (D = 128): each corner is one 512-byte coalesced read.
 // ---------------------------------------------------------------------------------
+// One keypoint per wave: `base` = the frame's NHWC map + VPL * lane, (gx, gy) the grid coordinates in [-1, 1].
 template <int VPL>  // values per lane: 2 (D = 128, python net) or 4 (D = 256, cpp/src/settings.h:25)
-__global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
-                                                         const int32_t* count, const int32_t* xy, int cap,
-                                                         float* out) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int K = min(count[b], cap);
-  if (k >= K) return;
-  const int px = xy[((size_t)b * cap + k) * 2], py = xy[((size_t)b * cap + k) * 2 + 1];
-  const float gx = (float)((double)px / ((double)W / 2.) - 1.);
-  const float gy = (float)((double)py / ((double)H / 2.) - 1.);
+__device__ __forceinline__ void descriptor_sample(const float* base, int cs, int Hc, int Wc, float gx, float gy, float* dst) {
   const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
   const float iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
   const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), x1 = x0 + 1, y1 = y0 + 1;
   const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
   const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
   const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc, vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
-  const float* base = dmap + (size_t)b * Hc * Wc * cs + VPL * lane;
   float v[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) v[i] = 0.f;
@@ -689,11 +687,40 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int 
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float nrm = sqrtf(ss);
-  float* dst = out + ((size_t)b * cap + k) * (64 * VPL) + VPL * lane;
   if (VPL == 2)
     *reinterpret_cast<float2*>(dst) = make_float2(v[0] / nrm, v[1] / nrm);
   else
     *reinterpret_cast<float4*>(dst) = make_float4(v[0] / nrm, v[1] / nrm, v[VPL - 2] / nrm, v[VPL - 1] / nrm);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
+                                                         const int32_t* count, const int32_t* xy, int cap,
+                                                         float* out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int K = min(count[b], cap);
+  if (k >= K) return;
+  const int px = xy[((size_t)b * cap + k) * 2], py = xy[((size_t)b * cap + k) * 2 + 1];
+  const float gx = (float)((double)px / ((double)W / 2.) - 1.);
+  const float gy = (float)((double)py / ((double)H / 2.) - 1.);
+  descriptor_sample<VPL>(dmap + (size_t)b * Hc * Wc * cs + VPL * lane, cs, Hc, Wc, gx, gy,
+                         out + ((size_t)b * cap + k) * (64 * VPL) + VPL * lane);
+}
+
+// get_descriptors on its own (netutils.py:103-121): K caller-provided points (x, y) as float64 -- the reference's
+// `points` array -- on ONE descriptor map; the normalisation runs in double and is rounded to float once, as
+// `sample_points.float()` does there.  out [K][D].
+template <int VPL>
+__global__ __launch_bounds__(256) void descriptor_at_points_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
+                                                                   const double* xy, int K, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const float gx = (float)(xy[(size_t)k * 2] / ((double)W / 2.) - 1.);
+  const float gy = (float)(xy[(size_t)k * 2 + 1] / ((double)H / 2.) - 1.);
+  descriptor_sample<VPL>(dmap + VPL * lane, cs, Hc, Wc, gx, gy, out + (size_t)k * (64 * VPL) + VPL * lane);
 }
 
 // NHWC (pixel stride cs, first C channels) -> NCHW, for the reference-layout dense outputs.
@@ -704,6 +731,16 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, int 
   const int c = (i / HW) % C;
   const int b = i / ((size_t)HW * C);
   out[i] = in[((size_t)b * HW + p) * cs + c];
+}
+
+// the same from a bf16 NHWC tensor (FPC_BF16 mode; fpc_read_activation)
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_kernel(const unsigned short* in, int cs, int C, int HW, int B, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * C * HW) return;
+  const int p = i % HW;
+  const int c = (i / HW) % C;
+  const int b = i / ((size_t)HW * C);
+  out[i] = __uint_as_float((unsigned)in[((size_t)b * HW + p) * cs + c] << 16);
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, int C, int HW, int B, float* out) {

@@ -43,32 +43,66 @@ def shard_range(n_frames, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class WeightBroadcastError(RuntimeError):
+    """Raised on EVERY rank when the start-up exchange cannot go ahead (the source rank failed to load the
+    checkpoint, or some rank's engine would lay the blob out differently)."""
+
+
+def _coll_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def broadcast_packed_weights(engine, state_dict, src=0):
-    """Rank `src` loads `state_dict` into its engine; every other rank receives the packed,
-    BN-folded blob.  With NCCL/RCCL the broadcast writes straight into the library's
-    device buffer; with gloo it goes through host memory."""
+    """Rank `src` loads `state_dict` into its engine; every other rank receives the packed, BN-folded blob.
+
+    Three collectives, all of fixed size until every rank has agreed to the last one:
+      1. a 4-word status from `src`: (loaded ok, blob bytes, launch-plan hash lo / hi).  If the source rank failed in
+         load_state_dict (missing key, shape, FPC_E_RANGE) every rank raises WeightBroadcastError here, instead of the
+         others waiting in a broadcast for the backend's time-out;
+      2. a MAX all-reduce of "my engine disagrees" (blob size or plan hash: another dtype, arch, build or FPC_* plan
+         knob) -- again every rank raises together;
+      3. the blob.  It carries its own tag, which fpc_import_packed / fpc_mark_weights_loaded verify once more.
+    A C/C++ host does the same through fpc_broadcast_weights(ctx, ncclComm_t, root) (include/fpc.h)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         engine.load_state_dict(state_dict)
         return
     rank = dist.get_rank()
+    dev = _coll_device()
+    err = None
     if rank == src:
-        engine.load_state_dict(state_dict)
+        try:
+            engine.load_state_dict(state_dict)
+        except Exception as e:              # reported to every rank below, then re-raised here
+            err = e
+    n = engine.packed_size()
+    ph = engine.plan_hash() if hasattr(engine, "plan_hash") else 0
+    status = torch.tensor([0 if err is not None else 1, n, ph & 0xffffffff, ph >> 32], dtype=torch.int64, device=dev)
+    dist.broadcast(status, src=src)
+    ok, src_n, src_lo, src_hi = (int(v) for v in status.cpu())
+    if not ok:
+        if err is not None:
+            raise WeightBroadcastError("rank %d could not load the checkpoint: %s" % (src, err)) from err
+        raise WeightBroadcastError("rank %d could not load the checkpoint (see its log)" % src)
+    mine_differs = src_n != n or (src_lo | (src_hi << 32)) != ph
+    flag = torch.tensor([1 if mine_differs else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        raise WeightBroadcastError(
+            "rank %d: packed-weight layout %s rank %d's (%d bytes, plan %016x here; %d bytes, plan %016x there): every "
+            "rank must run the same build with the same dtype / arch / plan knobs"
+            % (rank, "differs from" if mine_differs else "matches, but another rank's differs from", src, n, ph, src_n,
+               src_lo | (src_hi << 32)))
     if dist.get_backend() == "nccl":
         # RCCL broadcast over xGMI, device to device, of a torch-owned buffer (16 MB, start-up only), then one copy
         # into the library.  FPC_DIST_ZERO_COPY=1 broadcasts straight into the library's blob instead (a tensor view
-        # of memory the library allocated): it saves that copy, but a failure on SOME ranks only would leave the ranks
-        # in different collectives, so it is opt-in and every rank must set it.
-        done = False
+        # of memory the library allocated): it saves that copy; every rank must set it.
         if os.environ.get("FPC_DIST_ZERO_COPY") == "1":
             view = engine.packed_view()
             dist.broadcast(view, src=src)
             torch.cuda.synchronize()
             if rank != src:
-                engine.mark_weights_loaded()
-            done = True
-        if not done:
-            n = engine.packed_size()
-            dev = torch.device("cuda", torch.cuda.current_device())
+                engine.mark_weights_loaded()      # verifies the tag that arrived
+        else:
             buf = (torch.from_numpy(engine.export_packed()).to(dev) if rank == src
                    else torch.empty(n, dtype=torch.uint8, device=dev))
             dist.broadcast(buf, src=src)
@@ -76,7 +110,6 @@ def broadcast_packed_weights(engine, state_dict, src=0):
             if rank != src:
                 engine.import_packed(buf.cpu().numpy())
     else:
-        n = engine.packed_size()
         buf = torch.from_numpy(engine.export_packed()) if rank == src else torch.empty(n, dtype=torch.uint8)
         dist.broadcast(buf, src=src)
         if rank != src:

@@ -43,7 +43,8 @@ def _as_tensor_table(state_dict):
 
 class Engine:
     def __init__(self, height, width, max_batch=1, device=0, nms_dist=4, conf_thresh=0.015,
-                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3, dtype="f32", arch="resnet"):
+                 border_remove=4, descriptor_enabled=True, max_keypoints=0, in_channels=3, dtype="f32", arch="resnet",
+                 num_streams=0, plan_flags=(), nms_round_launches=0, min_sub_batch=0):
         self._l = _lib.load()          # raises if libfpc.so is not built: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("fpc_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -64,6 +65,12 @@ class Engine:
         cfg.arch = 1 if arch == "vgg" else 0     # FPC_ARCH_RESNET / FPC_ARCH_VGG
         self.arch = arch
         self.in_channels = 1 if in_channels == 1 else 3
+        # launch-plan knobs (fpc_config.num_streams / plan_flags / ...; zeros = the default plan)
+        cfg.num_streams, cfg.nms_round_launches, cfg.min_sub_batch = num_streams, nms_round_launches, min_sub_batch
+        flags = 0
+        for f in ([plan_flags] if isinstance(plan_flags, (str, int)) else plan_flags):
+            flags |= f if isinstance(f, int) else _lib.PLAN_FLAGS[f]
+        cfg.plan_flags = flags
         self.cfg = cfg
         self.h, self.w, self.max_batch, self.device = height, width, max_batch, device
         self.descriptor_enabled = bool(descriptor_enabled)
@@ -115,6 +122,14 @@ class Engine:
 
     def mark_weights_loaded(self):
         _lib.check(self._l.fpc_mark_weights_loaded(self._ctx), "fpc_mark_weights_loaded")
+
+    def plan_hash(self):
+        """Equal on two engines iff they can exchange packed weights (same build, dtype, arch, launch plan)."""
+        return int(self._l.fpc_plan_hash(self._ctx))
+
+    def broadcast_weights(self, nccl_comm, root=0):
+        """fpc_broadcast_weights: RCCL broadcast of the packed blob on a raw ncclComm_t (an int / c_void_p)."""
+        _lib.check(self._l.fpc_broadcast_weights(self._ctx, ctypes.c_void_p(nccl_comm), root), "fpc_broadcast_weights")
 
     # -- execution -------------------------------------------------------------------
     def use_torch_stream(self):
@@ -224,6 +239,41 @@ class Engine:
         torch.cuda.synchronize(self.torch_device)
         _lib.check(self._l.fpc_get_points(self._ctx, prob_map.data_ptr(), dptr, n), "fpc_get_points")
         return self.fetch(n, with_desc=desc_map is not None)
+
+    def sample_descriptors(self, desc_map, xy):
+        """get_descriptors on its own (netutils.py:103-121): desc_map [D,H/8,W/8] (or [1,D,H/8,W/8]), xy float64 [K,2]
+        (x, y) in pixels -> unit-norm descriptors float32 [K,D] (numpy)."""
+        if not isinstance(desc_map, torch.Tensor):
+            desc_map = torch.from_numpy(np.ascontiguousarray(desc_map, dtype=np.float32))
+        dm = desc_map.to(self.torch_device, torch.float32).contiguous()
+        if dm.dim() == 4 and dm.shape[0] == 1:
+            dm = dm[0]
+        if tuple(dm.shape) != (self.desc_dim, self.h // 8, self.w // 8):
+            raise ValueError("descriptor map must be [%d,%d,%d], got %s" % (self.desc_dim, self.h // 8, self.w // 8, tuple(dm.shape)))
+        pts = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)).to(self.torch_device)
+        k = pts.shape[0]
+        out = torch.empty((k, self.desc_dim), dtype=torch.float32, device=self.torch_device)
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_sample_descriptors(self._ctx, dm.data_ptr(), pts.data_ptr(), k, out.data_ptr()),
+                   "fpc_sample_descriptors")
+        self.sync()
+        return out.cpu().numpy()
+
+    ACTIVATIONS = ("pool", "layer1.0", "layer1.1", "layer2.0", "layer2.1", "det.0", "det.1", "desc_in.0", "desc_in.1",
+                   "up", "desc_out.0", "desc_out.1")
+
+    def activation(self, name, frame0=0, n=1):
+        """Intermediate tensor of the LAST forward / detect call as a forward hook on the reference module would return
+        it: float32 CUDA tensor [n,C,h,w] (fpc_read_activation)."""
+        c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._l.fpc_read_activation(self._ctx, name.encode(), frame0, n, None, ctypes.byref(c), ctypes.byref(h),
+                                               ctypes.byref(w)), "fpc_read_activation")
+        out = torch.empty((n, c.value, h.value, w.value), dtype=torch.float32, device=self.torch_device)
+        torch.cuda.synchronize(self.torch_device)
+        _lib.check(self._l.fpc_read_activation(self._ctx, name.encode(), frame0, n, out.data_ptr(), None, None, None),
+                   "fpc_read_activation")
+        self.sync()
+        return out
 
     def sync(self):
         _lib.check(self._l.fpc_sync(self._ctx), "fpc_sync")

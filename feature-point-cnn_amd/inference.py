@@ -196,8 +196,15 @@ def get_descriptors(points, descriptors_map, img_h, img_w, settings, engine=None
     d = descriptors_map.shape[1]
     if points.shape[1] == 0:
         return np.zeros((d, 0))
-    raise NotImplementedError("use InferenceWrapper.run / Engine.get_points(prob_map, desc_map): "
-                              "points and descriptors are produced in one device pass")
+    if descriptors_map.dim() != 4 or descriptors_map.shape[0] != 1:
+        raise ValueError("get_descriptors takes one frame's map [1,D,H/8,W/8]")
+    # the descriptor head is not needed to SAMPLE a map: an engine made here is detector-only (small workspace)
+    e = engine or Engine(img_h, img_w, 1, descriptors_map.device.index or 0, settings.nms_dist,
+                         settings.confidence_thresh, settings.border_remove, False)
+    if e.desc_dim != d or e.h != img_h or e.w != img_w:
+        raise ValueError("engine geometry %dx%d D=%d does not match the map (%dx%d, D=%d)" % (e.h, e.w, e.desc_dim, img_h, img_w, d))
+    pts = np.ascontiguousarray(np.asarray(points, np.float64)[:2, :].T)       # [K,2] (x, y), float64 as in the reference
+    return np.ascontiguousarray(e.sample_descriptors(descriptors_map[0], pts).T)
 
 
 def get_features(frame, net):

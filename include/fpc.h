@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 1
+#define FPC_ABI_VERSION 2
 
 enum {
   FPC_OK = 0,
@@ -56,10 +56,11 @@ typedef struct fpc_config {
   int max_batch;          /* frames per fpc_detect / fpc_forward call              */
   int cell;               /* 8   settings.py:7   (only 8 is supported)             */
   int nms_dist;           /* 4   settings.py:4                                     */
-  float conf_thresh;      /* 0.015 settings.py:5                                   */
+  float conf_thresh;      /* 0.015 settings.py:5; finite and >= 0 (probabilities)  */
   int border_remove;      /* 4   settings.py:8                                     */
   int descriptor_enabled; /* 0 = MagicPoint, detector only (superpoint.py:103-109) */
-  int max_keypoints;      /* per-frame output capacity; 0 = worst case for nms_dist */
+  int max_keypoints;      /* per-frame output capacity; 0 = worst case for nms_dist; */
+                          /* a smaller value keeps the most confident points        */
   int in_channels;        /* 0 or 3: frames [n,3,H,W] (superpoint.py:12); 1: gray frames   */
                           /* [n,1,H,W] -- what the reference feeds after replicating the   */
                           /* plane x3 (dataset_utils.py:19-20, cpp/src/camera.cc:17-18)    */
@@ -76,8 +77,27 @@ typedef struct fpc_config {
                           /* FPC_ARCH_VGG (1): the C++ frontend's superpoint::SPModel        */
                           /* (cpp/src/model.cc, settings.h:19-25): gray input                */
                           /* (in_channels = 1), 256-D descriptors, fp32 or split mode        */
-  int reserved[4];
+  /* Launch-plan knobs (zeros = the default plan).  The FPC_* environment variables of the
+   * same names still override them, for A/B runs of an unmodified caller. */
+  int num_streams;        /* sub-batches of one call on separate HIP streams; 0 = default (2; 3 in split modes)  */
+  unsigned plan_flags;    /* FPC_PLAN_* bits                                                                   */
+  int nms_round_launches; /* parallel NMS launches before the per-frame finish: 0 = default (2), -1 = none     */
+  int min_sub_batch;      /* smallest sub-batch worth its own stream: 0 = default (8); calls below twice this   */
+                          /* take the latency plan                                                             */
 } fpc_config;
+
+enum {
+  FPC_PLAN_NO_FUSED_BLOCKS = 1 << 0,       /* conv1 / conv2 of a ResNetBlock as two launches            (FPC_FUSE=0)         */
+  FPC_PLAN_NO_WINOGRAD = 1 << 1,           /* direct 3x3 convolutions everywhere                        (FPC_WINOGRAD=0)     */
+  FPC_PLAN_NO_WINOGRAD_DETECTOR = 1 << 2,  /* ... in the detector's 65-channel blocks only              (FPC_WINOGRAD_DET=0) */
+  FPC_PLAN_NO_WINOGRAD_LAYER_IN1 = 1 << 3, /* descriptor.layer_in.1 as the fused direct block           (FPC_WINOGRAD_IN1=0) */
+  FPC_PLAN_NO_XCD_ORDER = 1 << 4,          /* plain tile order instead of the XCD-aware one             (FPC_XCD_ORDER=0)    */
+  FPC_PLAN_NO_FUSED_STEM_POOL = 1 << 5,    /* stem convolution and max-pool as two launches             (FPC_FUSE_STEM=0)    */
+  FPC_PLAN_SPLIT_HEADS = 1 << 6,           /* detector head + NMS on a side stream next to the descriptor head (FPC_SPLIT_HEADS=1) */
+  FPC_PLAN_NMS_IN_LINE = 1 << 7,           /* NMS on the sub-batch stream, not on a side stream         (FPC_NMS_ASIDE=0)    */
+  FPC_PLAN_NO_PERSISTENT_GRID = 1 << 8,    /* one workgroup per tile in the Winograd kernels            (FPC_PERSIST_MIN=0)  */
+  FPC_PLAN_LAYER1_TILE_8x16 = 1 << 9       /* direct layer1 blocks on 8x16 instead of 16x16 tiles       (FPC_L1_T816=1)      */
+};
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']
  * (python/src/saveutils.py:57-62), data in host memory. */
@@ -128,8 +148,22 @@ size_t fpc_packed_size(const fpc_ctx* ctx);
 void* fpc_packed_device_ptr(fpc_ctx* ctx);              /* in-place collective target */
 int fpc_export_packed(fpc_ctx* ctx, void* host_dst, size_t cap);
 int fpc_import_packed(fpc_ctx* ctx, const void* host_src, size_t n);
-/* Declares the blob at fpc_packed_device_ptr valid (after a broadcast into it). */
+/* Declares the blob at fpc_packed_device_ptr valid (after a broadcast into it).  The blob starts with a 64-byte tag
+ * (magic, ABI version, dtype, arch, launch-plan hash, size); fpc_import_packed and this call refuse a blob whose tag
+ * does not match the context (FPC_E_INVALID; fpc_last_hip_error says which field). */
 int fpc_mark_weights_loaded(fpc_ctx* ctx);
+/* Hash of everything the blob layout depends on -- equal on two contexts iff they can exchange packed weights. */
+uint64_t fpc_plan_hash(const fpc_ctx* ctx);
+
+/* Frame-batch sharding over the GPUs of a node (the heaviest batch caller to shard is
+ * python/src/preprocess_coco.py:64-74): the ONE exchange of the path.  The root rank has loaded the checkpoint
+ * (fpc_load_weights); every rank of the communicator calls this with its own ctx, and receives the packed, BN-folded
+ * blob by ncclBroadcast (RCCL over xGMI) straight into its device buffer -- no other rank parses the file.
+ * nccl_comm is an ncclComm_t (passed as void* so that this header needs no rccl.h); librccl.so is resolved at run
+ * time (FPC_E_HIP if absent).  Two collectives on the ctx stream: the 64-byte tag, then the blob; a root without
+ * weights makes every rank return FPC_E_NO_WEIGHTS after the first; a rank whose ctx (dtype, arch, plan, build)
+ * differs from the root's still completes both collectives, then returns FPC_E_INVALID.  Synchronous. */
+int fpc_broadcast_weights(fpc_ctx* ctx, void* nccl_comm, int root);
 
 /* Work is enqueued on this hipStream_t (default: a stream the ctx owns). */
 int fpc_set_stream(fpc_ctx* ctx, void* hip_stream);
@@ -142,6 +176,17 @@ int fpc_sync(fpc_ctx* ctx);
  * (device, NCHW like the reference; any output may be NULL).  Asynchronous. */
 int fpc_forward(fpc_ctx* ctx, const float* frames_dev, int n, float* prob_map_dev,
                 float* desc_dev, float* logits_dev);
+
+/* The intermediate tensors the last fpc_forward / fpc_detect left in the workspace -- what a forward hook on the
+ * reference's modules returns -- for per-layer parity tests (SURVEY.md 8c fixture F1).  name: "pool" (encoder.max_pool),
+ * "layer1.0", "layer1.1", "layer2.0", "layer2.1" (encoder blocks), "det.0", "det.1" (= logits), "desc_in.0",
+ * "desc_in.1", "up" (descriptor.relu after the transposed convolution + bn), "desc_out.0", "desc_out.1" (= the
+ * descriptor map).  Frames frame0 .. frame0+n-1 as float32 NCHW into out_dev [n,C,h,w] (bf16 tensors of the FPC_BF16
+ * mode are widened exactly); channels / height / width receive the tensor's shape (out_dev may be NULL to query it).
+ * The fused kernels never write a block's inner tensor h nor the un-pooled stem output to memory: those have no name
+ * here.  FPC_ARCH_RESNET only.  Asynchronous on the ctx stream. */
+int fpc_read_activation(fpc_ctx* ctx, const char* name, int frame0, int n, float* out_dev, int* channels, int* height,
+                        int* width);
 
 /* ~ InferenceWrapper.run (inferencewrapper.py:29-46) / SuperPoint::ProcessFrame
  * (cpp/src/superpoint.cc:68-96) for n independent frames: forward, exp-softmax,
@@ -193,6 +238,15 @@ int fpc_homography_adaptation(fpc_ctx* ctx, const float* frames_dev, int n, cons
  * [n,H,W] (device) -- get_points on its own (netutils.py:78-100). Descriptors are
  * sampled from desc_nchw_dev [n,128,H/8,W/8] when it is not NULL. */
 int fpc_get_points(fpc_ctx* ctx, const float* prob_map_dev, const float* desc_nchw_dev, int n);
+
+/* ~ get_descriptors(points, descriptors_map, img_h, img_w, settings) on its own (python/src/netutils.py:103-121):
+ * bilinear grid_sample (align_corners=True, zero padding) of ONE descriptor map desc_nchw_dev [D,H/8,W/8] at k
+ * caller-provided points, then division by the L2 norm (no epsilon: an all-zero sample gives NaN, as there).
+ * xy_dev [k][2] float64 (x, y) in pixels of the ctx's H x W frame -- the first two rows of the reference's float64
+ * `points`, transposed; the normalisation x / (W / 2) - 1 runs in double and is rounded to float once, as
+ * `sample_points.float()` does.  out_dev [k][D] (the reference returns the transpose, [D][k]).  All device memory.
+ * Asynchronous on the ctx stream.  Works with descriptor_enabled = 0 too (the map is the caller's). */
+int fpc_sample_descriptors(fpc_ctx* ctx, const float* desc_nchw_dev, const double* xy_dev, int k, float* out_dev);
 
 /* --- next row of the path: descriptor matching ----------------
  * ~ cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(query, train) (python/src/inference.py:88-96):

@@ -431,12 +431,15 @@ int oracle_get_points(const float* prob, int H, int W, float conf_thresh, int nm
 /* grid_sampler_2d; then each column is divided by its L2 norm, no epsilon    */
 /* (:120; an all-zero descriptor gives NaN, as in the reference).             */
 /* ------------------------------------------------------------------------- */
-void oracle_get_descriptors(const float* desc_map, int D, int Hc, int Wc, int H, int W,
-                            const int32_t* xs, const int32_t* ys, int K, float* out) {
+/* One body for both entry points: `xs_i/ys_i` (integer pixels, what get_points returns) or `xy_d` ([K][2] float64, the
+ * reference's `points` array as it stands -- netutils.py:110-112 normalises in float64, :115 rounds to float once). */
+static void get_descriptors_impl(const float* desc_map, int D, int Hc, int Wc, int H, int W, const int32_t* xs,
+                                 const int32_t* ys, const double* xy_d, int K, float* out) {
 #pragma omp parallel for schedule(static)
   for (int k = 0; k < K; ++k) {
-    const float gx = (float)((double)xs[k] / ((double)W / 2.) - 1.);
-    const float gy = (float)((double)ys[k] / ((double)H / 2.) - 1.);
+    const double px = xy_d ? xy_d[2 * (size_t)k] : (double)xs[k], py = xy_d ? xy_d[2 * (size_t)k + 1] : (double)ys[k];
+    const float gx = (float)(px / ((double)W / 2.) - 1.);
+    const float gy = (float)(py / ((double)H / 2.) - 1.);
     const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
     const float iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
     const float fx = floorf(ix), fy = floorf(iy);
@@ -461,6 +464,17 @@ void oracle_get_descriptors(const float* desc_map, int D, int Hc, int Wc, int H,
     const float nrm = sqrtf(ss);
     for (int d = 0; d < D; ++d) out[(size_t)k * D + d] /= nrm;
   }
+}
+
+void oracle_get_descriptors(const float* desc_map, int D, int Hc, int Wc, int H, int W,
+                            const int32_t* xs, const int32_t* ys, int K, float* out) {
+  get_descriptors_impl(desc_map, D, Hc, Wc, H, W, xs, ys, 0, K, out);
+}
+
+/* get_descriptors at arbitrary (fractional, possibly out-of-frame) float64 points xy [K][2] */
+void oracle_get_descriptors_at(const float* desc_map, int D, int Hc, int Wc, int H, int W, const double* xy, int K,
+                               float* out) {
+  get_descriptors_impl(desc_map, D, Hc, Wc, H, W, 0, 0, xy, K, out);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -97,6 +97,122 @@ def forward(image, state_dict, spec, descriptor_enabled=True, with_taps=False):
     return prob, desc, logits
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The same network with the roundings of the product's FPC_BF16 mode (BASELINE.json configs[4]) put where that mode
+# puts them -- so that the bf16 path is held to a bound of a few fp32-accumulation ulps, not to "what 8 significant
+# bits give" (round-1 VERDICT: a 0.25-absolute bound can hide a mis-rounded layer).  What is rounded to bf16
+# (round-to-nearest-even): the frame; every BatchNorm-folded weight (fold in double, round to float, round to bf16);
+# every tensor the mode keeps in bf16 -- h inside a block, block outputs, the transposed convolution's output.  What
+# stays fp32: the stem output / pooled map (it is rounded when the first block reads it), biases, accumulation (here:
+# double), the outputs of detector.layer.1 and descriptor.layer_out.1.  Convolutions are the oracle's own
+# (oracle_conv2d / oracle_conv_transpose2d / oracle_maxpool3s2, double accumulation).
+# ---------------------------------------------------------------------------------------------------------------
+def round_bf16(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return r.view(np.float32)
+
+
+def _conv2d(x, w, stride, pad):
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    b, cin, h, wd = x.shape
+    cout, _, k, _ = w.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    out = np.empty((b, cout, ho, wo), np.float32)
+    lib().oracle_conv2d(_p(x), _p(w), _p(out), b, cin, h, wd, cout, k, stride, pad)
+    return out
+
+
+def _fold(sd, bn):
+    s = sd[bn + ".weight"].astype(np.float64) / np.sqrt(sd[bn + ".running_var"].astype(np.float64) + 1e-5)
+    t = sd[bn + ".bias"].astype(np.float64) - sd[bn + ".running_mean"].astype(np.float64) * s
+    return s, t
+
+
+def _wq(w, s):
+    """BN-folded weight as the product packs it: (float)(w * s) in double, then bf16."""
+    return round_bf16((w.astype(np.float64) * s[:, None, None, None]).astype(np.float32))
+
+
+# (output tensor, input tensor(s)) of every layer of the bf16 plan, by the names of TAP_NAMES / fpc_read_activation
+BF16_LAYERS = [("layer1.0", ("pool",)), ("layer1.1", ("layer1.0",)), ("layer2.0", ("layer1.1",)), ("layer2.1", ("layer2.0",)),
+               ("det.0", ("layer2.1",)), ("det.1", ("det.0",)), ("desc_in.0", ("layer2.1",)), ("desc_in.1", ("desc_in.0",)),
+               ("up", ("desc_in.1",)), ("desc_out.0", ("up", "layer2.1")), ("desc_out.1", ("desc_out.0",))]
+_BF16_BLOCKS = {  # name -> (checkpoint prefix, stride, projection shortcut, fp32 output)
+    "layer1.0": ("encoder.layer1.0", 1, True, False), "layer1.1": ("encoder.layer1.1", 1, False, False),
+    "layer2.0": ("encoder.layer2.0", 2, True, False), "layer2.1": ("encoder.layer2.1", 1, False, False),
+    "det.0": ("detector.layer.0", 1, True, False), "det.1": ("detector.layer.1", 1, False, True),
+    "desc_in.0": ("descriptor.layer_in.0", 2, True, False), "desc_in.1": ("descriptor.layer_in.1", 1, False, False),
+    "desc_out.0": ("descriptor.layer_out.0", 1, True, False), "desc_out.1": ("descriptor.layer_out.1", 1, False, True)}
+
+
+def _relu(v):
+    return np.maximum(v, np.float32(0))
+
+
+def _bias(t):
+    return t.astype(np.float32)[None, :, None, None]
+
+
+def bf16_emulated_stem(image, sd):
+    """frames -> the pooled stem output ("pool"), fp32: bf16 frame and weights, fp32 bias / ReLU / max-pool."""
+    image = np.ascontiguousarray(image, np.float32)
+    b, _, hh, ww = image.shape
+    s, t = _fold(sd, "encoder.bn1")
+    st = _relu(_conv2d(round_bf16(image), _wq(sd["encoder.conv1.weight"], s), 2, 3) + _bias(t))
+    x0 = np.empty((b, 64, hh // 4, ww // 4), np.float32)
+    lib().oracle_maxpool3s2(_p(np.ascontiguousarray(st)), _p(x0), b, 64, hh // 2, ww // 2)
+    return x0
+
+
+def bf16_emulated_layer(name, inputs, sd):
+    """ONE layer of the FPC_BF16 plan on given input tensor(s) [B,C,h,w] (float32 arrays; values the mode keeps in bf16
+    are rounded here where the kernel rounds them, so feeding the device's own tensors back in is exact)."""
+    x = round_bf16(np.ascontiguousarray(np.concatenate(inputs, 1) if len(inputs) > 1 else inputs[0], np.float32))
+    if name == "up":     # ConvTranspose2d(256, 128, 3, 2, 1, 1) + bias, bn, relu (superpoint.py:45-47,55-57)
+        s, t = _fold(sd, "descriptor.bn")
+        wt = round_bf16((sd["descriptor.up_sample.weight"].astype(np.float64) * s[None, :, None, None]).astype(np.float32))
+        bt = (sd["descriptor.up_sample.bias"].astype(np.float64) * s + t).astype(np.float32)
+        b, _, h, w = x.shape
+        up = np.empty((b, 128, 2 * h, 2 * w), np.float32)
+        lib().oracle_conv_transpose2d(_p(x), _p(np.ascontiguousarray(wt)), _p(bt), _p(up), b, 256, h, w, 128)
+        return round_bf16(_relu(up))
+    p, stride, proj, out_f32 = _BF16_BLOCKS[name]
+    s1, t1 = _fold(sd, p + ".bn1")
+    s2, t2 = _fold(sd, p + ".bn2")
+    h = round_bf16(_relu(_conv2d(x, _wq(sd[p + ".conv1.weight"], s1), stride, 1) + _bias(t1)))
+    y = _conv2d(h, _wq(sd[p + ".conv2.weight"], s2), 1, 0)
+    if proj:
+        sp, tp = _fold(sd, p + ".identity_downsample.1")
+        # one fp32 accumulator over [h | x] on the device; here two double-accumulated halves added in float
+        y = y + _conv2d(x, _wq(sd[p + ".identity_downsample.0.weight"], sp), stride, 0) + _bias(t2 + tp)
+    else:
+        y = y + _bias(t2) + x
+    y = _relu(y)
+    return y if out_f32 else round_bf16(y)
+
+
+def forward_bf16_emulated(image, sd, descriptor_enabled=True, with_taps=False):
+    """image float32 [B,3,H,W] -> (prob_map, desc, logits[, taps]) as `forward`, with FPC_BF16's roundings."""
+    image = np.ascontiguousarray(image, np.float32)
+    b, _, hh, ww = image.shape
+    taps = {"pool": bf16_emulated_stem(image, sd)}
+    for name, ins in BF16_LAYERS:
+        if not descriptor_enabled and (name.startswith("desc") or name == "up"):
+            continue
+        taps[name] = bf16_emulated_layer(name, [taps[i] for i in ins], sd)
+    logits = taps["det.1"]
+    hc, wc = hh // 8, ww // 8
+    desc = taps["desc_out.1"] if descriptor_enabled else np.zeros((b, 128, hc, wc), np.float32)
+    # exp-softmax (+1e-5, no max-subtraction) and depth-to-space, superpoint.py:111-114, in float as `forward` does
+    e = np.exp(logits.astype(np.float32))
+    sm = e / (e.sum(1, keepdims=True, dtype=np.float32) + np.float32(.00001))
+    prob = np.empty((b, hh, ww), np.float32)
+    lib().oracle_restore_prob_map(_p(np.ascontiguousarray(sm.astype(np.float32))), _p(prob), b, hc, wc, 8)
+    return (prob, desc, logits, taps) if with_taps else (prob, desc, logits)
+
+
 def get_points(prob, conf_thresh=0.015, nms_dist=4, border_remove=4):
     """prob float32 [H,W] -> (xs int32[K], ys int32[K], conf float32[K], n_candidates)."""
     prob = np.ascontiguousarray(prob, dtype=np.float32)
@@ -123,6 +239,18 @@ def get_descriptors(desc_map, xs, ys, h, w):
     if k:
         lib().oracle_get_descriptors(_p(desc_map), d, hc, wc, h, w, xs.ctypes.data_as(_i32p),
                                      ys.ctypes.data_as(_i32p), k, _p(out))
+    return out
+
+
+def get_descriptors_at(desc_map, xs, ys, h, w):
+    """As get_descriptors, at float64 points (fractional / outside the frame allowed)."""
+    desc_map = np.ascontiguousarray(desc_map, dtype=np.float32)
+    d, hc, wc = desc_map.shape
+    xy = np.ascontiguousarray(np.stack([np.asarray(xs, np.float64), np.asarray(ys, np.float64)], 1))
+    out = np.empty((len(xy), d), np.float32)
+    if len(xy):
+        lib().oracle_get_descriptors_at(_p(desc_map), d, hc, wc, h, w, xy.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        len(xy), _p(out))
     return out
 
 

@@ -211,17 +211,22 @@ def golden_get_descriptors_random():
     print("F4b get_descriptors cases: 5")
 
 
-def golden_end_to_end():
+def golden_end_to_end(only=None):
     """F5: full path on whole frames: keypoints, confidences, a descriptor subset and
     strided probes of the dense maps."""
-    for tag, h, w, wseed, dust, fseed, descriptor in [
-            ("qvga", 240, 320, 21, 7.0, 300, True),
-            ("vga", 480, 640, 0, 7.0, 100, True),
-            ("magicpoint_qvga", 240, 320, 22, 7.0, 301, False)]:
-        net, settings, _ = build_net(wseed, dust, via_checkpoint=(tag == "vga"))
+    cases = [("qvga", 240, 320, 21, 7.0, 300, True),
+             ("vga", 480, 640, 0, 7.0, 100, True),
+             ("magicpoint_qvga", 240, 320, 22, 7.0, 301, False),
+             # BASELINE.json configs[0]: ONE 640x480 GRAY frame.  The reference network takes 3 channels; a gray plane is
+             # replicated x3 (dataset_utils.py:19-20), which is what synth.make_frame(gray=True) returns.
+             ("gray_vga", 480, 640, 6, 6.0, 501, True)]
+    if only:
+        cases = [c for c in cases if c[0] in only]
+    for tag, h, w, wseed, dust, fseed, descriptor in cases:
+        net, settings, _ = build_net(wseed, dust, via_checkpoint=(tag in ("vga", "gray_vga")))
         if not descriptor:
             net.disable_descriptor()          # superpoint.py:74-78, 103-109
-        frame = synth.make_frame(fseed, h, w)
+        frame = synth.make_frame(fseed, h, w, gray=tag.startswith("gray"))
         prob, desc_map, logits, points, desc = run_frame(net, settings, frame)
         p = prob.numpy()
         ys_, xs_ = np.where(p[0] >= settings.confidence_thresh)
@@ -367,6 +372,9 @@ def golden_u8():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         golden_u8()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "f5":
+        golden_end_to_end(sys.argv[2:])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f9":
         golden_query_image()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fpc_abi_version() == 1
+    assert lib.fpc_abi_version() == 2
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fpc_[a-z_0-9]+)", out))
     assert set(declared) <= exported
@@ -255,3 +255,57 @@ def test_checkpoint_reader_rejects_damaged_files_cleanly(tmp_path):
     lines = r.stdout.strip().split("\n")
     assert lines[0] == "ok 163" and len(lines) == len(files) and all(ln.startswith(("ok", "rejected")) for ln in lines)
     assert sum(ln == "rejected" for ln in lines[1:9]) == 8          # every truncation is rejected
+
+    # Crafted files: valid containers whose PICKLED integers are hostile (round-1 advisor finding).  A hand-written
+    # protocol-2 pickle of {"w": _rebuild_tensor_v2(storage '0', offset, shape, stride, ...)} in a STORED zip.
+    import struct
+    import zipfile
+
+    def p_int(v):
+        return b"J" + struct.pack("<i", v) if -2**31 <= v < 2**31 else b"\x8a\x08" + struct.pack("<q", v)
+
+    def p_tuple(vals):
+        return b"(" + b"".join(p_int(v) for v in vals) + b"t"
+
+    def p_str(t):
+        return b"X" + struct.pack("<I", len(t)) + t
+
+    def tensor_pickle(offset, shape, stride):
+        pid = b"(" + p_str(b"storage") + b"ctorch\nFloatStorage\n" + p_str(b"0") + p_str(b"cpu") + p_int(4) + b"tQ"
+        args = b"(" + pid + p_int(offset) + p_tuple(shape) + p_tuple(stride) + b"\x89" + b"ccollections\nOrderedDict\n)R" + b"t"
+        return b"\x80\x02}(" + p_str(b"w") + b"ctorch._utils\n_rebuild_tensor_v2\n" + args + b"Ru."
+
+    def crafted(name, pkl, storage=b"\0" * 16):
+        f = str(tmp_path / name)
+        with zipfile.ZipFile(f, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("archive/data.pkl", pkl)
+            z.writestr("archive/data/0", storage)
+        return f
+
+    cases = [
+        ("c_ok.pt", tensor_pickle(0, (2, 2), (2, 1)), "ok 1"),
+        ("c_negoff.pt", tensor_pickle(-1000000, (1000001,), (1,)), "rejected"),        # ((size_t)off + numel) * es wraps
+        ("c_negoff2.pt", tensor_pickle(-1, (2,), (1,)), "rejected"),
+        ("c_shortstride.pt", tensor_pickle(0, (2, 2), (1,)), "rejected"),              # stride[d] past the end
+        ("c_negdim.pt", tensor_pickle(0, (-2, -2), (-2, 1)), "rejected"),              # product of two negatives is positive
+        ("c_hugedim.pt", tensor_pickle(0, (2**62, 4), (4, 1)), "rejected"),            # numel wraps to 0
+        ("c_hugeoff.pt", tensor_pickle(2**62, (4,), (1,)), "rejected"),
+        ("c_q_empty.pt", b"\x80\x02q\x00.", "rejected"),                              # BINPUT on an empty stack
+        ("c_a_empty.pt", b"\x80\x02N\x85a.", "rejected"),                             # APPEND with nothing below
+        ("c_s_empty.pt", b"\x80\x02NNs.", "rejected"),
+        ("c_h_unknown.pt", b"\x80\x02h\x07.", "rejected"),                            # BINGET of a key never put
+        ("c_mark.pt", b"\x80\x02(NNt0e.", "rejected"),
+    ]
+    cfiles = [crafted(n, pk) for n, pk, _ in cases]
+    # a ZIP64-style central directory entry whose extra field claims more bytes than it has
+    b = bytearray(open(cfiles[0], "rb").read())
+    cd = b.rfind(b"PK\x01\x02")
+    b[cd + 24:cd + 28] = b"\xff\xff\xff\xff"      # uncompressed size -> "see zip64 extra field" (there is none)
+    cfiles.append(str(tmp_path / "c_zip64_short.pt"))
+    open(cfiles[-1], "wb").write(bytes(b))
+    cases.append(("c_zip64_short.pt", None, "rejected"))
+    r = subprocess.run([exe] + cfiles, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+    got = r.stdout.strip().split("\n")
+    assert got == [w for _, _, w in cases], list(zip([n for n, _, _ in cases], got))

@@ -19,11 +19,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class FakeEngine:
     """Holds a 'packed blob' exactly like Engine does, minus the GPU."""
 
-    def __init__(self, n=4099):
+    def __init__(self, n=4099, plan=0x1234567890abcdef):
         self.blob = np.zeros(n, np.uint8)
         self.loaded = False
+        self.plan = plan
+
+    def plan_hash(self):
+        return self.plan
 
     def load_state_dict(self, sd):
+        if "blob" not in sd:
+            raise KeyError("checkpoint entry: encoder.conv1.weight")
         self.blob[:] = np.frombuffer(sd["blob"], np.uint8)
         self.loaded = True
 
@@ -53,7 +59,28 @@ def _worker(rank, world, port, q):
     tmax = fdist.max_over_ranks(1.0 + rank)
     tsum = fdist.sum_over_ranks(hi - lo)
     fdist.barrier()
-    q.put((rank, ok, lo, hi, tmax, tsum))
+    # the source rank fails to load: EVERY rank raises instead of waiting in the blob broadcast
+    bad_src = FakeEngine()
+    try:
+        fdist.broadcast_packed_weights(bad_src, {} if rank == 0 else None)
+        src_fail = False
+    except fdist.WeightBroadcastError as e:
+        src_fail = ("could not load" in str(e)) and not bad_src.loaded
+    # one rank's engine would lay the blob out differently (other dtype / plan knobs): every rank raises, none imports
+    odd = FakeEngine(plan=0x1111 if rank == 1 else 0x1234567890abcdef)
+    try:
+        fdist.broadcast_packed_weights(odd, sd)
+        plan_fail = False
+    except fdist.WeightBroadcastError as e:
+        plan_fail = "plan" in str(e) and (rank == 0 or not odd.loaded)
+    small = FakeEngine(n=4099 if rank == 0 else 2048)
+    try:
+        fdist.broadcast_packed_weights(small, sd)
+        size_fail = False
+    except fdist.WeightBroadcastError:
+        size_fail = rank == 0 or not small.loaded
+    fdist.barrier()   # the group is still usable after the refused exchanges
+    q.put((rank, ok, lo, hi, tmax, tsum, src_fail, plan_fail, size_fail))
     torch.distributed.destroy_process_group()
 
 
@@ -75,6 +102,9 @@ def test_two_ranks_gloo():
     assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 19, 19, 37)
     assert res[0][4] == 2.0 and res[1][4] == 2.0        # MAX over ranks
     assert res[0][5] == 37.0
+    assert all(r[6] for r in res), "a failing source rank must raise on every rank"
+    assert all(r[7] for r in res), "a plan mismatch on one rank must raise on every rank"
+    assert all(r[8] for r in res), "a size mismatch on one rank must raise on every rank"
 
 
 def test_shard_ranges_cover_every_frame_once():

@@ -75,6 +75,30 @@ def _check_frame_against_oracle_postproc(oracle, prob_b, desc_b, res, h, w):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
+def test_f1_per_layer_taps_on_the_device(torch_gpu, golden_dir, dtype):
+    """Fixture F1 -- forward hooks on the reference's own modules -- against the tensors the HIP path leaves in its
+    workspace (fpc_read_activation), layer by layer at the 1e-4 bar: a mid-network indexing error cannot cancel out
+    before the final maps.  (The un-pooled stem output and a block's inner h never reach memory in the fused plan.)"""
+    g = np.load(os.path.join(golden_dir, "f1_layers_32x48.npz"))
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_batch(int(g["seed_frame"]), 1, h, w)
+    from fpc_amd.engine import Engine
+    for kw in (dict(), dict(plan_flags=["no_winograd"]), dict(plan_flags=["no_fused_blocks"])):
+        if kw and dtype != "f32":
+            continue
+        e = engine(h, w, dtype=dtype, **kw)
+        e.load_state_dict(sd)
+        e.forward(frame)
+        for name in Engine.ACTIVATIONS:
+            got = e.activation(name).cpu().numpy()
+            want = g["tap_" + name]
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            np.testing.assert_allclose(got, want, rtol=0, atol=ATOL, err_msg="%s %s %s" % (dtype, kw, name))
+        e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
 @pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
 def test_f5_end_to_end(torch_gpu, golden_dir, tag, dtype):
     """The reference's own outputs (tests/golden/make_golden.py) at the north_star bar -- dense maps within
@@ -520,8 +544,6 @@ def test_gray_frames_equal_replicated_rgb(torch_gpu):
 # outputs to agreement with the fp32 path.  Post-processing runs in fp32 on whatever dense maps it is given
 # and stays EXACT against the oracle on those maps.
 BF16_LOGIT_MAX, BF16_LOGIT_RMS, BF16_KP_OVERLAP, BF16_DESC_COS = 0.25, 0.02, 0.97, 0.999
-
-
 def _overlap_and_cosine(ra, rb):
     (xa, _, fa, _), (xb, _, fb, _) = ra, rb
     ia = {tuple(p): k for k, p in enumerate(xa.tolist())}
@@ -529,6 +551,42 @@ def _overlap_and_cosine(ra, rb):
     common = [p for p in ia if p in ib]
     cos = [float(np.dot(fa[ia[p]], fb[ib[p]])) for p in common] if fa is not None else [1.0]
     return len(common) / max(1, max(len(ia), len(ib))), min(cos) if cos else 1.0
+
+
+# ... and, so that a mis-rounded or mis-indexed layer cannot hide inside that allowance, EVERY LAYER is also checked on
+# its own (round-1 VERDICT): the layer's input tensor is read back from the device (fpc_read_activation), the oracle
+# computes that one layer with bf16's roundings put where the mode puts them (oracle.bf16_emulated_layer: bf16 inputs,
+# BN-folded bf16 weights, bf16 h, bf16 or fp32 output, double accumulation), and the device's output tensor must agree
+# up to what is left: fp32-vs-double accumulation order, plus -- for a value that lands within that distance of a bf16
+# rounding boundary -- one bf16 ulp of the output or of an h feeding it.  Nothing compounds across layers, so the bound
+# is a per-element one: |got - want| <= 1.25 * 2^-7 * max(|want|, 1) everywhere (one ulp of a bf16 output is between 2^-8
+# and 2^-7 of its value; an h flip moves the sum by at most 2^-7 |h| |w|; two ulps would be >= 2^-7), and at most 0.5 % of
+# the elements may differ by more than 1e-4 * max(|want|, 1) at all.  Measured on the MI355X (VGA and 64 x HD): max
+# 0.0078 = one ulp, 0.001 - 0.10 % of a layer's elements flipped.
+BF16_LAYER_REL, BF16_LAYER_EXACT, BF16_LAYER_FLIPS = 1.25 * 2.0 ** -7, 1e-4, 0.005
+
+
+def _check_bf16_layers(oracle, e16, frames, sd, frame_idx, what):
+    """frames must be the batch of the engine's LAST forward call."""
+    stem = oracle.bf16_emulated_stem(frames[frame_idx], sd)
+    got0 = np.concatenate([e16.activation("pool", i, 1).cpu().numpy() for i in frame_idx], 0)
+    scale = np.maximum(np.abs(stem), 1.0)
+    assert float((np.abs(got0 - stem) / scale).max()) < 1e-5, what + ": pooled stem output"
+    worst = 0.0
+    for name, ins in oracle.BF16_LAYERS:
+        if not e16.descriptor_enabled and (name.startswith("desc") or name == "up"):
+            continue
+        xin = [np.concatenate([e16.activation(t, i, 1).cpu().numpy() for i in frame_idx], 0) for t in ins]
+        got = np.concatenate([e16.activation(name, i, 1).cpu().numpy() for i in frame_idx], 0)
+        want = oracle.bf16_emulated_layer(name, xin, sd)
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1.0)
+        frac = float((rel > BF16_LAYER_EXACT).mean())
+        worst = max(worst, float(rel.max()))
+        print("bf16 layer %-10s %s: max rel %.3g, %.4f %% of elements off by more than %g" % (name, what, rel.max(), 100 * frac, BF16_LAYER_EXACT))
+        assert float(rel.max()) < BF16_LAYER_REL, (what, name, float(rel.max()))
+        assert frac < BF16_LAYER_FLIPS, (what, name, frac)
+    return worst
 
 
 @pytest.mark.gpu
@@ -548,6 +606,7 @@ def test_bf16_path_against_fp32_and_oracle(torch_gpu, golden_dir):
     # against the reference's own probes of the dense maps (golden fixture), same bound
     assert np.max(np.abs(l16.cpu().numpy().ravel()[::7] - g["logits_probe"])) < BF16_LOGIT_MAX
     assert np.max(np.abs(d16.cpu().numpy().ravel()[::11] - g["desc_map_probe"])) < BF16_LOGIT_MAX
+    _check_bf16_layers(oracle_mod(), e16, frame, sd, [0], "VGA")     # e16's last forward was on `frame`
     r32, r16 = e32.detect(frame)[0], e16.detect(frame)[0]
     # post-processing is exact on the bf16 engine's own dense maps
     _check_frame_against_oracle_postproc(oracle_mod(), p16[0].cpu().numpy(), d16[0].cpu().numpy(), r16, h, w)
@@ -563,24 +622,38 @@ def test_bf16_path_against_fp32_and_oracle(torch_gpu, golden_dir):
 
 @pytest.mark.gpu
 def test_bf16_hd_batch_properties(torch_gpu):
-    """BASELINE.json configs[4] geometry and dtype (1280x960, bf16) on a batch that splits unevenly over the
-    sub-batch streams: batch == single frames, NMS / ordering / unit-norm properties, MagicPoint variant."""
-    h, w, n = 960, 1280, 5
+    """BASELINE.json configs[4] AT ITS STATED SIZE: 64 frames of 1280x960 in bf16, one call.  Dense maps of three
+    frames against the bf16-emulating oracle; post-processing exact against the oracle on three frames; batch == single
+    frame bit for bit on two; NMS radius / border / ordering / unit-norm properties on all 64; MagicPoint variant."""
+    h, w, n = 960, 1280, 64
     sd = synth.make_state_dict(5, dustbin_bias=7.0)
-    frames = synth.make_batch(700, n, h, w)
+    # 8 distinct frames, repeated with a shift so that every slot of the batch holds a different image
+    base = synth.make_batch(700, 8, h, w)
+    frames = np.concatenate([np.roll(base, 16 * k, axis=3) for k in range(n // 8)], 0)
     e = engine(h, w, n, dtype="bf16")
     e.load_state_dict(sd)
     prob, desc, _ = e.forward(frames)
     res = e.detect(frames)
     oracle = oracle_mod()
-    for i in (0, n - 1):
+    for i in (0, 29, n - 1):
         _check_frame_against_oracle_postproc(oracle, prob[i].cpu().numpy(), desc[i].cpu().numpy(), res[i], h, w)
-    one = e.detect(frames[3:4])[0]
-    np.testing.assert_array_equal(one[0], res[3][0])
-    np.testing.assert_array_equal(one[1], res[3][1])
-    np.testing.assert_array_equal(one[2], res[3][2])
+    # every layer of three frames of the batch (first, one at the sub-batch boundary, last) against the bf16-emulating
+    # oracle, each on the device's own input tensor (the last call, detect, ran the same 64 frames)
+    _check_bf16_layers(oracle, e, frames, sd, [0, 31, n - 1], "HD x64")
+    for i in (3, 40):
+        one = e.detect(frames[i:i + 1])[0]
+        np.testing.assert_array_equal(one[0], res[i][0])
+        np.testing.assert_array_equal(one[1], res[i][1])
+        np.testing.assert_array_equal(one[2], res[i][2])
     for xy, conf, d, ncand in res:
-        assert len(conf) > 1000 and np.all(np.diff(conf) <= 0)
+        assert len(conf) > 1000 and np.all(np.diff(conf) <= 0) and ncand >= len(conf)
+        assert xy[:, 0].min() >= 4 and xy[:, 0].max() < w - 4 and xy[:, 1].min() >= 4 and xy[:, 1].max() < h - 4
+        grid = np.zeros((h + 8, w + 8), bool)
+        grid[xy[:, 1] + 4, xy[:, 0] + 4] = True
+        for dy in range(-4, 5):           # no two keypoints within infinity-distance 4 of each other
+            for dx in range(-4, 5):
+                if dy or dx:
+                    assert not grid[xy[:, 1] + 4 + dy, xy[:, 0] + 4 + dx].any()
         np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
     e.close()
     m = engine(h, w, 1, dtype="bf16", descriptor_enabled=False)

@@ -83,12 +83,12 @@ def test_f4_get_descriptors(golden_dir):
     assert oracle.get_descriptors(g["desc_map"][0], [], [], h, w).shape == (0, 16)
 
 
-@pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
+@pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga", "gray_vga"])
 def test_f5_end_to_end(golden_dir, tag):
     g = load(golden_dir, "f5_e2e_%s.npz" % tag)
     h, w = int(g["h"]), int(g["w"])
     sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
-    frame = synth.make_frame(int(g["seed_frame"]), h, w)
+    frame = synth.make_frame(int(g["seed_frame"]), h, w, gray=tag.startswith("gray"))   # gray plane x3: dataset_utils.py:19-20
     de = bool(int(g["descriptor_enabled"]))
     prob, desc, logits = oracle.forward(frame.transpose(2, 0, 1)[None], sd, SPEC, descriptor_enabled=de)
     np.testing.assert_allclose(logits.ravel()[::7], g["logits_probe"], rtol=5e-5, atol=5e-5)
