@@ -10,8 +10,26 @@ one batch of 32 synthetic 640x480 frames that is already resident in HBM
 (BASELINE.json configs[1]).  With N ranks every rank runs its own 32-frame batch
 (weak scaling; configs[2] = 256 frames over 8 GPUs); the only collective is the
 start-up broadcast of the packed weights.  Prints ONE JSON line on rank 0.
+
+What the line holds besides the contract's fields:
+  roofline          the dominant kernel symbol of the timed region: achieved = ALGORITHMIC work per launch / mean launch
+                    duration from HIP events on the launch streams.  bound "mfma" (fp32 workloads): TFLOP/s against the
+                    fp32 matrix peak, with BOTH fractions -- `frac` = `frac_algorithmic` (direct-convolution FLOPs) and
+                    `frac_mfma_issued` (what the matrix cores were really given: a Winograd launch issues 16/36 of its 3x3's
+                    FLOPs, so `algorithmic_ceiling` = algorithmic / issued FLOPs is how far above 1.0 frac may legally go).
+                    bound "hbm" (hd64-bf16): GB/s of the layer-fused activation bytes against 8 TB/s.
+                    `traffic` = measured HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), looked
+                    up by kernel symbol and scaled to this launch's frames; null when no profile holds the symbol.
+  roofline_serial   the same with one stream (the kernel alone on the GPU).
+  steady_state      the same loop run for >= 2 s right after the K timed steps (clock settled).
+  latency_ms_b1     one frame, one call at a time (BASELINE.json configs[0]'s use case).
+  cpu_baseline      SURVEY 8(d): the torch.nn.functional CPU restatement of the path (oracle/torch_cpu.py + the C
+                    oracle's post-processing) on this host, all cores and one thread, forward and post-processing
+                    separately, on a bounded sample.
 """
 import argparse
+import csv
+import glob
 import json
 import os
 import sys
@@ -27,49 +45,123 @@ import fpc_amd  # noqa: E402,F401
 from fpc_amd import arch, dist as fdist, synth  # noqa: E402
 from fpc_amd.engine import Engine  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (dense, f32 in / f32 acc)
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: FP32 matrix peak (dense, f32 in / f32 acc)
 PEAK_BF16_MFMA_TFLOPS = 2516.8  # ibid.: BF16 MFMA dense = 16x the FP32 matrix rate (~2.5 PF)
-PEAK_TFLOPS = PEAK_F32_MFMA_TFLOPS     # ceiling for ALGORITHMIC flops in the selected arithmetic mode
-PEAK_ISSUED_TFLOPS = PEAK_F32_MFMA_TFLOPS  # ceiling for the MFMA instructions really issued
-BATCH = 32
-# HBM bytes per FRAME of each kernel symbol from the rocprofv3 PMC passes in
-# profiles/r01j_pmc_summary_serial.csv (one stream, default plan): (2*FETCH_SIZE + WRITE_SIZE) KiB per
-# dispatch / 32 frames, averaged over the layers that share the symbol (the x2 on FETCH_SIZE is the gfx950
-# correction of MI355X_MICROARCH.md for 16 B/lane reads; FETCH_SIZE and WRITE_SIZE in separate passes).
-TRAFFIC_BYTES_PER_FRAME = {
-    "wblock_mfma_kernel<32, 4, 128>": 254242720 / 32.0,
-    "wblock_mfma_kernel<32, 2, 64>": 326846528 / 32.0,
-    "wblock_mfma_kernel<32, 3, 72>": 174261248 / 32.0,
-    "stem_pool_kernel": 315067808 / 32.0,
-    # split-operand kernels (profiles/r01j_pmc_summary_serial_f32_split_f16.csv; the bf16-term twins move the same bytes)
-    "block_h2_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 307176736 / 32.0,
-    "block_h2_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 460159776 / 32.0,
-    "block_x3_kernel<6, 20, 1, 3, 64, 2, 2, 2, 2, 128>": 307176736 / 32.0,
-    "block_x3_kernel<8, 16, 1, 3, 64, 2, 2, 2, 1, 64>": 460159776 / 32.0,
-    "stem_pool_x3_kernel": 315311808 / 32.0,
-}
-H, W = 480, 640
+PEAK_HBM_GBS = 8000.0           # ibid.: HBM3E 8.0 TB/s (spec; 6.3 TB/s measured with a float4 copy)
+H, W, BATCH = 480, 640, 32
 
 
-def cpu_baseline(state_dict, frames):
-    """The CPU oracle (oracle/fpc_oracle.c, kind "port") timed on this host's cores on a
-    bounded sample of the same workload.  Rank 0, N=1 only."""
-    from oracle import oracle
-    spec = arch.state_dict_spec()
-    n = frames.shape[0]
-    threads = oracle.max_threads()
-    oracle.forward(frames[:1], state_dict, spec)          # warm-up
+class Mode:
+    """What bounds the selected workload and the peaks to price it against."""
+
+    def __init__(self, dtype, workload):
+        self.dtype = dtype
+        self.bound = "hbm" if workload == "hd64-bf16" else "mfma"
+        # ceiling for ALGORITHMIC flops (one product = 1 fp32 MFMA / 6 bf16 / 3 fp16 / 1 bf16 MFMA) and for issued MFMAs
+        self.peak_algorithmic = {"f32": PEAK_F32_MFMA_TFLOPS, "f32_split": PEAK_BF16_MFMA_TFLOPS / 6.0,
+                                 "f32_split_f16": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16": PEAK_BF16_MFMA_TFLOPS}[dtype]
+        self.peak_issued = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# measured HBM traffic: the newest committed PMC summary (profiles/*pmc_summary*.csv) that holds the symbol
+# ----------------------------------------------------------------------------------------------------------------
+def load_traffic_table(dtype):
+    """kernel symbol (template arguments included, 'void ' and argument list stripped) ->
+    (HBM bytes per FRAME, file).  Files are written by profiles/summarize_pmc.py from three rocprofv3 --pmc passes
+    (FETCH_SIZE x 2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, KiB -> bytes)."""
+    table = {}
+    tag = {"f32": "", "bf16": "bf16", "f32_split": "f32_split", "f32_split_f16": "f32_split_f16"}[dtype]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_summary*.csv")))
+    for f in files:   # later rounds / letters sort last and win
+        base = os.path.basename(f)
+        is_mode = base.rsplit("pmc_summary", 1)[1].replace(".csv", "").replace("_serial", "").strip("_")
+        if is_mode != tag and not (tag == "f32_split" and is_mode == "f32_split_f16"):   # the bf16-term twins move the same bytes
+            continue
+        try:
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    sym = row["kernel"].replace("void ", "").split("(")[0].replace("fpc::", "").strip()
+                    frames = float(row.get("frames_per_dispatch") or 32)
+                    if tag == "f32_split" and is_mode == "f32_split_f16":
+                        sym = sym.replace("block_h2_kernel", "block_x3_kernel")
+                    table[sym] = (float(row["hbm_bytes_per_dispatch"]) / frames, "profiles/" + base)
+        except (OSError, KeyError, ValueError):
+            continue
+    return table
+
+
+def lookup_traffic(table, sym):
+    """Exact symbol, or the same kernel name where one side carries no template arguments (the engine reports
+    `stem_pool_kernel`, rocprofv3 `stem_pool_kernel<3>`); among several candidates the newest profile wins."""
+    cands = [(v[1], k == sym, v) for k, v in table.items()
+             if k == sym or (k.split("<")[0] == sym.split("<")[0] and ("<" not in sym or "<" not in k))]
+    return max(cands)[2] if cands else None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY 8d)
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(state_dict, frames, budget_s=28.0, descriptor=True):
+    """The path on this host's cores: forward = oracle/torch_cpu.py (torch.nn.functional, eager, fp32: what the
+    reference's CPU path is), post-processing = the C oracle's get_points + get_descriptors (nms.py's Python loops
+    restated in C -- faster than the reference's, so the figure errs in the baseline's favour).  All cores and ONE
+    thread; batch 1 (the reference's facade) and batch 32 forward; bounded by `budget_s` of CPU time in total."""
+    from oracle import oracle, torch_cpu
+    sd = torch_cpu.to_torch(state_dict)
+    x = torch.from_numpy(np.ascontiguousarray(frames))
+    n = x.shape[0]
+    h, w = x.shape[2], x.shape[3]
+    all_threads = torch.get_num_threads()
+    t_start = time.perf_counter()
+
+    def run(threads, warm, want, share):
+        """batch-1 loop: returns (frames, forward seconds, post-processing seconds)."""
+        torch.set_num_threads(threads)
+        oracle.set_threads(threads)
+        for i in range(warm):
+            torch_cpu.forward(x[i % n:i % n + 1], sd, descriptor)
+        tf = tp = 0.0
+        k = 0
+        deadline = time.perf_counter() + share
+        while k < want and (k < 3 or time.perf_counter() < deadline):
+            i = k % n
+            t0 = time.perf_counter()
+            prob, desc, _ = torch_cpu.forward(x[i:i + 1], sd, descriptor)
+            t1 = time.perf_counter()
+            xs, ys, _, _ = oracle.get_points(prob[0].numpy())
+            if descriptor:
+                oracle.get_descriptors(desc[0].numpy(), xs, ys, h, w)
+            t2 = time.perf_counter()
+            tf += t1 - t0
+            tp += t2 - t1
+            k += 1
+        return k, tf, tp
+
+    ka, fa, pa = run(all_threads, 20, 100, budget_s * 0.3)        # 8(d): 20 warm-up + 100 timed iterations, time-bounded
+    torch.set_num_threads(all_threads)
+    nb = min(n, 32)
+    torch_cpu.forward(x[:nb], sd, descriptor)
     t0 = time.perf_counter()
-    kept = 0
-    for i in range(n):
-        prob, desc, _ = oracle.forward(frames[i:i + 1], state_dict, spec)
-        xs, ys, _, _ = oracle.get_points(prob[0])
-        oracle.get_descriptors(desc[0], xs, ys, H, W)
-        kept += len(xs)
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d of the bench's %dx%d frames, full path (forward + get_points + get_descriptors), "
-                      "oracle/fpc_oracle.c with %d OpenMP threads, %.1f s" % (n, W, H, threads, dt)}
+    reps = 0
+    while reps < 2 or (reps < 10 and time.perf_counter() - t0 < budget_s * 0.15):
+        torch_cpu.forward(x[:nb], sd, descriptor)
+        reps += 1
+    fb = (time.perf_counter() - t0) / reps
+    k1, f1, p1 = run(1, 2, 20, budget_s * 0.4)
+    torch.set_num_threads(all_threads)
+    oracle.set_threads(oracle.max_threads())
+    spent = time.perf_counter() - t_start
+    r3 = lambda v: round(v, 3)   # noqa: E731
+    return {"value": r3(ka / (fa + pa)), "unit": "frames/s", "cores": all_threads, "kind": "port",
+            "sample": "%d of the bench's %dx%d frames one at a time after 20 warm-up frames: forward by the "
+                      "torch.nn.functional restatement oracle/torch_cpu.py (eager fp32, %d threads) + post-processing "
+                      "(get_points + get_descriptors) by the C oracle; %.1f s of CPU work in all legs" % (ka, w, h, all_threads, spent),
+            "forward_ms": r3(fa / ka * 1e3), "postproc_ms": r3(pa / ka * 1e3),
+            "forward_only_frames_per_s": r3(ka / fa),
+            "batch%d_forward_frames_per_s" % nb: r3(nb / fb),
+            "single_thread": {"value": r3(k1 / (f1 + p1)), "frames": k1, "forward_ms": r3(f1 / k1 * 1e3),
+                              "postproc_ms": r3(p1 / k1 * 1e3)}}
 
 
 def cpu_baseline_vgg_reference(sd, frames):
@@ -135,32 +227,48 @@ def host_fed_rates(sd, frames_np, local, dtype, steps=12):
 
 
 def symbol_stats(timings, steps):
-    """kernel symbol -> dict(avg ms, algorithmic / MFMA-issued FLOPs per launch, launches per step, layers)."""
-    by = {}
-    layers = {}
-    for name, kern, ms, fl, mf in timings:
-        by.setdefault(kern, []).append((ms, fl, mf))
+    """kernel symbol -> dict(mean launch ms, algorithmic / MFMA-issued FLOPs and algorithmic bytes per launch, ...)."""
+    by, layers = {}, {}
+    for name, kern, ms, fl, mf, nbytes in timings:
+        by.setdefault(kern, []).append((ms, fl, mf, nbytes))
         layers.setdefault(kern, set()).add(name)
     out = {}
     for k, v in by.items():
-        ms = float(np.mean([m for m, _, _ in v]))
-        out[k] = {"avg_launch_ms": ms, "flops": float(np.mean([f for _, f, _ in v])),
-                  "mfma_flops": float(np.mean([f for _, _, f in v])), "launches_per_step": len(v) // max(1, steps),
-                  "layers": len(layers[k]), "total_ms": float(np.sum([m for m, _, _ in v])) / max(1, steps)}
+        out[k] = {"avg_launch_ms": float(np.mean([r[0] for r in v])), "flops": float(np.mean([r[1] for r in v])),
+                  "mfma_flops": float(np.mean([r[2] for r in v])), "bytes": float(np.mean([r[3] for r in v])),
+                  "launches_per_step": len(v) // max(1, steps), "layers": len(layers[k]),
+                  "total_ms": float(np.sum([r[0] for r in v])) / max(1, steps)}
     return out
 
 
-def roofline_entry(sym, st, step_ms):
-    ach = st["flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12
-    frames = BATCH * st["layers"] / max(1, st["launches_per_step"])
-    return {"bound": "mfma", "kernel": sym, "achieved": round(ach, 3), "peak": PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
-            "traffic": (round(TRAFFIC_BYTES_PER_FRAME[sym] * frames)
-                        if sym in TRAFFIC_BYTES_PER_FRAME and (H, W) == (480, 640) else None),
-            "avg_launch_ms": round(st["avg_launch_ms"], 4), "frames_per_launch": frames,
-            "flops_per_launch": st["flops"], "mfma_issued_flops_per_launch": st["mfma_flops"],
-            "mfma_issued_frac": round(st["mfma_flops"] / (st["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_ISSUED_TFLOPS, 4),
-            "launches_per_step": st["launches_per_step"], "share_of_step": round(st["total_ms"] / step_ms, 3)}
+def roofline_entry(mode, sym, st, step_ms, traffic_table):
+    sec = st["avg_launch_ms"] * 1e-3
+    frames = BATCH * st["layers"] / max(1, st["launches_per_step"])      # frames one launch covers (a sub-batch)
+    alg_tf = st["flops"] / sec / 1e12
+    iss_tf = st["mfma_flops"] / sec / 1e12
+    gbs = st["bytes"] / sec / 1e9
+    tr = lookup_traffic(traffic_table, sym)
+    e = {"bound": mode.bound, "kernel": sym}
+    if mode.bound == "hbm":
+        e.update(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                 algorithmic_bytes_per_launch=st["bytes"])
+    else:
+        e.update(achieved=round(alg_tf, 3), peak=mode.peak_algorithmic, unit="TFLOP/s",
+                 frac=round(alg_tf / mode.peak_algorithmic, 4))
+    e["traffic"] = round(tr[0] * frames) if tr else None
+    e["traffic_source"] = tr[1] if tr else None
+    e.update(
+        frac_algorithmic=round(alg_tf / mode.peak_algorithmic, 4),
+        frac_mfma_issued=round(iss_tf / mode.peak_issued, 4),
+        # algorithmic FLOPs / FLOPs issued on the matrix cores: 1.0 for a direct convolution on an exact tile, ~2.0 for
+        # a block whose 3x3 runs as Winograd F(2x2,3x3) (36/16 on the 3x3, 1 on the 1x1), < 1 with tile / channel padding;
+        # frac_algorithmic may legally reach this value
+        algorithmic_ceiling=round(st["flops"] / st["mfma_flops"] * mode.peak_issued / mode.peak_algorithmic, 3) if st["mfma_flops"] else None,
+        hbm_gbytes_per_s_algorithmic=round(gbs, 1), frac_hbm_algorithmic=round(gbs / PEAK_HBM_GBS, 4),
+        avg_launch_ms=round(st["avg_launch_ms"], 4), frames_per_launch=frames, flops_per_launch=st["flops"],
+        mfma_issued_flops_per_launch=st["mfma_flops"], algorithmic_bytes_per_launch=st["bytes"],
+        launches_per_step=st["launches_per_step"], share_of_step=round(st["total_ms"] / step_ms, 3))
+    return e
 
 
 def main():
@@ -189,20 +297,24 @@ def main():
                     help="resnet (default): the Python network of BASELINE.json's configs. vgg: the cpp/ frontend's "
                          "superpoint::SPModel (SURVEY 8f rank 4), gray frames, 52 GFLOP per VGA frame")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (H2D-inclusive) passes")
-    ap.add_argument("--no-alt-pass", action="store_true", help="skip the extra pass in the other fp32 arithmetic mode")
+    ap.add_argument("--no-alt-pass", action="store_true", help="skip the extra passes in the other fp32 arithmetic modes")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the >= 2 s steady-state pass")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency pass")
+    ap.add_argument("--only-timed", action="store_true", help="the timed region and nothing else (profiling runs)")
     args = ap.parse_args()
-    global H, W, BATCH, PEAK_TFLOPS, PEAK_ISSUED_TFLOPS
+    if args.only_timed:
+        args.no_cpu_baseline = args.no_serial_pass = args.no_host_fed = args.no_alt_pass = True
+        args.no_steady_state = args.no_latency = True
+    global H, W, BATCH
     dtype = args.dtype
-    if dtype in ("f32_split", "f32_split_f16"):
-        PEAK_TFLOPS = PEAK_BF16_MFMA_TFLOPS / (6.0 if dtype == "f32_split" else 3.0)   # six bf16 / three fp16 MFMAs per product
-        PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
     magic = args.workload == "qvga32-magicpoint"   # configs[3]: detector only, 240x320, NMS r = 4
     if magic:
         H, W = 240, 320
         args.no_host_fed = True
     if args.workload == "hd64-bf16":
-        H, W, BATCH, dtype, PEAK_TFLOPS = 960, 1280, 64, "bf16", PEAK_BF16_MFMA_TFLOPS
-        PEAK_ISSUED_TFLOPS = PEAK_BF16_MFMA_TFLOPS
+        H, W, BATCH, dtype = 960, 1280, 64, "bf16"
+        args.no_host_fed = True
+    mode = Mode(dtype, args.workload)
 
     rank, world, local = fdist.init_from_env()
     if world != args.gpus:
@@ -217,54 +329,80 @@ def main():
         args.gray, args.no_host_fed, args.no_alt_pass = True, True, True
     sd = (synth.make_vgg_state_dict(0, dustbin_bias=5.5) if vgg else synth.make_state_dict(0, dustbin_bias=7.0)) if rank == 0 else None
     cin = 1 if args.gray else 3
-    eng = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
+    kw = dict(device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
+    eng = Engine(H, W, max_batch=BATCH, **kw)
+    fdist.barrier()
+    tb0 = time.perf_counter()
     fdist.broadcast_packed_weights(eng, sd)
+    torch.cuda.synchronize(dev)
+    bcast_ms = (time.perf_counter() - tb0) * 1e3      # rank 0: parse + pack + broadcast; others: wait + receive + import
     engs = [eng]
     for _ in range(1, max(1, args.contexts)):
-        e2 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
+        e2 = Engine(H, W, max_batch=BATCH, **kw)
         e2.import_packed(eng.export_packed())
         engs.append(e2)
     # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
-    frames_np = synth.make_batch(100 + BATCH * rank, BATCH, H, W, gray=args.gray)
+    nbase = BATCH if H * W <= 480 * 640 else 8      # HD: 8 distinct frames, shifted copies fill the batch
+    frames_np = synth.make_batch(100 + BATCH * rank, nbase, H, W, gray=args.gray)
+    if nbase < BATCH:
+        frames_np = np.concatenate([np.roll(frames_np, 16 * k, axis=3) for k in range(BATCH // nbase)], 0)
     if args.gray:
         frames_np = np.ascontiguousarray(frames_np[:, :1])
     frames = torch.from_numpy(frames_np).to(dev)
     torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        engs[i % len(engs)].detect_async(frames, BATCH)
-    for e_ in engs:
-        e_.sync()
+    def loop(k):
+        for i in range(k):
+            engs[i % len(engs)].detect_async(frames, BATCH)
+        for e_ in engs:
+            e_.sync()
+
+    loop(args.warmup)
     cnt, ncand = eng.counts(BATCH)
 
     use_events = not args.no_timing_events
     for e_ in engs:
         e_.set_timing(use_events)
-    per_kernel, per_symbol = {}, {}
     fdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        engs[i % len(engs)].detect_async(frames, BATCH)
-    for e_ in engs:
-        e_.sync()
+    loop(args.steps)
     torch.cuda.synchronize(dev)
+    my_dt = time.perf_counter() - t0
     fdist.barrier()
     dt = time.perf_counter() - t0
-    if use_events:
-        # every launch of the timed region: layer name / kernel symbol -> [(ms, algorithmic flops, mfma flops)]
-        for e_ in engs:
-            for name, kern, ms, fl, mf in e_.timings():
-                per_kernel.setdefault(name, []).append((ms, fl, mf))
     timed_timings = [t for e_ in engs for t in e_.timings()] if use_events else []
     for e_ in engs:
         e_.set_timing(False)
     dt = fdist.max_over_ranks(dt)
+    per_rank = None
+    if world > 1:
+        import torch.distributed as tdist
+        coll_dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([BATCH * args.steps / my_dt, bcast_ms], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        tdist.all_gather(allr, mine)
+        per_rank = [[round(float(v), 2) for v in r.cpu()] for r in allr]
+
+    # steady state: the same loop for >= 2 s (the K timed steps of the contract last well under DVFS settling time)
+    steady = None
+    if not args.no_steady_state:
+        ks = max(args.steps, int(np.ceil(2.2 / max(1e-6, my_dt / args.steps))))
+        fdist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        loop(ks)
+        torch.cuda.synchronize(dev)
+        fdist.barrier()
+        d1 = fdist.max_over_ranks(time.perf_counter() - t1)
+        steady = {"value": round(BATCH * ks * world / d1, 2), "unit": "frames/s", "steps": ks, "seconds": round(d1, 3),
+                  "ms_per_step": round(d1 / ks * 1e3, 4)}
+
+    single = rank == 0 and world == 1
     serial = None
-    if use_events and rank == 0 and world == 1 and not args.no_serial_pass:
+    if use_events and single and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
-        os.environ["FPC_STREAMS"], os.environ["FPC_SPLIT_HEADS"], os.environ["FPC_NMS_ASIDE"] = "1", "0", "0"
-        e1 = Engine(H, W, max_batch=BATCH, device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
+        e1 = Engine(H, W, max_batch=BATCH, num_streams=1, plan_flags=["nms_in_line"], **kw)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
             e1.detect_async(frames, BATCH)
@@ -278,12 +416,26 @@ def main():
         d1 = time.perf_counter() - t1
         serial = (symbol_stats(e1.timings(), ks), d1 / ks * 1e3, e1.timings(), ks)
         e1.close()
+    latency = None
+    if single and not args.no_latency:
+        el = Engine(H, W, max_batch=1, **kw)
+        el.import_packed(eng.export_packed())
+        one = frames[:1].contiguous()
+        for _ in range(20):
+            el.detect_async(one, 1)
+            el.sync()
+        lat = []
+        for _ in range(200):
+            t1 = time.perf_counter()
+            el.detect_async(one, 1)
+            el.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        latency = {"median": round(float(np.median(lat)), 4), "p10": round(float(np.percentile(lat, 10)), 4),
+                   "p90": round(float(np.percentile(lat, 90)), 4), "calls": len(lat)}
+        el.close()
     alt = {}
-    if rank == 0 and world == 1 and not args.no_alt_pass and args.workload == "vga32" and not vgg:
+    if single and not args.no_alt_pass and args.workload == "vga32" and not vgg:
         # the other fp32 arithmetic modes on the same frames (not part of `value`)
-        os.environ.pop("FPC_STREAMS", None)
-        os.environ.pop("FPC_SPLIT_HEADS", None)
-        os.environ.pop("FPC_NMS_ASIDE", None)
         for adt in ("f32", "f32_split", "f32_split_f16"):
             if adt == dtype:
                 continue
@@ -305,12 +457,13 @@ def main():
                         "same_keypoint_counts_as_headline_mode": bool(np.array_equal(acnt, cnt))}
             ea.close()
     host_fed = None
-    if rank == 0 and world == 1 and not args.no_host_fed and args.workload == "vga32" and not args.gray:
+    if single and not args.no_host_fed and args.workload == "vga32" and not args.gray:
         host_fed = host_fed_rates(sd, frames_np, local, dtype)
     total_frames = BATCH * args.steps * world
 
     if rank == 0:
         value = total_frames / dt
+        step_ms = dt / args.steps * 1e3
         flops_frame = 2.0 * (arch.vgg_conv_macs(H, W) if vgg else arch.conv_macs(H, W, descriptor=not magic))
         wl = ("batch=32 640x480 frames per GPU, super_point checkpoint layout, fp32 "
               "(BASELINE.json configs[1]; configs[2] when n_gpus=8)" +
@@ -326,7 +479,7 @@ def main():
         out = {
             "metric": "frames/sec (%s) SuperPoint fwd+NMS+descriptors" % ("QVGA 320x240, detector only" if magic else "VGA 640x480" if dtype != "bf16" else "HD 1280x960"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "bf16", "f32_split": "f32 (3 x bf16 split operands, 6 MFMA per product, f32 accumulate)",
                       "f32_split_f16": "f32 (2 x fp16 split operands, 3 MFMA per product, f32 accumulate)"}[dtype],
@@ -340,31 +493,47 @@ def main():
                 (PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
             "keypoints_per_frame": round(float(np.mean(cnt)), 1),
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
+            "weights_broadcast_ms": round(bcast_ms, 2),
         }
-        if per_kernel:
-            # dominant kernel = the kernel SYMBOL (as rocprofv3 aggregates) with the largest share of
-            # the step; achieved = its ALGORITHMIC FLOPs per launch / its average launch duration, from
-            # HIP events recorded on the launch streams inside the timed region.  Winograd launches issue
-            # fewer FLOPs on the matrix cores than the direct convolution they compute (16/36 of the 3x3),
-            # so `achieved` counts work the matrix cores did not have to do; `mfma_issued_frac` is their
-            # utilisation by what was really issued.  In the timed region up to four streams run
-            # concurrently, so a launch's duration includes the time it shares the GPU with others;
+        if per_rank is not None:
+            out["per_rank"] = {"frames_per_s": [r[0] for r in per_rank], "weights_start_up_ms": [r[1] for r in per_rank]}
+        if steady is not None:
+            out["steady_state"] = steady
+        if latency is not None:
+            out["latency_ms_b1"] = latency["median"]
+            out["latency_b1"] = latency
+        if timed_timings:
+            # dominant kernel = the kernel SYMBOL (as rocprofv3 aggregates) with the largest share of the step.  In the
+            # timed region several streams run concurrently, so a launch's duration includes the time it shares the GPU;
             # `roofline_serial` repeats the measurement with one stream (kernels alone on the GPU).
+            table = load_traffic_table(dtype) if (H, W) == (480, 640) or mode.bound == "hbm" else {}
             stats = symbol_stats(timed_timings, args.steps)
-            sym = max((k for k in stats if stats[k]["flops"] > 0), key=lambda k: stats[k]["total_ms"])
-            out["roofline"] = roofline_entry(sym, stats[sym], dt / args.steps * 1e3)
-            sum_ms = {k: float(np.sum([m for m, _, _ in v])) / args.steps for k, v in per_kernel.items()}
-            out["layer_ms_per_step_concurrent"] = {k: round(v, 4) for k, v in sum_ms.items()}
-            out["mfma_issued_tflops_whole_step"] = round(
-                sum(f for v in per_kernel.values() for _, _, f in v) / args.steps / (dt / args.steps) / 1e12, 3)
+            key = "bytes" if mode.bound == "hbm" else "flops"
+            sym = max((k for k in stats if stats[k][key] > 0), key=lambda k: stats[k]["total_ms"])
+            out["roofline"] = roofline_entry(mode, sym, stats[sym], step_ms, table)
+            per_layer = {}
+            for name, kern, ms, fl, mf, nb in timed_timings:
+                per_layer.setdefault(name, []).append((ms, mf, nb))
+            out["layer_ms_per_step_concurrent"] = {k: round(float(np.sum([m for m, _, _ in v])) / args.steps, 4) for k, v in per_layer.items()}
+            out["mfma_issued_tflops_whole_step"] = round(sum(f for v in per_layer.values() for _, f, _ in v) / args.steps / (step_ms * 1e-3) / 1e12, 3)
+            alg_bytes = sum(b for v in per_layer.values() for _, _, b in v) / args.steps
+            out["whole_path_hbm"] = {"algorithmic_bytes_per_frame": round(alg_bytes / BATCH), "achieved": round(alg_bytes / (step_ms * 1e-3) / 1e9, 1),
+                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             if serial is not None:
                 sstats, sms, stim, ks = serial
-                out["roofline_serial"] = roofline_entry(sym, sstats[sym], sms)
+                out["roofline_serial"] = roofline_entry(mode, sym, sstats[sym], sms, table)
                 out["roofline_serial"]["ms_per_step_one_stream"] = round(sms, 4)
                 lay = {}
-                for name, kern, ms, fl, mf in stim:
+                for name, kern, ms, fl, mf, nb in stim:
                     lay.setdefault(name, []).append(ms)
                 out["layer_ms_serial"] = {k: round(float(np.mean(v)), 4) for k, v in lay.items()}
+                # every kernel symbol of the plan, alone on the GPU: both fractions and the HBM rate
+                out["kernels_serial"] = {
+                    k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "launches_per_step": v["launches_per_step"],
+                        "frac_algorithmic": round(v["flops"] / (v["avg_launch_ms"] * 1e-3) / 1e12 / mode.peak_algorithmic, 4),
+                        "frac_mfma_issued": round(v["mfma_flops"] / (v["avg_launch_ms"] * 1e-3) / 1e12 / mode.peak_issued, 4),
+                        "hbm_gbytes_per_s_algorithmic": round(v["bytes"] / (v["avg_launch_ms"] * 1e-3) / 1e9, 1)}
+                    for k, v in sorted(sstats.items(), key=lambda kv: -kv[1]["total_ms"])}
         if host_fed is not None:
             out["host_fed"] = host_fed
         out.update(alt)
@@ -373,9 +542,9 @@ def main():
             if cb is not None:
                 out["cpu_baseline"] = cb
         elif world == 1 and not args.no_cpu_baseline:
-            ncb = 8 if H * W <= 480 * 640 else 2
+            ncb = 32 if H * W <= 480 * 640 else 4
             cb_frames = frames_np[:ncb] if not args.gray else np.repeat(frames_np[:ncb], 3, axis=1)
-            out["cpu_baseline"] = cpu_baseline(sd, cb_frames)
+            out["cpu_baseline"] = cpu_baseline(sd, cb_frames, descriptor=not magic)
         print(json.dumps(out))
     for e_ in engs:
         e_.close()

@@ -131,7 +131,7 @@ def load():
     l.fpc_set_timing.argtypes = [vp, ci]
     l.fpc_get_timings.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double),
-                                  ctypes.POINTER(ctypes.c_double)]
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     for s in SYMBOLS:
         getattr(l, s)  # AttributeError if the library lacks a declared symbol
     if l.fpc_abi_version() != ABI_VERSION:

@@ -271,6 +271,7 @@ struct Op {
   int grid_y = 1, grid_z = 1;
   double flops_per_frame = 0;  // algorithmic: 2 * MACs of the real (unpadded) convolution
   double mfma_flops_per_frame = 0;  // issued on the matrix cores (padding included; Winograd: 16/36 of the 3x3)
+  double bytes_per_frame = 0;       // algorithmic HBM bytes: the launch's input tensor(s) read once + its output written once
   bool descriptor_branch = false;
 };
 
@@ -471,6 +472,8 @@ static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
   *blob_off += (size_t)nbt * 32;
   a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
+  op.bytes_per_frame = 4.0 * ((double)s.cin0 * s.H0 * s.W0 + (s.in1 ? (double)s.cin1 * s.H1 * s.W1 : 0.0) +
+                              (s.res ? (double)s.cout * s.Ho * s.Wo : 0.0) + (double)s.cout * s.Ho * s.Wo);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -527,6 +530,7 @@ static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
   op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
   op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
                             ((double)a.nchunk * k.KC * 9 + (a.k8_h + a.k8_x) * 8.0);
+  op.bytes_per_frame = 4.0 * ((double)s.cin * s.H * s.W + (double)s.cout * a.Ho * a.Wo);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -568,6 +572,7 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   // 16 GEMMs of 32 rows per 128-pixel tile instead of 9 taps x 128 rows; then the 1x1 on 128 rows
   op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) *
                             (16.0 * 32 * a.nchunk * k.KC + 128.0 * (a.k8_h + a.k8_x) * 8.0);
+  op.bytes_per_frame = 4.0 * ((double)s.cin * s.H * s.W + (double)s.cout * s.H * s.W);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -610,6 +615,7 @@ static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, 
   *blob_off += (size_t)k.NBT * 32;
   op.flops_per_frame = 2.0 * H * W * (double)k.CMID * cin * 9;
   op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) * (16.0 * 32 * a.nchunk * k.KC);
+  op.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)std::min(k.CMID, cout - n0) * H * W);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -675,6 +681,8 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   // split operands: six bf16 MFMAs per product
   op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : k.planes == 2 ? 3.0 : 1.0) * 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
                             ((double)a.nchunk * k.KC * 9 + (a.k16_h + a.k16_x) * 16.0);
+  op.bytes_per_frame = (double)s.cin * s.H * s.W * ((s.in_f32 || k.planes > 1) ? 4.0 : 2.0) +
+                       (double)s.cout * a.Ho * a.Wo * ((s.out_f32 || k.planes > 1) ? 4.0 : 2.0);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -731,6 +739,8 @@ static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, 
     *blob_off += (size_t)nbt * 32;
     op.flops_per_frame = 2.0 * a.ntaps * H * W * cin * cout;
     op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : k.planes == 2 ? 3.0 : 1.0) * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+    // the four phases read the same input: a quarter of it is attributed to each, plus the phase's quarter of the output
+    op.bytes_per_frame = (k.planes > 1 ? 4.0 : 2.0) * ((double)cin * H * W / 4.0 + (double)cout * H * W);
     c->ops.push_back(op);
     c->convw.push_back(cw);
   }
@@ -841,6 +851,7 @@ static void add_fconv(fpc_ctx* c, FKind kind, const std::string& prefix, const f
   *blob_off += (size_t)nbt * 32;
   op.flops_per_frame = 2.0 * a.ntaps * H * W * (double)cin * cout;
   op.mfma_flops_per_frame = (k.planes == 2 ? 3.0 : 6.0) * 2.0 * a.ntaps * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (a.nchunk * k.KC) * (nbt * 32.0);
+  op.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)cout * H * W);
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -932,6 +943,7 @@ static int build_vgg_plan(fpc_ctx* c) {
       op.pout = a;
       op.pH = H; op.pW = W;
       op.flops_per_frame = 2.0 * H * W * 64 * 9;
+      op.bytes_per_frame = 4.0 * ((double)H * W + 64.0 * H * W);
       c->ops.push_back(op);
       c->convw.push_back({});
       c->vconv0_off = bo;
@@ -947,6 +959,7 @@ static int build_vgg_plan(fpc_ctx* c) {
       op.pin = b;
       op.pout = F(o_p[i]);
       op.pH = ah[i]; op.pW = aw[i]; op.pC = ac[i];
+      op.bytes_per_frame = 4.0 * 1.25 * ac[i] * ah[i] * aw[i];
       c->ops.push_back(op);
       c->convw.push_back({});
       x = op.pout;
@@ -973,6 +986,7 @@ static int build_vgg_plan(fpc_ctx* c) {
     op.name = "descriptor L2 normalisation over channels";
     op.descriptor_branch = true;
     op.pout = c->desc_map;
+    op.bytes_per_frame = 4.0 * 2 * 256.0 * Hc * Wc;
     c->ops.push_back(op);
     c->convw.push_back({});
   }
@@ -989,6 +1003,8 @@ static int build_vgg_plan(fpc_ctx* c) {
       c->convw.push_back({});
     }
   }
+  for (Op& op : c->ops)
+    if (op.type == OP_SOFTMAX) op.bytes_per_frame = 4.0 * (65.0 * Hc * Wc + 2.0 * H * W);
   c->blob_floats = bo;
   HIPCHECK(hipMalloc((void**)&c->blob, c->blob_floats * sizeof(float)));
   HIPCHECK(hipMemset(c->blob, 0, c->blob_floats * sizeof(float)));
@@ -1081,6 +1097,7 @@ static int build_plan(fpc_ctx* c) {
     op.name = "encoder.conv1+bn1+relu";
     op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;  // of the reference's 3-channel convolution, also for gray frames
     op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
+    op.bytes_per_frame = 4.0 * ((double)c->cin * H * W + 64.0 * H4 * W4);   // frame in, pooled map out (fp32 in every mode)
     if (c->split || c->bf16)  // stem_pool_x3_kernel: (rows + 1) / 2 K16 steps of six bf16 MFMAs
       op.mfma_flops_per_frame = (c->bf16 ? 1 : c->split_f16 ? 3 : 6) * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
     c->ops.push_back(op);
@@ -1239,6 +1256,8 @@ postproc:
       c->convw.push_back({});
     }
   }
+  for (Op& op : c->ops)
+    if (op.type == OP_SOFTMAX) op.bytes_per_frame = 4.0 * (65.0 * Hc * Wc + 2.0 * H * W);   // logits in; prob + NMS state map out
   c->blob_floats = bo;
   HIPCHECK(hipMalloc((void**)&c->blob, c->blob_floats * sizeof(float)));
   HIPCHECK(hipMemset(c->blob, 0, c->blob_floats * sizeof(float)));
@@ -2761,7 +2780,7 @@ int fpc_set_timing(fpc_ctx* c, int enable) {
 }
 
 int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernels, float* ms, double* flops,
-                    double* mfma_flops) {
+                    double* mfma_flops, double* bytes) {
   if (!c) return FPC_E_INVALID;
   const int n = (int)c->timings.size();
   for (int i = 0; i < n && i < cap; ++i) {
@@ -2791,6 +2810,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
     if (ms) ms[i] = v;
     if (flops) flops[i] = op ? op->flops_per_frame * t.frames : 0.0;
     if (mfma_flops) mfma_flops[i] = op ? op->mfma_flops_per_frame * t.frames : 0.0;
+    if (bytes) bytes[i] = op ? op->bytes_per_frame * t.frames : 0.0;
   }
   return n;
 }

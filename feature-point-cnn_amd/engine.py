@@ -338,16 +338,17 @@ class Engine:
         _lib.check(self._l.fpc_set_timing(self._ctx, int(bool(on))), "fpc_set_timing")
 
     def timings(self):
-        """[(layer name, kernel symbol, ms, algorithmic FLOPs per frame, MFMA-issued FLOPs per frame)]
-        of the launches recorded since set_timing(True)."""
-        cap = max(128, _lib.check(self._l.fpc_get_timings(self._ctx, 0, None, None, None, None, None), "fpc_get_timings"))
+        """[(layer name, kernel symbol, ms, algorithmic FLOPs, MFMA-issued FLOPs, algorithmic HBM bytes)] of the
+        launches recorded since set_timing(True) (FLOPs and bytes are per LAUNCH: per frame x the launch's frames)."""
+        cap = max(128, _lib.check(self._l.fpc_get_timings(self._ctx, 0, None, None, None, None, None, None), "fpc_get_timings"))
         names = (ctypes.c_char_p * cap)()
         kernels = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_float * cap)()
         fl = (ctypes.c_double * cap)()
         mf = (ctypes.c_double * cap)()
-        n = _lib.check(self._l.fpc_get_timings(self._ctx, cap, names, kernels, ms, fl, mf), "fpc_get_timings")
-        return [(names[i].decode(), kernels[i].decode(), float(ms[i]), float(fl[i]), float(mf[i]))
+        by = (ctypes.c_double * cap)()
+        n = _lib.check(self._l.fpc_get_timings(self._ctx, cap, names, kernels, ms, fl, mf, by), "fpc_get_timings")
+        return [(names[i].decode(), kernels[i].decode(), float(ms[i]), float(fl[i]), float(mf[i]), float(by[i]))
                 for i in range(min(n, cap))]
 
 

@@ -280,9 +280,11 @@ int fpc_set_timing(fpc_ctx* ctx, int enable);
  * ms[i] is the event-to-event duration; flops[i] the ALGORITHMIC FLOPs of that launch
  * (2 x MACs of the direct convolution x its frames, 0 for non-conv kernels); mfma_flops[i]
  * the FLOPs actually issued on the matrix cores (tile / channel padding included;
- * Winograd launches issue 16/36 of their 3x3 convolution's count).  Any array may be NULL. */
+ * Winograd launches issue 16/36 of their 3x3 convolution's count); bytes[i] the ALGORITHMIC HBM bytes of that launch
+ * (its input tensor(s) read once + its output tensor written once, in the mode's storage type, x its frames; weights
+ * -- L2-resident -- and data-dependent post-processing traffic not counted).  Any array may be NULL. */
 int fpc_get_timings(fpc_ctx* ctx, int cap, const char** names, const char** kernels, float* ms,
-                    double* flops, double* mfma_flops);
+                    double* flops, double* mfma_flops, double* bytes);
 
 #ifdef __cplusplus
 }

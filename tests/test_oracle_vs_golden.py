@@ -124,6 +124,21 @@ def test_f5_end_to_end(golden_dir, tag):
         assert not desc.any()
 
 
+@pytest.mark.parametrize("tag", ["qvga", "gray_vga"])
+def test_torch_cpu_restatement_against_the_reference(golden_dir, tag):
+    """oracle/torch_cpu.py -- what bench.py times as the CPU baseline -- computes the reference's network."""
+    import torch
+    from oracle import torch_cpu
+    g = load(golden_dir, "f5_e2e_%s.npz" % tag)
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frame = synth.make_frame(int(g["seed_frame"]), h, w, gray=tag.startswith("gray"))
+    prob, desc, logits = torch_cpu.forward(torch.from_numpy(frame.transpose(2, 0, 1)[None].copy()), torch_cpu.to_torch(sd))
+    np.testing.assert_allclose(logits.numpy().ravel()[::7], g["logits_probe"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(desc.numpy().ravel()[::11], g["desc_map_probe"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(prob.numpy().ravel()[::13], g["prob_probe"], rtol=0, atol=1e-6)
+
+
 def test_f6_u8_to_float(golden_dir):
     """8-bit frames -> float frames (camera.py:31, preprocess_coco.py:25, inferencewrapper.py:70-81,
     inference.py:79): the oracle against numpy's / torch's own evaluation of the reference's expressions."""
