@@ -22,6 +22,7 @@
 #include "block_bf16.h"
 #include "block_x3.h"
 #include "wblock_mfma.h"
+#include "wblock16_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "match.h"
@@ -137,16 +138,22 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
 #undef X
 };
 
-// Winograd ResNetBlock instances.  WKIND(name, KC, NBT, CMID)
+// Winograd ResNetBlock instances.  WKIND(name, KC, NBT, CMID): wblock_mfma_kernel (generation 1: 32x32x2 blocks, a wave
+// owns 4 positions x 64 channels, phases in lockstep); W16KIND(name, NCG): wblock16_kernel (generation 2: 16x16x4 blocks,
+// a wave owns 16 channels x all positions, input side pipelined into the GEMM), N = 16 NCG output channels.
 #define FPC_WBLOCK_KINDS(X)     \
   X(W816_K32_C64, 32, 2, 64)    \
   X(W816_K32_C128, 32, 4, 128)  \
   X(W816_K32_C72, 32, 3, 72)    \
   X(W816_K24_C72, 24, 3, 72)
+#define FPC_W16_KINDS(X) \
+  X(W16_C64, 4)          \
+  X(W16_C128, 8)
 
 enum WKind {
 #define X(name, ...) WK_##name,
   FPC_WBLOCK_KINDS(X)
+  FPC_W16_KINDS(X)
 #undef X
       WK_COUNT
 };
@@ -154,7 +161,9 @@ enum WKind {
 struct WKindInfo {
   const char* name;
   const char* symbol;
+  int gen;               // 1: wblock_mfma_kernel, 2: wblock16_kernel
   int KC, NBT, CMID, lds_bytes;
+  int NCG;               // generation 2: channel groups of 16
   const void* fn;
   void (*launch)(const WBlockArgs&, dim3, hipStream_t);
 };
@@ -166,12 +175,23 @@ struct WKindInfo {
   }
 FPC_WBLOCK_KINDS(X)
 #undef X
+#define X(name, NCG)                                                                                      \
+  static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
+    hipLaunchKernelGGL((wblock16_kernel<NCG>), grid, dim3(512), W16Cfg<NCG>::LDS_BYTES, st, a);           \
+  }
+FPC_W16_KINDS(X)
+#undef X
 
 static const WKindInfo g_wkinds[WK_COUNT] = {
 #define X(name, KC, NBT, CMID)                                                                            \
-  {#name, "wblock_mfma_kernel<" #KC ", " #NBT ", " #CMID ">", KC, NBT, CMID,                              \
-   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
+  {#name, "wblock_mfma_kernel<" #KC ", " #NBT ", " #CMID ">", 1, KC, NBT, CMID,                           \
+   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, 0, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
     FPC_WBLOCK_KINDS(X)
+#undef X
+#define X(name, NCG)                                                                                      \
+  {#name, "wblock16_kernel<" #NCG ">", 2, 16, NCG / 2, NCG * 16, W16Cfg<NCG>::LDS_BYTES, NCG,             \
+   (const void*)wblock16_kernel<NCG>, launchw_##name},
+    FPC_W16_KINDS(X)
 #undef X
 };
 
@@ -322,6 +342,7 @@ struct fpc_ctx {
   bool winograd_in1 = true;          // descriptor.layer_in.1 (256 ch): conv-only Winograd x2 + 1x1 (FPC_WINOGRAD_IN1=0: fused direct block)
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
+  int winograd_gen = 2;              // 64- and 128-channel Winograd layers on wblock16_kernel (2) or wblock_mfma_kernel (1; FPC_WINOGRAD_GEN)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
   bool plan_error = false;           // a layer asked for a kernel instance that does not exist (fpc_create -> FPC_E_INVALID)
@@ -550,6 +571,7 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   a.x = s.x;
   a.csx = s.csx;
   a.nchunk = s.cin_pad / k.KC;
+  if (s.cin_pad % k.KC) { c->plan_error = true; return; }
   a.H = s.H;
   a.W = s.W;
   a.k8_h = k.CMID / 8;
@@ -561,11 +583,17 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   a.tiles_y = (s.H + 7) / 8;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
-  *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
+  if (k.gen == 2) {   // [channel group][chunk of 16][position][64 lanes] float4 + zero pad per group (wblock16_mfma.h)
+    if (a.nchunk < 4 || (a.nchunk & 1)) { c->plan_error = true; return; }
+    *blob_off += (size_t)k.NCG * ((size_t)a.nchunk * 16 + W16Cfg<8>::WPAD) * 256;
+  } else {
+    *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
+  }
   cw.b_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   cw.w_off[1] = *blob_off;
-  *blob_off += ((size_t)(a.k8_h + a.k8_x) + 2) * k.NBT * 64 * 4;
+  if (k.gen == 2) *blob_off += (size_t)k.NCG * ((size_t)(a.k8_h + a.k8_x) / 2 + W16Cfg<8>::WPAD) * 256;
+  else *blob_off += ((size_t)(a.k8_h + a.k8_x) + 2) * k.NBT * 64 * 4;
   cw.b2_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   op.flops_per_frame = 2.0 * s.H * s.W * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
@@ -610,7 +638,12 @@ static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, 
   a.tiles_y = (H + 7) / 8;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
-  *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
+  if (k.gen == 2) {
+    if (a.nchunk < 4 || (a.nchunk & 1)) { c->plan_error = true; return; }
+    *blob_off += (size_t)k.NCG * ((size_t)a.nchunk * 16 + W16Cfg<8>::WPAD) * 256;
+  } else {
+    *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
+  }
   cw.b_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   op.flops_per_frame = 2.0 * H * W * (double)k.CMID * cin * 9;
@@ -910,7 +943,7 @@ static int build_vgg_plan(fpc_ctx* c) {
       return;
     }
     if (ksize == 3 && relu && c->winograd) {  // Winograd F(2x2,3x3), conv-only; 256 outputs = two 128-channel launches
-      const WKind wk = cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128;
+      const WKind wk = c->winograd_gen == 2 ? (cout == 64 ? WK_W16_C64 : WK_W16_C128) : (cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128);
       for (int n0 = 0; n0 < cout; n0 += g_wkinds[wk].CMID)
         add_wconv(c, prefix, false, wk, x, cin, cin, Hx, Wx, out, cso, cout, n0, desc, &bo);
       return;
@@ -1120,8 +1153,8 @@ static int build_plan(fpc_ctx* c) {
       const BlockSpec bs{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc};
       WKind wk = WK_COUNT;
       if (c->winograd && stride == 1) {
-        if (cinp % 32 == 0 && cout == 64) wk = WK_W816_K32_C64;
-        else if (cinp % 32 == 0 && cout == 128) wk = WK_W816_K32_C128;
+        if (cinp % 32 == 0 && cout == 64) wk = c->winograd_gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
+        else if (cinp % 32 == 0 && cout == 128) wk = c->winograd_gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
         else if (c->winograd_det && cinp % 32 == 0 && coutp == 72) wk = WK_W816_K32_C72;
         else if (c->winograd_det && cinp == 72 && coutp == 72) wk = WK_W816_K24_C72;
       }
@@ -1211,7 +1244,7 @@ static int build_plan(fpc_ctx* c) {
       // launches of 128 output channels each, then conv2 + identity + ReLU as a 1x1 launch (h makes one round trip)
       const std::string p = "descriptor.layer_in.1";
       for (int n0 = 0; n0 < 256; n0 += 128)
-        add_wconv(c, p, true, WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+        add_wconv(c, p, true, c->winograd_gen == 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
       ConvSpec t{};
       t.name = p + ".conv2+bn2+identity+relu";
       t.kind = K_T620_1x1_K64_N128; t.ksize = 1; t.stride = 1;
@@ -1343,6 +1376,45 @@ static bool check_blob_header(const fpc_ctx* c, const uint32_t* h, std::string* 
       return false;
     }
   return true;
+}
+
+// ---- generation-2 Winograd fragments (wblock16_mfma.h) ---------------------------------------------
+// U: [nn][ci][16] Winograd-domain filters (scaled); dst: [channel group][chunk of 16][position][lane] float4 with
+// lane (n = l & 15, kq = l >> 4) holding { U[16 cg + n][16 chunk + 4 kq + j][pos] }, j = 0..3; WPAD zero steps per group.
+static void pack_w16_winograd(const std::vector<double>& U, int nn, int ci, int ncg, int nchunk, float* dst) {
+  const size_t gstride = ((size_t)nchunk * 16 + W16Cfg<8>::WPAD) * 256;
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int ch = 0; ch < nchunk; ++ch)
+      for (int xi = 0; xi < 16; ++xi)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = 16 * cg + (lane & 15), kq = lane >> 4;
+          float* d4 = dst + cg * gstride + (((size_t)ch * 16 + xi) * 64 + lane) * 4;
+          for (int j = 0; j < 4; ++j) {
+            const int cc = 16 * ch + 4 * kq + j;
+            d4[j] = (n < nn && cc < ci) ? (float)U[((size_t)n * ci + cc) * 16 + xi] : 0.f;
+          }
+        }
+}
+
+// 1x1 over [h | x]: sources concatenated along K (each a multiple of 16 channels); dst [channel group][step of 16][lane] float4
+static void pack_w16_1x1(const std::vector<PackSource>& srcs, int cout, int ncg, float* dst) {
+  size_t steps = 0;
+  for (auto& s : srcs) steps += (size_t)s.cin_pad / 16;
+  const size_t gstride = (steps + W16Cfg<8>::WPAD) * 256;
+  size_t step0 = 0;
+  for (auto& s : srcs) {
+    for (int g = 0; g < s.cin_pad / 16; ++g)
+      for (int cg = 0; cg < ncg; ++cg)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = 16 * cg + (lane & 15), kq = lane >> 4;
+          float* d4 = dst + cg * gstride + ((step0 + g) * 64 + lane) * 4;
+          for (int j = 0; j < 4; ++j) {
+            const int cc = 16 * g + 4 * kq + j;
+            d4[j] = (n < cout && cc < s.cin) ? (float)(s.w(n, cc, 0) * (*s.scale)[n]) : 0.f;
+          }
+        }
+    step0 += (size_t)s.cin_pad / 16;
+  }
 }
 
 // ---- checkpoint -> blob -----------------------------------------------------------------
@@ -1485,6 +1557,8 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
               for (int j = 0; j < 4; ++j)
                 U[((size_t)n * ci + cc) * 16 + i * 4 + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * f1.s[op.n0 + n];
           }
+        if (k.gen == 2) pack_w16_winograd(U, nn, ci, k.NCG, a.nchunk, dst);
+        else
         for (int ch = 0; ch < a.nchunk; ++ch)
           for (int xi = 0; xi < 16; ++xi)
             for (int k8 = 0; k8 < K8; ++k8)
@@ -1519,6 +1593,8 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
               U[((size_t)n * ci + cc) * 16 + i * 4 + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * f1.s[n];
         }
       float* dst = blob.data() + cw.w_off[0];
+      if (k.gen == 2) pack_w16_winograd(U, co, ci, k.NCG, a.nchunk, dst);
+      else
       for (int ch = 0; ch < a.nchunk; ++ch)
         for (int xi = 0; xi < 16; ++xi)
           for (int k8 = 0; k8 < K8; ++k8)
@@ -1542,8 +1618,12 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
         srcs.push_back({ci, a.k8_x * 8, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
         for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
       }
-      std::vector<float> frag = pack_conv(srcs, co, nbt, 8);
-      memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
+      if (k.gen == 2) {
+        pack_w16_1x1(srcs, co, k.NCG, blob.data() + cw.w_off[1]);
+      } else {
+        std::vector<float> frag = pack_conv(srcs, co, nbt, 8);
+        memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
+      }
       for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
       continue;
     }
@@ -1857,6 +1937,10 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
 #endif
         a.total = a.tiles_x * a.tiles_y * n;
         a.xcd_order = c->xcd_order ? 1 : 0;
+        {  // range of the input's buffer descriptor: frames 0 .. f0 + n - 1 of the tensor, from `x` (already offset to its first channel)
+          const unsigned long long xb = (unsigned long long)(f0 + n) * a.H * a.W * a.csx * sizeof(float);
+          a.x_bytes = xb > 0xfffffff0ull ? 0xfffffff0u : (unsigned)xb;
+        }
         // persistent (one workgroup per CU walking the tiles) when a workgroup gets enough tiles to
         // amortise; otherwise one workgroup per tile
         const int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
@@ -2169,6 +2253,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->split_heads = (pf & FPC_PLAN_SPLIT_HEADS) != 0;
     if (pf & FPC_PLAN_NO_PERSISTENT_GRID) c->persist_min_tiles = 0;
     c->layer1_t816 = (pf & FPC_PLAN_LAYER1_TILE_8x16) != 0;
+    c->winograd_gen = (pf & FPC_PLAN_WINOGRAD_GEN1) ? 1 : 2;
+    if (const char* e = getenv("FPC_WINOGRAD_GEN")) c->winograd_gen = atoi(e) == 1 ? 1 : 2;
     if (cfg->min_sub_batch > 0) c->min_sub = cfg->min_sub_batch;
     if (cfg->nms_round_launches > 0) c->nms_passes = std::min(64, cfg->nms_round_launches);
     else if (cfg->nms_round_launches < 0) c->nms_passes = 0;
@@ -2446,7 +2532,7 @@ int fpc_sync(fpc_ctx* c) {
 #ifdef FPC_DIAG
   if (c->diag_stamps && c->diag_n) {
     if (FILE* f = fopen(getenv("FPC_STAMP_FILE") ? getenv("FPC_STAMP_FILE") : "/tmp/fpc_stamps.bin", "wb")) {
-      fwrite(c->diag_stamps, sizeof(unsigned long long) * 8, c->diag_n, f);
+      fwrite(c->diag_stamps, sizeof(unsigned long long) * 8, getenv("FPC_STAMP_FULL") ? 65536 : c->diag_n, f);
       fclose(f);
     }
   }
