@@ -147,8 +147,9 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
   X(W816_K32_C72, 32, 3, 72)    \
   X(W816_K24_C72, 24, 3, 72)
 #define FPC_W16_KINDS(X) \
-  X(W16_C64, 4)          \
-  X(W16_C128, 8)
+  X(W16_C64, 4, 8)       \
+  X(W16_C128, 8, 8)      \
+  X(W16_C128H, 8, 4)
 
 enum WKind {
 #define X(name, ...) WK_##name,
@@ -164,6 +165,7 @@ struct WKindInfo {
   int gen;               // 1: wblock_mfma_kernel, 2: wblock16_kernel
   int KC, NBT, CMID, lds_bytes;
   int NCG;               // generation 2: channel groups of 16
+  int TH;                // tile height in pixels (8; 4 for the latency instance)
   const void* fn;
   void (*launch)(const WBlockArgs&, dim3, hipStream_t);
 };
@@ -175,9 +177,10 @@ struct WKindInfo {
   }
 FPC_WBLOCK_KINDS(X)
 #undef X
-#define X(name, NCG)                                                                                      \
+#define X(name, NCG, TH)                                                                                  \
   static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
-    hipLaunchKernelGGL((wblock16_kernel<NCG>), grid, dim3(512), W16Cfg<NCG>::LDS_BYTES, st, a);           \
+    constexpr int lds = W16Cfg<NCG, TH>::LDS_BYTES;                                                       \
+    hipLaunchKernelGGL((wblock16_kernel<NCG, TH>), grid, dim3(512), lds, st, a);                          \
   }
 FPC_W16_KINDS(X)
 #undef X
@@ -185,12 +188,12 @@ FPC_W16_KINDS(X)
 static const WKindInfo g_wkinds[WK_COUNT] = {
 #define X(name, KC, NBT, CMID)                                                                            \
   {#name, "wblock_mfma_kernel<" #KC ", " #NBT ", " #CMID ">", 1, KC, NBT, CMID,                           \
-   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, 0, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
+   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, 0, 8, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
     FPC_WBLOCK_KINDS(X)
 #undef X
-#define X(name, NCG)                                                                                      \
-  {#name, "wblock16_kernel<" #NCG ">", 2, 16, NCG / 2, NCG * 16, W16Cfg<NCG>::LDS_BYTES, NCG,             \
-   (const void*)wblock16_kernel<NCG>, launchw_##name},
+#define X(name, NCG, TH)                                                                                  \
+  {#name, TH == 8 ? "wblock16_kernel<" #NCG ">" : "wblock16_kernel<" #NCG ", " #TH ">", 2, 16, NCG / 2, NCG * 16,     \
+   W16Cfg<NCG, TH>::LDS_BYTES, NCG, TH, (const void*)wblock16_kernel<NCG, TH>, launchw_##name},
     FPC_W16_KINDS(X)
 #undef X
 };
@@ -198,7 +201,7 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 // bf16 / split-operand instances.  FKIND(name, KERNEL, CFG, PLANES, TH,TW, S,EXT, KC, WM,WN, MB,NB, CMIDP)
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
 #define FPC_BF16_KINDS(X)                                                                   \
-  X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 4, 1, 1, 2, 64)     \
+  X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
   X(F620_s2_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
@@ -279,6 +282,7 @@ struct Op {
   BlockBfArgs fargs{};
   int phase = -1;              // ConvTranspose output-parity phase of a bf16 conv-only op
   int when = 0;                // 0: always; 1: only in calls of a few frames; 2: only in larger calls
+  bool shadow = false;         // packed like any op but never launched: the second half of a merged two-half launch (see add_wconv)
   bool wconv = false;          // conv-only Winograd launch: 3x3 conv + (BN or bias) + ReLU, output channels n0 .. n0+127
   int n0 = 0;
   bool plain_conv = false;     // a Conv2d + bias (+ ReLU) of the C++ network: weights `prefix`.weight / .bias, no BN
@@ -342,6 +346,7 @@ struct fpc_ctx {
   bool winograd_in1 = true;          // descriptor.layer_in.1 (256 ch): conv-only Winograd x2 + 1x1 (FPC_WINOGRAD_IN1=0: fused direct block)
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
+  bool latency_tiles = true;         // calls of a few frames run the 128-channel Winograd blocks on 4 x 16 tiles (FPC_LATENCY_TILES=0: 8 x 16)
   int winograd_gen = 2;              // 64- and 128-channel Winograd layers on wblock16_kernel (2) or wblock_mfma_kernel (1; FPC_WINOGRAD_GEN)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
   bool weights_loaded = false;
@@ -580,7 +585,7 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   a.out = s.out;
   a.cso = s.cso;
   a.tiles_x = (s.W + 15) / 16;
-  a.tiles_y = (s.H + 7) / 8;
+  a.tiles_y = (s.H + k.TH - 1) / k.TH;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
   if (k.gen == 2) {   // [channel group][chunk of 16][position][64 lanes] float4 + zero pad per group (wblock16_mfma.h)
@@ -599,10 +604,23 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   op.flops_per_frame = 2.0 * s.H * s.W * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
   // 16 GEMMs of 32 rows per 128-pixel tile instead of 9 taps x 128 rows; then the 1x1 on 128 rows
   op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) *
-                            (16.0 * 32 * a.nchunk * k.KC + 128.0 * (a.k8_h + a.k8_x) * 8.0);
+                            (16.0 * (4 * k.TH) * a.nchunk * k.KC + (16.0 * k.TH) * (a.k8_h + a.k8_x) * 8.0);
   op.bytes_per_frame = 4.0 * ((double)s.cin * s.H * s.W + (double)s.cout * s.H * s.W);
   c->ops.push_back(op);
   c->convw.push_back(cw);
+  if (wk == WK_W16_C128 && c->latency_tiles) {
+    // the same layer on 4 x 16 tiles for calls of a few frames (same fragments: the blob offsets are shared)
+    const WKindInfo& kh = g_wkinds[WK_W16_C128H];
+    c->ops.back().when = 2;
+    Op oh = c->ops.back();
+    oh.when = 1;
+    oh.wkind = WK_W16_C128H;
+    oh.wargs.tiles_y = (s.H + kh.TH - 1) / kh.TH;
+    oh.mfma_flops_per_frame = 2.0 * oh.wargs.tiles_x * oh.wargs.tiles_y * (kh.NBT * 32.0) *
+                              (16.0 * (4 * kh.TH) * a.nchunk * kh.KC + (16.0 * kh.TH) * (a.k8_h + a.k8_x) * 8.0);
+    c->ops.push_back(oh);
+    c->convw.push_back(cw);
+  }
 }
 
 // A 3x3 stride-1 convolution + (folded BN | bias) + ReLU on the Winograd kernel in conv-only form.  Output channels
@@ -635,7 +653,7 @@ static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, 
   a.out = out + n0;
   a.cso = cso;
   a.tiles_x = (W + 15) / 16;
-  a.tiles_y = (H + 7) / 8;
+  a.tiles_y = (H + k.TH - 1) / k.TH;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
   if (k.gen == 2) {
@@ -649,6 +667,20 @@ static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, 
   op.flops_per_frame = 2.0 * H * W * (double)k.CMID * cin * 9;
   op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) * (16.0 * 32 * a.nchunk * k.KC);
   op.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)std::min(k.CMID, cout - n0) * H * W);
+  if (k.gen == 2 && n0 == k.CMID && cout == 2 * k.CMID && !c->ops.empty() && c->ops.back().wconv && c->ops.back().prefix == prefix &&
+      c->ops.back().n0 == 0 && c->ops.back().wkind == wk) {
+    // second half of a 256-wide layer: ONE launch computes both halves (gridDim.y = 2); this op only carries the
+    // half's checkpoint -> fragment packing
+    Op& first = c->ops.back();
+    fpc_ctx::ConvW& cf = c->convw.back();
+    first.grid_y = 2;
+    first.wargs.ysplit_floats = (int)(cw.w_off[0] - cf.w_off[0]);
+    first.flops_per_frame *= 2;
+    first.mfma_flops_per_frame *= 2;
+    first.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)cout * H * W);
+    first.name = prefix + (bn ? ".conv1+bn1+relu [winograd, both 128-channel halves]" : " [winograd conv+bias+relu, both 128-channel halves]");
+    op.shadow = true;
+  }
   c->ops.push_back(op);
   c->convw.push_back(cw);
 }
@@ -1253,12 +1285,27 @@ static int build_plan(fpc_ctx* c) {
       t.out = c->y16b; t.cso = 256; t.cout = 256; t.nstore = 256; t.Ho = H16; t.Wo = W16; t.relu = 1;
       t.desc_branch = true;
       add_conv(c, t, &bo);
+      if (c->winograd_gen == 2 && c->latency_tiles) {
+        // calls of a few frames: the same two-half launch on 4 x 16 tiles (24 tiles x 2 halves per frame instead of
+        // 12 x 2), then the same 1x1 -- 0.10 ms for one frame against 0.16 ms for the fused direct block on 20 tiles
+        const size_t ia = c->ops.size() - 3;
+        c->ops[ia].when = 2;
+        Op oh = c->ops[ia];
+        oh.when = 1;
+        oh.wkind = WK_W16_C128H;
+        oh.wargs.tiles_y = (H16 + 3) / 4;
+        oh.mfma_flops_per_frame = 2 * 2.0 * oh.wargs.tiles_x * oh.wargs.tiles_y * 128.0 * (16.0 * 16 * 256);
+        const fpc_ctx::ConvW cwa = c->convw[ia];
+        c->ops.insert(c->ops.begin() + ia + 1, oh);
+        c->convw.insert(c->convw.begin() + ia + 1, cwa);
+      } else {
       for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
       // a call of a few frames has 12 tiles per frame here: three dependent launches cost more latency than they save
       // work, so small calls take the fused direct block instead (its weights sit in the blob next to the others)
       block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
             c->h16, 256, 256, 256, c->y16b, 256, false, true, BK_B320_s1_K64_C256);
       c->ops.back().when = 1;
+      }
     } else
     block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
           c->h16, 256, 256, 256, c->y16b, 256, false, true, BK_B320_s1_K64_C256);
@@ -1857,6 +1904,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
     const Op& op = c->ops[i];
     const int br = op.descriptor_branch ? 2 : (op.name.compare(0, 8, "detector") == 0 ? 1 : 0);
     if (br != which) continue;
+    if (op.shadow) continue;
     if (op.when == 1 && !sb.small) continue;   // variants of a layer for small / large calls
     if (op.when == 2 && sb.small) continue;
     switch (op.type) {
@@ -1944,7 +1992,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         // persistent (one workgroup per CU walking the tiles) when a workgroup gets enough tiles to
         // amortise; otherwise one workgroup per tile
         const int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
-        g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid)), sb.st);
+        g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid), op.grid_y), sb.st);
         break;
       }
       case OP_BLOCK: {
@@ -2255,6 +2303,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->layer1_t816 = (pf & FPC_PLAN_LAYER1_TILE_8x16) != 0;
     c->winograd_gen = (pf & FPC_PLAN_WINOGRAD_GEN1) ? 1 : 2;
     if (const char* e = getenv("FPC_WINOGRAD_GEN")) c->winograd_gen = atoi(e) == 1 ? 1 : 2;
+    c->latency_tiles = !(pf & FPC_PLAN_NO_LATENCY_TILES);
+    if (const char* e = getenv("FPC_LATENCY_TILES")) c->latency_tiles = atoi(e) != 0;
     if (cfg->min_sub_batch > 0) c->min_sub = cfg->min_sub_batch;
     if (cfg->nms_round_launches > 0) c->nms_passes = std::min(64, cfg->nms_round_launches);
     else if (cfg->nms_round_launches < 0) c->nms_passes = 0;

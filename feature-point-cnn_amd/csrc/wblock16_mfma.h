@@ -42,12 +42,18 @@ namespace fpc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NCG>
+// TH_ = 8: 8 x 16 pixel tiles (throughput).  TH_ = 4 (N = 128 only): 4 x 16 pixel tiles for calls of a few frames --
+// twice as many workgroups, each with half the MFMAs: the latency of a layer is the time of ONE tile when the frame has
+// fewer tiles than the chip has CUs (60 x 80 features: 40 tiles of 8 x 16).  The input side still stages and transforms
+// the 10-row window (rows 6..9 feed tiles nobody multiplies): wasteful, but off the critical path of a single frame.
+template <int NCG, int TH_ = 8>
 struct W16Cfg {
-  static constexpr int NT = 512, TH = 8, TW = 16, HW = 18, HH = 10, KC = 16;
+  static constexpr int NT = 512, TH = TH_, TW = 16, HW = 18, HH = 10, KC = 16;
   static constexpr int TG = 8 / NCG;        // wave groups over tiles / pixels: 1 (N = 128) or 2 (N = 64)
-  static constexpr int MBW = 2 / TG;        // 16-tile blocks per wave in the Winograd GEMMs
-  static constexpr int MB2 = 8 / TG;        // 16-pixel blocks per wave in the 1x1
+  static constexpr int MBW = TH_ == 4 ? 1 : 2 / TG;   // 16-tile blocks per wave in the Winograd GEMMs
+  static constexpr int MB2 = TH_ == 4 ? 4 : 8 / TG;   // 16-pixel blocks per wave in the 1x1
+  static constexpr int PX = TH_ * TW;       // output pixels of a tile
+  static_assert(TH_ == 8 || (TH_ == 4 && NCG == 8), "half-height tiles exist for the 128-channel instance");
   static constexpr int N = NCG * 16;
   static constexpr int V_FLOATS = 16 * 32 * 16;
   static constexpr int HROW = 20;           // halo row: 16 channels + 4 floats of skew
@@ -67,11 +73,11 @@ struct W16Cfg {
   static_assert(NCG == 8 || NCG == 4, "8 waves = NCG channel groups x TG tile groups");
 };
 
-template <int NCG>
+template <int NCG, int TH_ = 8>
 __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
-  using C = W16Cfg<NCG>;
+  using C = W16Cfg<NCG, TH_>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HW = C::HW, HROW = C::HROW;
-  constexpr int MBW = C::MBW, MB2 = C::MB2, N = C::N, RH = C::RH, RX = C::RX, RING = C::RING;
+  constexpr int MBW = C::MBW, MB2 = C::MB2, N = C::N, RH = C::RH, RX = C::RX, RING = C::RING, PX = C::PX;
   extern __shared__ float lds[];
   float* const V0 = lds + C::OFF_V0;
   float* const V1 = lds + C::OFF_V1;
@@ -85,6 +91,10 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
   const int cg = wave % NCG, tg = wave / NCG;
   const int tiles = a.tiles_x * a.tiles_y;
   const int nchunk = a.nchunk;              // Cin / 16, even, >= 4
+  // second half of a 256-wide conv-only layer (gridDim.y == 2)
+  const float4* const w1h = a.w1 + (size_t)blockIdx.y * (a.ysplit_floats / 4);
+  const float* const b1h = a.b1 + (size_t)blockIdx.y * a.ysplit_floats;
+  float* const outh = a.out + blockIdx.y * N;
 
   // tile walk (persistent, XCD-aware): as wblock_mfma_kernel
   const bool xcd_order = a.xcd_order && (gridDim.x & 7) == 0;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
   // (buffer_load ... offen with the lane offset in a VGPR that never changes and the step in the scalar offset: one
   // s_add per load instead of a 64-bit scalar address + a 64-bit vector add)
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float4*>(a.w1), 0, (int)((unsigned)NCG * ((unsigned)nchunk * 16u + (unsigned)C::WPAD) * 1024u), 0x00020000);
+      const_cast<float4*>(w1h), 0, (int)((unsigned)NCG * ((unsigned)nchunk * 16u + (unsigned)C::WPAD) * 1024u), 0x00020000);
   const unsigned wlane = (unsigned)cg * ((unsigned)nchunk * 16u + (unsigned)C::WPAD) * 1024u + lane16;
   auto ldb = [&](int s) {
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024, 0));
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
 
     // ---------------------------------------------------------------- output transform in registers -> h (LDS)
     {
-      const float bias = a.b1[16 * cg + t16];
+      const float bias = b1h[16 * cg + t16];
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
@@ -373,14 +383,14 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
     if (wg == wg_stamp) { FPC_STAMP(2) }
 
     if (a.conv_only) {  // h is the result: [128 px][N] in LDS -> 16-byte stores
-      constexpr int C4 = N / 4, EIT = 128 * C4 / NT;
+      constexpr int C4 = N / 4, EIT = PX * C4 / NT;
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
         const int e = tid_t + i * NT;
         const int m = e / C4, c4 = e - m * C4;
         const int y = ty * TH + (m >> 4), x = tx * TW + (m & 15);
         if (y < a.H && x < a.W)
-          *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) =
+          *reinterpret_cast<float4*>(outh + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) =
               *reinterpret_cast<const float4*>(TL + m * RH + c4 * 4);
       }
       FPC_LDS_BARRIER();   // the next tile's second chunk is transformed into V1 = this region
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
       }
     };
     // projection shortcut: the tile's centre pixels of x, up to 128 channels per pass, requested before the GEMM over h
-    constexpr int XIT = 128 * 32 / NT;
+    constexpr int XIT = PX * 32 / NT;
     float4 xst[XIT];
     auto load_x = [&](int pass) {
       const int kx4 = min(32, a.k8_x * 2 - pass * 32);   // float4 per pixel in this pass
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
     }
     FPC_LDS_BARRIER();
     {
-      constexpr int C4 = N / 4, EIT = 128 * C4 / NT;
+      constexpr int C4 = N / 4, EIT = PX * C4 / NT;
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
         const int e = tid_t + i * NT;

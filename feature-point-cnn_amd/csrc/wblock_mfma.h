@@ -31,6 +31,9 @@ struct WBlockArgs {
   int cso, tiles_x, tiles_y, frame0;
   int total;             // tiles_x * tiles_y * frames of this launch; the grid is persistent
   int xcd_order;         // 1: XCD-aware tile order (see the kernel)
+  int ysplit_floats;     // wblock16_kernel, conv_only: blockIdx.y = 1 computes the NEXT 16 NCG output channels -- its fragments and
+                         // bias lie this many floats behind w1 / b1, its outputs 16 NCG channels behind `out` (a 256-wide
+                         // layer is one launch of two 128-channel halves)
   unsigned x_bytes;      // wblock16_kernel: bytes from `x` to the end of the input tensor's frames of this launch (buffer descriptor range)
   int conv_only;         // 1: stop after h = relu(conv3x3(x) + b1) and store it (a plain Conv2d + bias/BN + ReLU:
                          // the layers of the C++ network, conv1 of a block too wide to fuse); w2 / b2 unused
