@@ -196,7 +196,7 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
     FPC_WBLOCK_KINDS(X)
 #undef X
 #define X(name, NCG, TH)                                                                                  \
-  {#name, TH == 8 ? "wblock16_kernel<" #NCG ">" : "wblock16_kernel<" #NCG ", " #TH ">", 2, 16, NCG / 2, NCG * 16,     \
+  {#name, "wblock16_kernel<" #NCG ", " #TH ">", 2, 16, NCG / 2, NCG * 16,                                  \
    W16Cfg<NCG, TH>::LDS_BYTES, NCG, TH, (const void*)wblock16_kernel<NCG, TH>, launchw_##name},
     FPC_W16_KINDS(X)
 #undef X
@@ -565,15 +565,16 @@ static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
   c->convw.push_back(cw);
 }
 
-// The op just added, once more on a finer tile for calls of a few frames (when = 1; the original becomes when = 2).
-// The instance must consume the same fragments (same KC and channel blocking): the blob offsets are shared.
-static void add_latency_twin(fpc_ctx* c, BKind small) {
+// The op just added moves to a finer tile (an instance that consumes the same fragments: same KC and channel blocking).
+// Half-size tiles double the workgroups of the stride-2 blocks, the transposed convolution and layer_in.1's 1x1: the
+// latency of a single frame's layer is one tile's time (20 - 40 tiles per frame on 256 CUs), and a 32-frame batch runs
+// 3 - 10 % faster on them too (shorter tail, more workgroups per CU in flight) -- measured, so they serve every call.
+// FPC_PLAN_NO_LATENCY_TILES keeps round 1's tiles.
+static void retile_last(fpc_ctx* c, BKind small) {
   if (!c->latency_tiles || c->ops.empty() || c->ops.back().type != OP_BLOCK) return;
   const BKindInfo &k0 = g_bkinds[c->ops.back().bkind], &k = g_bkinds[small];
   if (k.KC != k0.KC || k.WN * k.NB != k0.WN * k0.NB || k.S != k0.S || k.CMIDP != k0.CMIDP) { c->plan_error = true; return; }
-  c->ops.back().when = 2;
-  Op o = c->ops.back();
-  o.when = 1;
+  Op& o = c->ops.back();
   o.bkind = small;
   BlockArgs& a = o.bargs;
   const int HWp = (k.TW - 1) * k.S + 3, ROW4 = k.KC / 4 + 1;
@@ -583,18 +584,13 @@ static void add_latency_twin(fpc_ctx* c, BKind small) {
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
   o.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (k.WN * k.NB * 32.0) *
                            ((double)a.nchunk * k.KC * 9 + (a.k8_h + a.k8_x) * 8.0);
-  const fpc_ctx::ConvW cw = c->convw.back();
-  c->ops.push_back(o);
-  c->convw.push_back(cw);
 }
 
-static void add_latency_twin(fpc_ctx* c, Kind small) {
+static void retile_last(fpc_ctx* c, Kind small) {
   if (!c->latency_tiles || c->ops.empty() || c->ops.back().type != OP_CONV) return;
   const KindInfo &k0 = g_kinds[c->ops.back().kind], &k = g_kinds[small];
   if (k.KC != k0.KC || k.WN * k.NB != k0.WN * k0.NB || k.S != k0.S || k.EXT != k0.EXT) { c->plan_error = true; return; }
-  c->ops.back().when = 2;
-  Op o = c->ops.back();
-  o.when = 1;
+  Op& o = c->ops.back();
   o.kind = small;
   ConvArgs& a = o.args;
   const int HWp = (k.TW - 1) * k.S + k.EXT, HWp0 = (k0.TW - 1) * k0.S + k0.EXT, ROW4 = k.KC / 4 + 1;
@@ -605,9 +601,6 @@ static void add_latency_twin(fpc_ctx* c, Kind small) {
     }
   a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
-  const fpc_ctx::ConvW cw = c->convw.back();
-  c->ops.push_back(o);
-  c->convw.push_back(cw);
 }
 
 static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_off) {
@@ -1280,7 +1273,7 @@ static int build_plan(fpc_ctx* c) {
         c->x2, 64, false, false, l1kind);
   block("encoder.layer2.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, c->x2, 64, 64, 64, H4, W4, c->h8, 128,
         128, 128, c->x3, 128, true, false, BK_B620_s2_K32_C128);
-  if (c->fuse_blocks) add_latency_twin(c, BK_B320_s2_K32_C128);
+  if (c->fuse_blocks) retile_last(c, BK_B320_s2_K32_C128);
   block("encoder.layer2.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->x3, 128, 128, 128, Hc, Wc, c->h8, 128,
         128, 128, feat, 256, false, false, BK_B620_s1_K64_C128);
   if (c->fuse_blocks) {
@@ -1321,7 +1314,7 @@ static int build_plan(fpc_ctx* c) {
   if (de) {
     block("descriptor.layer_in.0", K_T620_3x3s2_K32_N128, K_T620_1x1_K64_N128, 2, feat, 256, 128, 128, Hc, Wc, c->h16,
           256, 256, 256, c->y16a, 256, true, true, BK_B320_s2_K32_C256);
-    if (c->fuse_blocks) add_latency_twin(c, BK_B310_s2_K32_C256);
+    if (c->fuse_blocks) retile_last(c, BK_B310_s2_K32_C256);
     if (c->fuse_blocks && c->winograd && c->winograd_in1) {
       // 256 channels are too wide for the fused Winograd block (accumulators): conv1 as two conv-only Winograd
       // launches of 128 output channels each, then conv2 + identity + ReLU as a 1x1 launch (h makes one round trip)
@@ -1336,11 +1329,11 @@ static int build_plan(fpc_ctx* c) {
       t.out = c->y16b; t.cso = 256; t.cout = 256; t.nstore = 256; t.Ho = H16; t.Wo = W16; t.relu = 1;
       t.desc_branch = true;
       add_conv(c, t, &bo);
-      if (c->winograd_gen == 2 && c->latency_tiles) add_latency_twin(c, K_T320_1x1_K64_N128);
+      retile_last(c, K_T320_1x1_K64_N128);
       if (c->winograd_gen == 2 && c->latency_tiles) {
         // calls of a few frames: the same two-half launch on 4 x 16 tiles (24 tiles x 2 halves per frame instead of
         // 12 x 2), then the same 1x1 -- 0.10 ms for one frame against 0.16 ms for the fused direct block on 20 tiles
-        const size_t ia = c->ops.size() - 4;   // [two-half launch, its shadow, 1x1, 1x1 on the finer tile]
+        const size_t ia = c->ops.size() - 3;   // [two-half launch, its shadow, 1x1]
         c->ops[ia].when = 2;
         Op oh = c->ops[ia];
         oh.when = 1;
@@ -1368,7 +1361,7 @@ static int build_plan(fpc_ctx* c) {
     u.out = c->cat; u.cso = 256; u.cout = 128; u.nstore = 128; u.Ho = Hc; u.Wo = Wc; u.relu = 1;
     u.desc_branch = true;
     add_conv(c, u, &bo);
-    add_latency_twin(c, K_T320_2x2_K64_N128);
+    retile_last(c, K_T320_2x2_K64_N128);
     block("descriptor.layer_out.0", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->cat, 256, 256, 256, Hc, Wc,
           c->lo_h, 128, 128, 128, c->lo0, 128, true, true, BK_B620_s1_K64_C128);
     block("descriptor.layer_out.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->lo0, 128, 128, 128, Hc, Wc,
