@@ -80,7 +80,6 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
   constexpr int MBW = C::MBW, MB2 = C::MB2, N = C::N, RH = C::RH, RX = C::RX, RING = C::RING, PX = C::PX;
   extern __shared__ float lds[];
   float* const V0 = lds + C::OFF_V0;
-  float* const V1 = lds + C::OFF_V1;
   float* const HB0 = lds + C::OFF_H0;
   float* const HB1 = lds + C::OFF_H1;
   float* const TL = lds + C::OFF_V1;        // h, x staging, output tile
@@ -235,10 +234,15 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
     // not an MFMA costs the SIMD ~2.6 cycles of a chunk, in-kernel stamps of both instances)
     auto chunk_body = [&](auto PAR, const int c) {
       constexpr int par = decltype(PAR)::value;
-      const float* vb = par ? V1 : V0;
-      float* vn = par ? V0 : V1;
-      const float* hn = par ? HB0 : HB1;   // halo[(c + 1) & 1]
       float* hs = par ? HB1 : HB0;         // halo[c & 1]
+      // (LDS addresses as ONE opaque register per stream -- buffer base included, V1 and halo1 lie beyond the 64 KiB
+      // an instruction's immediate offset reaches -- plus immediates; with the base added per access the loop carried
+      // 60 vector adds per two chunks, and every non-MFMA instruction costs the SIMD ~2.6 cycles)
+      constexpr int VB_OFF = par ? C::OFF_V1 : C::OFF_V0, VN_OFF = par ? C::OFF_V0 : C::OFF_V1;
+      constexpr int HN_OFF = par ? C::OFF_H0 : C::OFF_H1;   // halo[(c + 1) & 1]
+      const float* vb = lds;
+      float* vn = lds;
+      const float* hn = lds;
       // chunk c + 3 of this tile, or the next tile's chunk c + 3 - nchunk
       const int c3 = c + 3;
       const int l_wg = c3 < nchunk ? wg : wg + wg_step;
@@ -257,10 +261,10 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
       // (opaque per-chunk copies of the lane's LDS offsets: left visible, every `buffer + offset + position` sum is
       // loop-invariant, gets its own register outside the tile loop -- 40 of them -- and is spilled; opaque, the
       // position becomes the instruction's immediate offset)
-      int ao[MBW], trd_c = trd, twr_c = twr;
+      int ao[MBW], trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb) {
-        ao[mb] = aoff[mb];
+        ao[mb] = aoff[mb] + VB_OFF;
         asm volatile("" : "+v"(ao[mb]));
       }
       asm volatile("" : "+v"(trd_c), "+v"(twr_c));
