@@ -340,6 +340,7 @@ struct fpc_ctx {
   int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
   bool xcd_order = true;             // FPC_XCD_ORDER=0: plain tile order in the persistent Winograd kernel
   int nms_passes = 2;
+  bool nms_one_workgroup = false;  // FPC_PLAN_NMS_ONE_WORKGROUP: round 1's sort (one workgroup per frame) for every frame
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
   bool layer1_t816 = false;          // direct (non-Winograd) layer1 blocks on 8x16 tiles instead of 16x16
@@ -366,6 +367,7 @@ struct fpc_ctx {
   int32_t *ncand, *count, *xy, *status;
   float *conf, *desc_out;
   unsigned long long* sort_scratch;
+  int32_t* nms_aux = nullptr;  // [B][NMS_AUX_INTS] (kernels_misc.h: nms_chunk_sort_kernel)
   unsigned long long *rowbest, *colbest;  // descriptor matching workspace, `cap` entries each
 
   float* u8stage = nullptr;          // fpc_detect_u8: converted frames [B,cin,H,W], allocated on first use
@@ -982,7 +984,8 @@ static int build_vgg_plan(fpc_ctx* c) {
   const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4);
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>((size_t)B * c->cap * 256);
-  const size_t o_sort = cv.take<unsigned long long>(c->sort_cap > NMS_LDS_KEYS ? (size_t)B * c->sort_cap : 64);
+  const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
+  const size_t o_aux = cv.take<int32_t>((size_t)B * NMS_AUX_INTS);
   const size_t o_rowbest = cv.take<unsigned long long>(c->cap), o_colbest = cv.take<unsigned long long>(c->cap);
   c->slab_bytes = cv.off;
   if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
@@ -1001,6 +1004,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
   c->sort_scratch = reinterpret_cast<unsigned long long*>(c->slab + o_sort);
+  c->nms_aux = reinterpret_cast<int32_t*>(c->slab + o_aux);
   c->rowbest = reinterpret_cast<unsigned long long*>(c->slab + o_rowbest);
   c->colbest = reinterpret_cast<unsigned long long*>(c->slab + o_colbest);
 
@@ -1168,7 +1172,8 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4);
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>(de ? (size_t)B * c->cap * 128 : 64);
-  const size_t o_sort = cv.take<unsigned long long>(c->sort_cap > NMS_LDS_KEYS ? (size_t)B * c->sort_cap : 64);
+  const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
+  const size_t o_aux = cv.take<int32_t>((size_t)B * NMS_AUX_INTS);
   const size_t o_rowbest = cv.take<unsigned long long>(c->cap), o_colbest = cv.take<unsigned long long>(c->cap);
   c->slab_bytes = cv.off;
   if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
@@ -1191,6 +1196,7 @@ static int build_plan(fpc_ctx* c) {
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
   c->sort_scratch = reinterpret_cast<unsigned long long*>(c->slab + o_sort);
+  c->nms_aux = reinterpret_cast<int32_t*>(c->slab + o_aux);
   c->rowbest = reinterpret_cast<unsigned long long*>(c->slab + o_rowbest);
   c->colbest = reinterpret_cast<unsigned long long*>(c->slab + o_colbest);
 
@@ -2135,15 +2141,16 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
   const int n = sb.n, f0 = sb.f0;
   NmsArgs a{};
   a.nmsmap = c->nmsmap + f0 * HW; a.cand = c->cand + f0 * HW; a.ncand = c->ncand + f0;
-  a.sort_scratch = c->sort_scratch + (c->sort_cap > NMS_LDS_KEYS ? (size_t)f0 * c->sort_cap : 0);
+  a.sort_scratch = c->sort_scratch + (size_t)f0 * c->sort_cap;
   a.sort_cap = c->sort_cap;
+  const bool chunked = !c->nms_one_workgroup;
+  a.aux = chunked ? c->nms_aux + (size_t)f0 * NMS_AUX_INTS : nullptr;
   a.H = c->H; a.W = c->W; a.r = c->cfg.nms_dist; a.border = c->cfg.border_remove; a.cap = c->cap;
   a.count = c->count + f0; a.xy = c->xy + (size_t)f0 * c->cap * 2; a.conf = c->conf + (size_t)f0 * c->cap;
   a.status = c->status;
   a.max_rounds = c->H * c->W;
   // enough workgroups that a typical frame (a few thousand candidates) has about one candidate
-  // per thread; a few launches back to back (each runs rounds while it makes progress), then the
-  // sort kernel finishes whatever is left
+  // per thread; the second launch normally finds nothing left to do
   const int G = c->nms_g > 0 ? c->nms_g : std::max(1, std::min(16, 512 / n));
   for (int pass = 0; pass < c->nms_passes; ++pass) {
     if (c->cfg.nms_dist == 4)
@@ -2151,7 +2158,22 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
     else
       hipLaunchKernelGGL(nms_rounds_kernel<0>, dim3(G, n), dim3(NMS_ROUNDS_THREADS), 0, sb.st, a);
   }
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), NMS_LDS_KEYS * sizeof(unsigned long long), sb.st, a);
+  if (chunked) {
+    // the leftovers of the round launches settled by one workgroup per frame, then slices of the candidate list sorted
+    // by one workgroup each and merged by rank (kernels_misc.h); nms_sort_kernel leaves at once unless a slice had
+    // more survivors than LDS holds
+    const bool big = HW > 400000;
+    const int GC = big ? 8 : 4;  // a frame of a few thousand candidates has this many slices
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(n), dim3(NMS_FINISH_THREADS), 0, sb.st, a);
+    if (big) {
+      hipLaunchKernelGGL(nms_chunk_sort_kernel<4096>, dim3(GC, n), dim3(1024), 4096 * sizeof(unsigned long long), sb.st, a);
+      hipLaunchKernelGGL(nms_merge_kernel<4096>, dim3(GC, n), dim3(1024), 4096 * sizeof(unsigned long long), sb.st, a);
+    } else {
+      hipLaunchKernelGGL(nms_chunk_sort_kernel<2048>, dim3(GC, n), dim3(1024), 2048 * sizeof(unsigned long long), sb.st, a);
+      hipLaunchKernelGGL(nms_merge_kernel<2048>, dim3(GC, n), dim3(1024), 2048 * sizeof(unsigned long long), sb.st, a);
+    }
+  }
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), chunked ? 0 : NMS_LDS_KEYS * sizeof(unsigned long long), sb.st, a);
 }
 
 static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
@@ -2351,6 +2373,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_WINOGRAD_GEN")) c->winograd_gen = atoi(e) == 1 ? 1 : 2;
     c->latency_tiles = !(pf & FPC_PLAN_NO_LATENCY_TILES);
     if (const char* e = getenv("FPC_LATENCY_TILES")) c->latency_tiles = atoi(e) != 0;
+    c->nms_one_workgroup = (pf & FPC_PLAN_NMS_ONE_WORKGROUP) != 0;
+    if (const char* e = getenv("FPC_NMS_CHUNKED")) c->nms_one_workgroup = atoi(e) == 0;
     if (cfg->min_sub_batch > 0) c->min_sub = cfg->min_sub_batch;
     if (cfg->nms_round_launches > 0) c->nms_passes = std::min(64, cfg->nms_round_launches);
     else if (cfg->nms_round_launches < 0) c->nms_passes = 0;
@@ -2981,7 +3005,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
           case OP_WBLOCK: k = g_wkinds[op->wkind].symbol; break;
           case OP_BF16: k = g_fkinds[op->fkind].symbol; break;
           case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
-          case OP_NMS: k = "nms_rounds_kernel+nms_sort_kernel"; break;
+          case OP_NMS: k = c->nms_one_workgroup ? "nms_rounds_kernel+nms_sort_kernel" : "nms_rounds_kernel+nms_finish_kernel+nms_chunk_sort_kernel+nms_merge_kernel"; break;
           case OP_DESC: k = "descriptor_kernel"; break;
           case OP_VCONV0: k = "vgg_conv0_kernel"; break;
           case OP_POOL2: k = "maxpool2_kernel"; break;

@@ -436,7 +436,12 @@ struct NmsArgs {
   float* conf;             // [B][cap]
   int32_t* status;         // [1] reserved (the round structure cannot fail to converge)
   int max_rounds;
+  int32_t* aux;            // [B][NMS_AUX_INTS]: [0] 1 = this frame takes nms_sort_kernel's one-workgroup path,
+                           // [2 + 2c], [3 + 2c] = offset and length of chunk c's sorted keys in sort_scratch
 };
+
+constexpr int NMS_MAX_CHUNKS = 8;    // slices of a frame's candidate list (nms_chunk_sort_kernel)
+constexpr int NMS_AUX_INTS = 2 + 2 * NMS_MAX_CHUNKS;
 
 constexpr int NMS_LDS_KEYS = 16384;  // 128 KiB of 64-bit keys
 
@@ -532,20 +537,150 @@ __device__ __forceinline__ void nms_run_rounds(uint32_t* map, uint32_t* cand, in
 }
 
 // Parallel rounds: grid = (G, B), the frame's candidates are dealt over G workgroups.  A
-// workgroup NEVER waits for another one: when a round decides nothing of its own it exits, and
-// whatever is still undecided is picked up by the next launch (the host issues a few of these
-// back to back) and finally by nms_sort_kernel, whose single workgroup per frame owns every
-// candidate and therefore always terminates.  No co-residency assumption anywhere.
+// workgroup NEVER waits for another one without bound: a wave whose candidates make no progress for
+// NMS_IDLE_ROUNDS rounds leaves, and whatever is still undecided is picked up by the next launch (the host
+// issues a few of these back to back) and finally by nms_finish_kernel, whose single workgroup per frame owns
+// every candidate and therefore always terminates.  No co-residency assumption anywhere.
+//
+// What a round costs decides everything here: the words of other workgroups' candidates are read past this XCD's
+// L2 (agent scope), 81 of them per window at r = 4, and the longest dependency chain of a frame is some tens of
+// rounds.  But only the undecided neighbours of HIGHER priority matter to a candidate (a kept neighbour always has
+// higher priority; lower ones and suppressed ones never influence it), at the densities of real maps one or two of
+// the 80: the first scan of a candidate records them -- up to eight window positions packed in 64 bits, in an LDS
+// slot of its own -- and every later round re-reads just those words.  A candidate with more than eight (dense maps)
+// or beyond the LDS slots (NMS_LIST_SLOTS per thread) is re-scanned every round, as round 1 of this build did for all.
 constexpr int NMS_ROUNDS_THREADS = 512;  // 8 waves: the unrolled window scan needs > 128 VGPRs
+constexpr int NMS_LIST_SLOTS = 16;       // LDS: 16 x 512 x 8 B = 64 KiB
+constexpr int NMS_IDLE_ROUNDS = 16;
+
+// First look at a candidate: the scan of nms_scan plus the list of what it has to wait for (0: too many to list).
+// FIRST: the scan of a launch's first round.  81 one-word requests per candidate is what bounds that round (the
+// vector memory pipeline, not latency), so there a window row is two 16-byte loads and a word -- plain loads, through
+// the caches: a word older than the truth only shows a decided neighbour as still undecided; it then goes on the list
+// and is re-read coherently in the next round.  Candidates within R of the frame's edge take the word-by-word scan.
+typedef uint32_t nms_u4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int R, bool FIRST>
+__device__ __forceinline__ void nms_scan_list(const uint32_t* map, int H, int W, uint32_t ci, uint32_t v, bool* kept_nb,
+                                              bool* wait, unsigned long long* list) {
+  constexpr int D = 2 * R + 1;
+  static_assert(D * D < 255, "window positions are stored in a byte");
+  const int y = ci / W, x = ci - y * W;
+  bool k = false;
+  int cnt = 0;
+  unsigned long long l = 0ull;
+  const bool inner = FIRST && R == 4 && y >= R && y < H - R && x >= R && x < W - R;
+#pragma unroll
+  for (int g = -R; g <= R; g += 3) {
+    uint32_t u[3 * D];
+    if (inner) {
+      if constexpr (R == 4) {
+#pragma unroll
+        for (int dy = g; dy < g + 3 && dy <= R; ++dy) {
+          const uint32_t* q = map + (y + dy) * W + x - R;
+          const nms_u4 a = *reinterpret_cast<const nms_u4*>(q), c = *reinterpret_cast<const nms_u4*>(q + 4);
+          uint32_t* o = u + (dy - g) * D;
+          o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = c.x; o[5] = c.y; o[6] = c.z; o[7] = c.w; o[8] = q[8];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int dy = g; dy < g + 3 && dy <= R; ++dy)
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          u[(dy - g) * D + dx + R] = ld_relaxed(map + (ok ? yy * W + xx : (int)ci));
+        }
+    }
+#pragma unroll
+    for (int dy = g; dy < g + 3 && dy <= R; ++dy)
+#pragma unroll
+      for (int dx = -R; dx <= R; ++dx) {
+        if (dy == 0 && dx == 0) continue;
+        const int yy = y + dy, xx = x + dx;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const uint32_t q = yy * W + xx, uu = u[(dy - g) * D + dx + R];
+        k |= ok && (uu & 0x80000000u);
+        if (ok && !(uu & 0x80000000u) && (uu > v || (uu == v && q < ci))) {
+          if (cnt < 8) l |= (unsigned long long)((dy + R) * D + (dx + R) + 1) << (8 * cnt);
+          ++cnt;
+        }
+      }
+  }
+  *kept_nb = k;
+  *wait = cnt > 0;
+  *list = cnt <= 8 ? l : 0ull;
+}
 
 template <int R>
 __global__ __launch_bounds__(NMS_ROUNDS_THREADS) void nms_rounds_kernel(const NmsArgs a) {
   const int b = blockIdx.y;
   const size_t HW = (size_t)a.H * a.W;
   const int n = a.ncand[b];
-  if (n <= 1 || (int)(blockIdx.x * NMS_ROUNDS_THREADS) >= n) return;  // n == 1 is settled by nms_sort_kernel
-  nms_run_rounds<R>(a.nmsmap + b * HW, a.cand + b * HW, n, blockIdx.x * NMS_ROUNDS_THREADS + threadIdx.x,
-                    gridDim.x * NMS_ROUNDS_THREADS, a.H, a.W, a.r, false);
+  if (n <= 1 || (int)(blockIdx.x * NMS_ROUNDS_THREADS) >= n) return;  // n == 1 is settled by nms_finish_kernel
+  uint32_t* map = a.nmsmap + b * HW;
+  uint32_t* cand = a.cand + b * HW;
+  const int first = blockIdx.x * NMS_ROUNDS_THREADS + threadIdx.x, stride = gridDim.x * NMS_ROUNDS_THREADS;
+  if constexpr (R == 0) {
+    nms_run_rounds<0>(map, cand, n, first, stride, a.H, a.W, a.r, false);
+  } else {
+    constexpr int D = 2 * R + 1;
+    __shared__ unsigned long long lists[NMS_LIST_SLOTS][NMS_ROUNDS_THREADS];  // slot k of a thread: its k-th candidate
+    const int W = a.W, H = a.H;
+#pragma unroll
+    for (int k = 0; k < NMS_LIST_SLOTS; ++k) lists[k][threadIdx.x] = 0ull;
+    int idle = 0;
+    for (int round = 0;; ++round) {  // waves run their rounds independently: nothing below is shared between threads
+      bool pending = false, progress = false;
+      int k = 0;
+      for (int i = first; i < n; i += stride, ++k) {
+        const uint32_t ci = cand[i];
+        if (ci & 0x80000000u) continue;  // decided earlier (only the owning thread writes cand[i])
+        bool kept_nb = false, wait = false;
+        unsigned long long l = k < NMS_LIST_SLOTS ? lists[k][threadIdx.x] : 0ull;
+        uint32_t v = 0;
+        if (l) {
+          unsigned long long keep_l = 0ull;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int code = (int)((l >> (8 * e)) & 0xffu);
+            if (code) {
+              const int dy = (code - 1) / D - R, dx = (code - 1) % D - R;
+              const uint32_t uu = ld_relaxed(map + (int)ci + dy * W + dx);
+              kept_nb |= (uu & 0x80000000u) != 0;
+              if (uu && !(uu & 0x80000000u)) keep_l |= (unsigned long long)code << (8 * e);
+            }
+          }
+          wait = keep_l != 0ull;
+          if (keep_l != l) {
+            lists[k][threadIdx.x] = keep_l;
+            if (!kept_nb && wait) progress = true;  // a neighbour was suppressed: the chain moves
+          }
+          if (!kept_nb && !wait) v = ld_relaxed(map + ci);
+        } else {
+          v = ld_relaxed(map + ci);
+          if (round == 0) nms_scan_list<R, true>(map, H, W, ci, v, &kept_nb, &wait, &l);
+          else nms_scan_list<R, false>(map, H, W, ci, v, &kept_nb, &wait, &l);
+          if (k < NMS_LIST_SLOTS && !kept_nb && wait) lists[k][threadIdx.x] = l;
+        }
+        if (kept_nb) {
+          st_relaxed(map + ci, 0u);
+          cand[i] = ci | 0x80000000u;
+          progress = true;
+        } else if (!wait) {
+          st_relaxed(map + ci, v | 0x80000000u);
+          cand[i] = ci | 0x80000000u;
+          progress = true;
+        } else {
+          pending = true;
+        }
+      }
+      if (!__any(pending)) break;                       // nothing of this wave's left
+      idle = __any(progress) ? 0 : idle + 1;
+      if (idle >= NMS_IDLE_ROUNDS) break;               // stuck on other workgroups' candidates: let the launch end
+    }
+  }
 }
 
 // Survivors inside the border -> sort -> outputs.  One workgroup per frame.
@@ -554,7 +689,7 @@ __global__ __launch_bounds__(NMS_ROUNDS_THREADS) void nms_rounds_kernel(const Nm
 template <typename KeyPtr>
 __device__ __forceinline__ void nms_sort_body(const NmsArgs& a, KeyPtr keys, int P, int K, int n, const uint32_t* map,
                                               const uint32_t* cand, int* s_count) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;  // nms_sort_kernel's grid is (B)
   const int H = a.H, W = a.W, bw = a.border;
   for (int i = tid; i < P; i += 1024) keys[i] = 0ull;
   __syncthreads();
@@ -601,10 +736,244 @@ __device__ __forceinline__ void nms_sort_body(const NmsArgs& a, KeyPtr keys, int
   }
 }
 
+// The usual case, after nms_finish_kernel has settled what the round launches left: the frame's candidate list in
+// at most NMS_MAX_CHUNKS slices (SLICE candidates each, longer ones when the frame has more than NMS_MAX_CHUNKS x
+// SLICE), one workgroup per slice (grid (NMS_MAX_CHUNKS, B)).  Survivors of the slice inside the border -> LDS ->
+// bitonic sort, descending -> a run of sort_scratch claimed with one atomicAdd on count[b] (which thereby ends up as
+// the frame's K).  nms_merge_kernel then places every key at (its index in its run) + (the number of larger keys in
+// every other run): keys are unique, so that is its position in the frame's order.  A slice with more than SLICE
+// survivors (LDS holds no more) raises aux[0]: nms_sort_kernel's single workgroup then redoes that frame.
+__device__ __forceinline__ void nms_slices(int n, int SLICE, int* S, int* C) {
+  const int s = n <= NMS_MAX_CHUNKS * SLICE ? SLICE : ((n + NMS_MAX_CHUNKS - 1) / NMS_MAX_CHUNKS + 1023) / 1024 * 1024;
+  *S = s;
+  *C = (n + s - 1) / s;
+}
+
+__device__ __forceinline__ unsigned long long nms_key(uint32_t state, uint32_t ci) {
+  return ((unsigned long long)(state & 0x7fffffffu) << 32) | (0xffffffffu - ci);
+}
+
+// One workgroup per frame owns all of the frame's candidates, so running rounds to completion cannot wait on anybody:
+// the few candidates at the ends of long chains that the parallel launches gave up on are decided here -- collected
+// in LDS first, so that a round costs their scans only, not a pass over the frame's whole candidate list.
+constexpr int NMS_FINISH_LIST = 4096;
+constexpr int NMS_FINISH_THREADS = 512;  // the unrolled window scan needs > 128 VGPRs
+
+template <int R>
+__device__ __forceinline__ void nms_finish_listed(uint32_t* map, uint32_t* cand, const int* list, int m, int H, int W,
+                                                  int r) {
+  while (true) {
+    int pending = 0;
+    for (int j = threadIdx.x; j < m; j += NMS_FINISH_THREADS) {
+      const int i = list[j];
+      const uint32_t ci = cand[i];
+      if (ci & 0x80000000u) continue;
+      const uint32_t v = ld_relaxed(map + ci);
+      bool kept_nb, wait;
+      nms_scan<R>(map, H, W, r, ci, v, &kept_nb, &wait);
+      if (kept_nb) {
+        st_relaxed(map + ci, 0u);
+        cand[i] = ci | 0x80000000u;
+      } else if (!wait) {
+        st_relaxed(map + ci, v | 0x80000000u);
+        cand[i] = ci | 0x80000000u;
+      } else {
+        pending = 1;
+      }
+    }
+    if (!__syncthreads_or(pending)) break;  // (the barrier also orders this round's stores before the next round's loads)
+  }
+}
+
+__global__ __launch_bounds__(NMS_FINISH_THREADS) void nms_finish_kernel(const NmsArgs a) {
+  __shared__ int s_list[NMS_FINISH_LIST];
+  __shared__ int s_n;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = a.ncand[b];
+  uint32_t* wmap = a.nmsmap + (size_t)b * a.H * a.W;
+  uint32_t* wcand = a.cand + (size_t)b * a.H * a.W;
+  if (tid == 0) {
+    a.count[b] = 0;  // nms_chunk_sort_kernel's allocation counter
+    a.aux[(size_t)b * NMS_AUX_INTS] = 0;
+    s_n = 0;
+  }
+  if (n == 1) {  // nms.py:23-25: a single candidate is returned as is
+    if (tid == 0) {
+      wmap[wcand[0] & 0x7fffffffu] |= 0x80000000u;
+      wcand[0] |= 0x80000000u;
+    }
+    return;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += NMS_FINISH_THREADS)
+    if (!(wcand[i] & 0x80000000u)) {
+      const int j = atomicAdd(&s_n, 1);
+      if (j < NMS_FINISH_LIST) s_list[j] = i;
+    }
+  __syncthreads();
+  const int m = s_n;
+  if (m == 0) return;
+  if (m > NMS_FINISH_LIST) nms_run_rounds<0>(wmap, wcand, n, tid, NMS_FINISH_THREADS, a.H, a.W, a.r, true);
+  else if (a.r == 4) nms_finish_listed<4>(wmap, wcand, s_list, m, a.H, a.W, a.r);
+  else nms_finish_listed<0>(wmap, wcand, s_list, m, a.H, a.W, a.r);
+}
+
+template <int SLICE>
+__global__ __launch_bounds__(1024) void nms_chunk_sort_kernel(const NmsArgs a) {
+  static_assert(SLICE >= 2048 && SLICE <= 16384 && (SLICE & (SLICE - 1)) == 0, "slice: a power of two that LDS holds");
+  extern __shared__ unsigned long long keys[];  // [SLICE]
+  __shared__ int s_count, s_base;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int n = a.ncand[b];
+  if (n <= 0) return;
+  int32_t* aux = a.aux + (size_t)b * NMS_AUX_INTS;
+  int S, C;
+  nms_slices(n, SLICE, &S, &C);
+  const int H = a.H, W = a.W, bw = a.border;
+  const uint32_t* map = a.nmsmap + (size_t)b * H * W;
+  const uint32_t* cand = a.cand + (size_t)b * H * W;
+  for (int c = blockIdx.x; c < C; c += gridDim.x) {
+    __syncthreads();  // the previous slice's keys have left LDS
+    if (tid == 0) s_count = 0;
+#pragma unroll
+    for (int it = 0; it < SLICE / 1024; ++it) keys[it * 1024 + tid] = 0ull;
+    __syncthreads();
+    for (int i0 = c * S; i0 < (c + 1) * S; i0 += 1024) {
+      const int i = i0 + tid;
+      const uint32_t ci = i < n ? cand[i] & 0x7fffffffu : 0u;
+      const int y = ci / W, x = ci - y * W;
+      const uint32_t u = i < n ? map[ci] : 0u;
+      const bool keep = (u & 0x80000000u) && x >= bw && x < W - bw && y >= bw && y < H - bw;
+      const unsigned long long mask = __ballot(keep);
+      if (mask) {
+        int base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&s_count, __popcll(mask));
+        base = __shfl(base, 0);
+        const int at = base + __popcll(mask & ((1ull << (tid & 63)) - 1));
+        if (keep && at < SLICE) keys[at] = nms_key(u, ci);
+      }
+    }
+    __syncthreads();
+    if (s_count > SLICE) {  // uniform
+      if (tid == 0) aux[0] = 1;
+      return;
+    }
+    const int K = s_count;
+    int P = 128;
+    while (P < K) P <<= 1;
+    // bitonic sort, descending.  Pair t of a pass with distance j is elements i(t) and i(t) + j; for j <= 64 the pairs
+    // t = 64 w .. 64 w + 63 of a wave lie in the same 128 elements in every such pass, so only the passes with
+    // j >= 128 need the workgroup barrier.
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        if (j >= 128) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int t = tid; t < (P >> 1); t += 1024) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+          const unsigned long long ki = keys[i], kl = keys[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? ki < kl : ki > kl) {
+            keys[i] = kl;
+            keys[l] = ki;
+          }
+        }
+        if (j >= 128) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    __syncthreads();
+    if (tid == 0) {
+      const int base = K ? atomicAdd(&a.count[b], K) : 0;
+      s_base = base;
+      aux[2 + 2 * c] = base;
+      aux[3 + 2 * c] = K;
+    }
+    __syncthreads();
+    unsigned long long* run = a.sort_scratch + (size_t)b * a.sort_cap + s_base;
+    for (int i = tid; i < K; i += 1024) run[i] = keys[i];
+  }
+}
+
+// grid (G, B): a workgroup ranks the keys of runs blockIdx.x, + G, ... against the other runs and writes the outputs.
+// The searches are what this kernel costs, and as one-key requests to L2 they were bound by the request rate of the
+// vector memory pipeline (HD: 82 M of them per 64 frames): each other run is staged in LDS with coalesced loads and
+// searched there; a thread keeps its SLICE / 1024 keys and their ranks in registers.
+template <int SLICE>
+__global__ __launch_bounds__(1024) void nms_merge_kernel(const NmsArgs a) {
+  constexpr int E = SLICE / 1024;
+  extern __shared__ unsigned long long other[];  // [SLICE]
+  __shared__ int s_off[NMS_MAX_CHUNKS], s_cnt[NMS_MAX_CHUNKS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int n = a.ncand[b];
+  const int32_t* aux = a.aux + (size_t)b * NMS_AUX_INTS;
+  if (n > 0 && aux[0]) return;  // nms_sort_kernel redoes this frame
+  int S = 0, C = 0;
+  if (n > 0) nms_slices(n, SLICE, &S, &C);
+  if ((int)blockIdx.x >= C && blockIdx.x > 0) return;
+  for (int q = tid; q < C; q += 1024) {
+    s_off[q] = aux[2 + 2 * q];
+    s_cnt[q] = aux[3 + 2 * q];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {  // count[b] was the allocation counter = K; the caller sees min(K, cap)
+    int K = 0;
+    for (int q = 0; q < C; ++q) K += s_cnt[q];
+    a.count[b] = K < a.cap ? K : a.cap;
+  }
+  const int W = a.W;
+  const unsigned long long* base = a.sort_scratch + (size_t)b * a.sort_cap;
+  for (int c = blockIdx.x; c < C; c += gridDim.x) {
+    const int Kc = s_cnt[c];
+    if (Kc == 0) continue;
+    unsigned long long key[E];
+    int pos[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int e = tid + u * 1024;
+      key[u] = e < Kc ? base[s_off[c] + e] : ~0ull;  // (a key that is larger than every real one: its searches end at 0)
+      pos[u] = e;
+    }
+    for (int q = 0; q < C; ++q) {
+      const int m = s_cnt[q];
+      if (q == c || m == 0) continue;
+      __syncthreads();  // the previous run has been searched
+      for (int i = tid; i < m; i += 1024) other[i] = base[s_off[q] + i];
+      __syncthreads();
+      // number of keys of the (descending) run larger than `key` = the largest idx with other[idx - 1] > key
+      int lo[E];
+#pragma unroll
+      for (int u = 0; u < E; ++u) lo[u] = 0;
+#pragma unroll 1
+      for (int s = SLICE; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+          const int idx = lo[u] + s;
+          if (idx <= m && other[idx - 1] > key[u]) lo[u] = idx;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < E; ++u) pos[u] += lo[u];
+    }
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int e = tid + u * 1024;
+      if (e < Kc && pos[u] < a.cap) {
+        const uint32_t ci = 0xffffffffu - (uint32_t)(key[u] & 0xffffffffu);
+        const int y = ci / W, x = ci - y * W;
+        a.xy[((size_t)b * a.cap + pos[u]) * 2 + 0] = x;
+        a.xy[((size_t)b * a.cap + pos[u]) * 2 + 1] = y;
+        a.conf[(size_t)b * a.cap + pos[u]] = nms_state_conf((uint32_t)(key[u] >> 32));
+      }
+    }
+  }
+}
+
+// The general path, one workgroup per frame; frames the two kernels above have dealt with are skipped
+// (a.aux == nullptr: every frame is done here).
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
   extern __shared__ unsigned long long keys_lds[];
   __shared__ int s_count, s_total;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (a.aux && (a.ncand[b] <= 0 || !a.aux[(size_t)b * NMS_AUX_INTS])) return;  // nms_merge_kernel has done the frame
   const int H = a.H, W = a.W;
   const uint32_t* map = a.nmsmap + (size_t)b * H * W;
   const uint32_t* cand = a.cand + (size_t)b * H * W;
@@ -638,7 +1007,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
   const int K = s_total;
   int P = 1;
   while (P < K) P <<= 1;
-  if (P <= NMS_LDS_KEYS)
+  if (!a.aux && P <= NMS_LDS_KEYS)  // (as the chunked path's fallback the kernel is launched without dynamic LDS)
     nms_sort_body(a, keys_lds, P, K, n, map, cand, &s_count);
   else  // more survivors than LDS holds (large frames): same code on a global scratch buffer
     nms_sort_body(a, a.sort_scratch + (size_t)b * a.sort_cap, P, K, n, map, cand, &s_count);

@@ -98,7 +98,8 @@ enum {
   FPC_PLAN_NO_PERSISTENT_GRID = 1 << 8,    /* one workgroup per tile in the Winograd kernels            (FPC_PERSIST_MIN=0)  */
   FPC_PLAN_LAYER1_TILE_8x16 = 1 << 9,      /* direct layer1 blocks on 8x16 instead of 16x16 tiles       (FPC_L1_T816=1)      */
   FPC_PLAN_WINOGRAD_GEN1 = 1 << 10,        /* round-1 Winograd kernel for the 64- / 128-channel layers  (FPC_WINOGRAD_GEN=1) */
-  FPC_PLAN_NO_LATENCY_TILES = 1 << 11      /* calls of a few frames keep the 8x16 tiles of the batch plan (FPC_LATENCY_TILES=0) */
+  FPC_PLAN_NO_LATENCY_TILES = 1 << 11,     /* calls of a few frames keep the 8x16 tiles of the batch plan (FPC_LATENCY_TILES=0) */
+  FPC_PLAN_NMS_ONE_WORKGROUP = 1 << 12     /* survivors of a frame sorted by one workgroup, not in slices (FPC_NMS_CHUNKED=0)   */
 };
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']

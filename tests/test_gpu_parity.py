@@ -479,6 +479,8 @@ def test_packed_weight_blob_round_trip(torch_gpu):
     {"FPC_STREAMS": "3", "FPC_NMS_PASSES": "0"},             # three sub-batches; NMS finished by the sort kernel alone
     {"FPC_SPLIT_HEADS": "1"},                                # detector head + NMS on a side stream of its own
     {"FPC_NMS_ASIDE": "0"},                                  # NMS in line instead of beside the descriptor head
+    {"FPC_NMS_CHUNKED": "0"},                                # survivors sorted by one workgroup per frame (round 1's kernel)
+    {"FPC_NMS_CHUNKED": "0", "FPC_NMS_PASSES": "0"},         # ... which then also runs every round itself
     {"FPC_XCD_ORDER": "0", "FPC_MIN_SUB": "4"},              # plain tile order in the Winograd kernel; sub-batches of 4
     {"FPC_PERSIST_MIN": "0"},                                # Winograd kernel with one workgroup per tile
     {"FPC_WINOGRAD_IN1": "0"},                               # layer_in.1 as one fused direct block (no conv-only Winograd)

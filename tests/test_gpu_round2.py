@@ -161,6 +161,35 @@ def test_threshold_zero_and_exact_zeros_in_the_map(torch_gpu):
         assert ei.value.code == -1
 
 
+def test_get_points_across_the_slices_of_the_candidate_list(torch_gpu):
+    """The survivors of a frame are sorted in slices of its candidate list by several workgroups and merged by rank
+    (nms_chunk_sort_kernel / nms_merge_kernel): every regime of that path against the oracle, bit for bit, on VGA maps --
+    a typical density (4 slices), just above 8 slices' worth (longer slices), every pixel a candidate (38 400 per
+    slice), and nms_dist = 0 on a dense map (more survivors in a slice than LDS holds: the one-workgroup kernel redoes
+    the frame); the same frames through the one-workgroup plan must agree too."""
+    torch = torch_gpu
+    oracle = oracle_mod()
+    h, w = 480, 640
+    rng = np.random.Generator(np.random.PCG64(23))
+    u = rng.uniform(0.0, 1.0, (h, w)).astype(np.float32)
+    cases = [(np.where(u > 0.978, u, 0.0), 0.015, 4, 4),          # ~6 800 candidates
+             (np.where(u > 0.94, u, 0.0), 0.015, 4, 4),           # ~18 400 > 8 x 2048
+             (np.maximum(u, 0.02), 0.015, 4, 4),                  # all 307 200
+             (np.where(u > 0.9, u, 0.0), 0.015, 0, 2),            # ~30 700 candidates, all of them survive
+             (np.where(u > 0.978, (u * 8).astype(np.int32) / 8.0, 0.0), 0.015, 4, 0)]   # ties everywhere
+    for i, (m, thr, r, bw) in enumerate(cases):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        oxs, oys, oconf, oncand = oracle.get_points(m, thr, r, bw)
+        for flags in ([], ["nms_one_workgroup"]):
+            e = engine(h, w, descriptor_enabled=False, nms_dist=r, border_remove=bw, conf_thresh=thr, plan_flags=flags)
+            xy, conf, _, ncand = e.get_points(torch.from_numpy(m[None]))[0]
+            assert ncand == oncand, (i, flags)
+            np.testing.assert_array_equal(xy[:, 0], oxs, err_msg=str((i, flags)))
+            np.testing.assert_array_equal(xy[:, 1], oys, err_msg=str((i, flags)))
+            np.testing.assert_array_equal(conf, oconf, err_msg=str((i, flags)))
+            e.close()
+
+
 def test_max_keypoints_keeps_the_most_confident_points(torch_gpu):
     """fpc_config.max_keypoints below the kept count: the frame stays readable and holds the `cap` best points
     (round 1 returned FPC_E_CAPACITY for such a frame)."""
@@ -197,7 +226,7 @@ def test_plan_fields_of_fpc_config(torch_gpu, golden_dir):
     ref = base.detect(frames)
     _, _, lref = base.forward(frames)
     plans = [dict(num_streams=1), dict(num_streams=3, min_sub_batch=2), dict(nms_round_launches=-1),
-             dict(nms_round_launches=5), dict(plan_flags=["no_winograd"]), dict(plan_flags=["no_fused_blocks"]),
+             dict(nms_round_launches=5), dict(plan_flags=["nms_one_workgroup"]), dict(plan_flags=["no_winograd"]), dict(plan_flags=["no_fused_blocks"]),
              dict(plan_flags=["no_winograd_detector", "no_winograd_layer_in1", "no_xcd_order"]),
              dict(plan_flags=["no_fused_stem_pool", "nms_in_line"]), dict(plan_flags=["split_heads", "no_persistent_grid"]),
              dict(plan_flags=["no_winograd", "layer1_tile_8x16"]), dict(plan_flags=sum(_lib.PLAN_FLAGS.values()) & ~(1 << 6))]
@@ -209,7 +238,7 @@ def test_plan_fields_of_fpc_config(torch_gpu, golden_dir):
         assert float((lg - lref).abs().max()) < ATOL, kw
         # a call below 2 * min_sub_batch frames takes the latency plan (layer_in.1 as the fused direct block instead of
         # the Winograd launches): min_sub_batch = 2 moves these 6 frames to the other side, i.e. to other arithmetic
-        same_arith = not kw.get("plan_flags") and not kw.get("min_sub_batch")
+        same_arith = kw.get("plan_flags", []) in ([], ["nms_one_workgroup"]) and not kw.get("min_sub_batch")
         for (xy, conf, d, nc), (rxy, rconf, rd, rnc) in zip(got, ref):
             if same_arith:      # stream / NMS-launch plans do not touch the arithmetic: bit-equal
                 assert nc == rnc
