@@ -5,8 +5,8 @@
 // shortcut, vectorised epilogue -- on v_mfma_f32_32x32x16_bf16 (16 channels per instruction: lane
 // (row = l & 31, half = l >> 5) supplies channels 8*half .. 8*half+7 as one 16-byte fragment).
 // Tensors are bf16 NHWC with the channel count padded to a multiple of 16 where they feed a GEMM's K.
-// The first block of the net reads the (fp32) stem output, the last detector / descriptor blocks write
-// fp32 so that the post-processing kernels are the same as in the fp32 path.
+// The last detector / descriptor blocks write fp32 so that the post-processing kernels are the same as in the
+// fp32 path.
 #pragma once
 #include "conv_mfma.h"
 
@@ -27,8 +27,9 @@ __device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
 }
 
 struct BlockBfArgs {
-  const void* x;         // input NHWC: bf16 (or fp32 when in_f32), offset to its first channel
+  const void* x;         // input NHWC: bf16 (fp32 when in_f32: the split-operand kernels of block_x3.h only), offset to its first channel
   int csx, nchunk;       // pixel stride in ELEMENTS, Cin_pad / KC
+  unsigned x_bytes;      // block_bf16_kernel: bytes of the input tensor from x on (buffer descriptor range)
   int H, W;
   int in_f32;
   const uint4* w1;       // 3x3 fragments: step = (chunk*ntaps + tap)*K16 + k16, [step][nb][64] uint4 (+2 steps)
@@ -96,33 +97,41 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
 
   const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
-  uint4 stage[ITER];
+  // The halo chunk through a buffer descriptor: a position outside the frame (or a chunk past the last one) gets an
+  // offset beyond the descriptor's range and comes back as zeros from the hardware's bounds check.  No branch anywhere
+  // between a request and its use: around a block boundary the compiler waits for EVERY outstanding load (it did, once
+  // per chunk, for the next chunk's halo right after requesting it and for the fragments in flight: PMC showed the
+  // waves of this kernel parked 61 % of the time).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 stage[ITER];   // (vector values: an array of uint4 structs is not promoted to registers)
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const unsigned xbase = (unsigned)(((b * a.H + iy0) * a.W + ix0) * a.csx * 2);   // mod 2^32; exact for in-frame pixels
   auto load_chunk = [&](int chunk) {
+    const int wlim = chunk < a.nchunk ? a.W : 0;   // nothing is in range past the last chunk
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int e = tid + i * NT;
       const int pix = e / KC8, c8 = e - pix * KC8;
       const int hy = pix / HW, hx = pix - hy * HW;
       const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c8 * 8 : 0;
-      uint4 v;
-      if (a.in_f32) {
-        const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + off);
-        v = pack8(p[0], p[1]);
-      } else {
-        v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + off);
-      }
-      if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-      stage[i] = v;
+      const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)wlim) & (hy < HH);   // (& not &&: no branch)
+      unsigned off = xbase + (unsigned)(((hy * a.W + hx) * a.csx + chunk * KC + c8 * 8) * 2);
+      asm volatile("" : "+v"(off));   // computed for every lane: as a conditional the compiler branches around it
+      stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : 0xfffffff0u), 0, 0));
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int e = tid + i * NT;
-      const int pix = e / KC8, c8 = e - pix * KC8;
-      if (NV % NT == 0 || e < NV) lds16[pix * ROW16 + c8] = stage[i];
+      int pix = e / KC8, c8 = e - pix * KC8;
+      if (NV % NT != 0) {   // elements past the halo go to the skew column of its last pixel (never read)
+        const bool in = e < NV;
+        pix = in ? pix : HH * HW - 1;
+        c8 = in ? c8 : KC8;
+      }
+      *reinterpret_cast<u32x4*>(&lds16[pix * ROW16 + c8]) = stage[i];
     }
   };
 
@@ -137,6 +146,58 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   // ---------------------------------------------------------------- phase 1: KxK conv
   load_chunk(0);
   uint4 b0[NB], b1[NB];
+  constexpr int NS = 9 * K16;                                            // steps of a chunk of a 3x3 convolution
+  constexpr int D = S == 2 ? 3 : NS % 6 == 0 ? 6 : NS % 5 == 0 ? 5 : NS % 4 == 0 ? 4 : 3;   // fragment ring: D steps ahead (the stride-2 halo needs the registers)
+  static_assert(NS % D == 0, "the ring position of a step must not depend on the chunk");
+  if (a.ntaps == 9) {
+    // Two steps of fragments ahead -- 256 MFMA cycles of this wave -- do not cover an L2 round trip, and the LDS read of a
+    // step's pixels sat right in front of its MFMAs.  Here the chunk's 9 x K16 steps are unrolled, fragments run D steps
+    // ahead in a register ring whose slots are compile-time names (through a buffer descriptor too: the lane's offset in
+    // a VGPR that never changes, the step in the scalar offset, and a request past the last step returns zeros), and a
+    // step's pixels are read while the previous step's MFMAs run.
+    u32x4 ring[D][NB];
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(a.w1), 0, (int)((unsigned)(a.nchunk * NS + 2) * (unsigned)(stepstride * 16)), 0x00020000);
+    const unsigned wlane = (unsigned)((wn * NB) * 64 + lane) * 16u;
+    int wstep = 0;   // (scalar) byte offset of the next step to request
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        ring[d][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + nb * 1024), wstep, 0));
+      wstep += stepstride * 16;
+    }
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      FPC_LDS_BARRIER();   // the previous chunk's pixels have been read
+      store_chunk();
+      FPC_LDS_BARRIER();
+      load_chunk(chunk + 1);
+      u32x4 av[MB], an[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + a.tapoff16[0]]);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) {
+          const int toff = a.tapoff16[(st + 1) / K16];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + toff + ((st + 1) % K16) * 2]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
+                                                                  __builtin_bit_cast(bf16x8, ring[st % D][nb]), acc[mb][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          ring[st % D][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + nb * 1024), wstep, 0));
+        wstep += stepstride * 16;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
+        __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the ring's requests to just before their use)
+      }
+    }
+  } else {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) b0[nb] = wp[nb * 64];
   wp += stepstride;
@@ -174,16 +235,44 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       }
     }
   }
+  }
 
   if (!a.conv_only) {
     // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (bf16)
+    // phase 2's fragments run D2 steps ahead in a ring of compile-time slots, like phase 1's; the first D2 steps -- and
+    // the first D2 steps of the projection's pixels -- are requested before h is written and land behind that.
+    constexpr int KH = CMIDP / 16, D2 = 4;
+    uint4 ring[D2][NB];
     const uint4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
+    int left = a.k16_h + a.k16_x + 1;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b0[nb] = wq[nb * 64];
-    wq += stepstride;
+    for (int d = 0; d < D2; ++d) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b1[nb] = wq[nb * 64];
-    wq += stepstride;
+      for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wq[nb * 64];
+      wq += left > 0 ? stepstride : 0;
+      --left;
+    }
+    size_t xoff[MB];
+    uint4 xr[D2][MB];
+    auto load_a = [&](int mb, int k) {
+      return *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + xoff[mb] + k * 16);
+    };
+    if (a.k16_x > 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        int m = (wm * MB + mb) * 32 + l31;
+        m = m < TH * TW ? m : TH * TW - 1;
+        const int py = m / TW, px = m - py * TW;
+        int y = (ty * TH + py) * S, x = (tx * TW + px) * S;
+        y = y < a.H ? y : a.H - 1;
+        x = x < a.W ? x : a.W - 1;
+        xoff[mb] = ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 8;
+      }
+#pragma unroll
+      for (int d = 0; d < D2; ++d)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) xr[d][mb] = load_a(mb, d < a.k16_x ? d : a.k16_x - 1);
+    }
     FPC_LDS_BARRIER();
     {
       bf16_t* hl = reinterpret_cast<bf16_t*>(lds16);
@@ -207,71 +296,50 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     int hbase[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH16 + half;
-    for (int k = 0; k < a.k16_h; ++k) {
-      uint4 b2[NB];
+    {
+      uint4 av[MB], an[MB];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
-      wq += stepstride;
-      __builtin_amdgcn_sched_barrier(0);
-      uint4 av[MB];
+      for (int mb = 0; mb < MB; ++mb) av[mb] = lds16[hbase[mb]];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) av[mb] = lds16[hbase[mb] + k * 2];
+      for (int k = 0; k < KH; ++k) {
+        if (k + 1 < KH) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
-                                                                __builtin_bit_cast(bf16x8, b0[nb]), acc[mb][nb], 0, 0, 0);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        b0[nb] = b1[nb];
-        b1[nb] = b2[nb];
-      }
-    }
-    // -------------------------------------------------------------- phase 2b: K over x (projection)
-    if (a.k16_x > 0) {
-      size_t xoff[MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        int m = (wm * MB + mb) * 32 + l31;
-        m = m < TH * TW ? m : TH * TW - 1;
-        const int py = m / TW, px = m - py * TW;
-        int y = (ty * TH + py) * S, x = (tx * TW + px) * S;
-        y = y < a.H ? y : a.H - 1;
-        x = x < a.W ? x : a.W - 1;
-        xoff[mb] = ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 8;
-      }
-      auto load_a = [&](int mb, int k) {
-        if (a.in_f32) {
-          const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + xoff[mb] + k * 16);
-          return pack8(p[0], p[1]);
+          for (int mb = 0; mb < MB; ++mb) an[mb] = lds16[hbase[mb] + (k + 1) * 2];
         }
-        return *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + xoff[mb] + k * 16);
-      };
-      uint4 an[MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) an[mb] = load_a(mb, 0);
-      for (int k = 0; k < a.k16_x; ++k) {
-        uint4 b2[NB], av[MB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b2[nb] = wq[nb * 64];
-        wq += stepstride;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          av[mb] = an[mb];
-          an[mb] = load_a(mb, k + 1 < a.k16_x ? k + 1 : k);
-        }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
-                                                                  __builtin_bit_cast(bf16x8, b0[nb]), acc[mb][nb], 0, 0, 0);
+                                                                  __builtin_bit_cast(bf16x8, ring[k % D2][nb]), acc[mb][nb], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          b0[nb] = b1[nb];
-          b1[nb] = b2[nb];
+        for (int nb = 0; nb < NB; ++nb) ring[k % D2][nb] = wq[nb * 64];
+        wq += left > 0 ? stepstride : 0;
+        --left;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // -------------------------------------------------------------- phase 2b: K over x (projection), D2 steps per trip
+    for (int k0 = 0; k0 < a.k16_x; k0 += D2) {
+#pragma unroll
+      for (int j = 0; j < D2; ++j) {
+        if (k0 + j < a.k16_x) {  // (k16_x is a multiple of 4 for every layer of this network; uniform)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xr[j][mb]),
+                                                                    __builtin_bit_cast(bf16x8, ring[(KH + j) % D2][nb]), acc[mb][nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) ring[(KH + j) % D2][nb] = wq[nb * 64];
+          wq += left > 0 ? stepstride : 0;
+          --left;
+          const int kn = k0 + j + D2;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) xr[j][mb] = load_a(mb, kn < a.k16_x ? kn : a.k16_x - 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -304,7 +372,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     // identity shortcut (same geometry as the output, stride 1; bf16, the only fp32 input feeds a projection block):
     // the loads are issued BEFORE the barrier, in the registers the dead accumulators free
     uint4 idq[EIT];
-    if (ident && !a.in_f32) {
+    if (ident) {
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
         const int e = tid + i * NT;
@@ -325,16 +393,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
         float4 v0 = ol4[m * ROWO4 + c8 * 2], v1 = ol4[m * ROWO4 + c8 * 2 + 1];
         if (ident) {
-          if (a.in_f32) {
-            const size_t ioff = ((size_t)(b * a.H + y) * a.W + x) * a.csx + c8 * 8;
-            const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + ioff);
-            v0.x += p[0].x; v0.y += p[0].y; v0.z += p[0].z; v0.w += p[0].w;
-            v1.x += p[1].x; v1.y += p[1].y; v1.z += p[1].z; v1.w += p[1].w;
-          } else {
-            const uint4 q = idq[i];
-            v0.x += bf2f(q.x & 0xffff); v0.y += bf2f(q.x >> 16); v0.z += bf2f(q.y & 0xffff); v0.w += bf2f(q.y >> 16);
-            v1.x += bf2f(q.z & 0xffff); v1.y += bf2f(q.z >> 16); v1.z += bf2f(q.w & 0xffff); v1.w += bf2f(q.w >> 16);
-          }
+          const uint4 q = idq[i];
+          v0.x += bf2f(q.x & 0xffff); v0.y += bf2f(q.x >> 16); v0.z += bf2f(q.y & 0xffff); v0.w += bf2f(q.y >> 16);
+          v1.x += bf2f(q.z & 0xffff); v1.y += bf2f(q.z >> 16); v1.z += bf2f(q.w & 0xffff); v1.w += bf2f(q.w >> 16);
         }
         if (!a.norelu) {
           v0.x = v0.x > 0.f ? v0.x : 0.f; v0.y = v0.y > 0.f ? v0.y : 0.f; v0.z = v0.z > 0.f ? v0.z : 0.f; v0.w = v0.w > 0.f ? v0.w : 0.f;

@@ -423,6 +423,7 @@ struct StemX3Args {
   const float* bias;    // [64]
   float* out;           // [B,Hp,Wp,64], zero-filled
   int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
+  int frames;           // stem_pool_bf16_kernel (persistent grid): frames of the launch
   int* range_flag;      // NP == 2: raised when an output leaves fp16's range
 #ifdef FPC_DIAG
   unsigned long long* stamps;
@@ -576,6 +577,195 @@ __global__ __launch_bounds__(256) void stem_pool_x3_kernel(const StemX3Args a) {
     if (nb == 0) { FPC_STAMP(3) } else { FPC_STAMP(5) }
     stem_pool_emit(lds, a.out, b, ty, tx, nb, a.Ho, a.Wo, a.Hp, a.Wp, tid, NP == 2 ? a.range_flag : nullptr);
     if (nb == 0) { FPC_STAMP(4) } else { FPC_STAMP(6) }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// FPC_BF16's stem: 7x7/2 convolution + bias + ReLU + 3x3/2 max-pool, bf16 in, bf16 out, every pooled value written
+// ONCE.  stem_pool_x3_kernel completes the pooling windows that straddle two tiles with atomicMax on an fp32 buffer:
+// at 64 HD frames that is a 0.94 GB memset, a read-modify-write of the same bytes, and the next layer reading 4-byte
+// values (2.5 GB of HBM traffic per launch by the PMC counters, for 0.7 GB of frames in and 0.47 GB of bf16 out).
+// Here a tile is 8 x 8 POOLED pixels and the 17 x 17 convolution outputs under them (one row above and one column
+// left of the 16 x 16 the old tile had: 13 % more MFMA work on a kernel whose matrix cores were 18 % busy), as ten
+// 32-pixel blocks on five waves.  A one-tile workgroup of this kind spends its life waiting -- for its input window,
+// then eleven times for weight fragments from L2 -- so the grid is persistent (two workgroups per CU, each XCD walking
+// a contiguous range of tiles so that neighbours share their input halos in one L2): the weight fragments are staged
+// in LDS once per workgroup, and the next tile's input window is requested before the current tile's K loop and
+// lands in registers behind it.  K layout and weight fragments are stem_pool_x3_kernel's.
+// ---------------------------------------------------------------------------------
+constexpr int STEMB_C = 17;                        // convolution rows / columns per tile
+constexpr int STEMB_ROWS = 2 * (STEMB_C - 1) + 7;  // 39 input rows
+constexpr int STEMB_LW = 44;                       // bf16 per LDS row: image columns 32 tx - 8 .. 32 tx + 35
+constexpr int STEMB_THREADS = 320;
+constexpr int STEMB_M = 320;                       // 289 real pixels in ten blocks of 32
+constexpr int STEMB_TILE_BYTES = STEMB_M * STEM_TROW * 4;  // the epilogue tile (42 KB) is the larger use of the region
+
+template <int CIN>
+struct StemBCfg {
+  static constexpr int ROWS = CIN * 7, STEPS = (ROWS + 1) / 2;  // 21 -> 11 steps; 7 -> 4
+  static constexpr int W_BYTES = STEPS * 2 * 64 * 16;
+  static constexpr int LDS_BYTES = STEMB_TILE_BYTES + W_BYTES;
+  static constexpr int NQ = STEMB_LW / 4, NE = CIN * STEMB_ROWS * NQ, IT = (NE + STEMB_THREADS - 1) / STEMB_THREADS;
+  static_assert(CIN * STEMB_ROWS * STEMB_LW * 2 <= STEMB_TILE_BYTES, "input window fits in the epilogue tile's LDS");
+};
+
+template <int CIN>
+__global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const StemX3Args a) {
+  using C = StemBCfg<CIN>;
+  constexpr int ROWS = C::ROWS, STEPS = C::STEPS, IT = C::IT, NQ = C::NQ, NE = C::NE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const unsigned* lds32 = reinterpret_cast<const unsigned*>(lds_raw);
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  uint4* wl = reinterpret_cast<uint4*>(lds_raw + STEMB_TILE_BYTES);  // [STEPS][2 nb][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  // XCD k (workgroups with blockIdx.x & 7 == k) walks the tiles [k T / 8, (k + 1) T / 8) of the launch
+  const int T = tiles * a.frames, per = gridDim.x >> 3, slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const int t_end = (int)(((long long)(xcd + 1) * T) >> 3);
+  int tcur = (int)(((long long)xcd * T) >> 3) + slot;
+
+  for (int i = tid; i < STEPS * 2 * 64; i += STEMB_THREADS) wl[i] = a.wfrag[i];
+
+  float4 v[IT];
+  auto request = [&](int tt) {  // the input window of tile tt as aligned float4 row segments (W is a multiple of 8: a
+                                // float4 is entirely inside or outside the frame)
+    const int b = tt / tiles, t = tt - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int iy0 = ty * 32 - 5, ixa = tx * 32 - 8;  // image row of LDS row 0, image column of LDS column 0
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * STEMB_THREADS;
+      const int row = e / NQ, q = e - row * NQ;
+      const int c = row / STEMB_ROWS, hy = row - c * STEMB_ROWS;
+      const int iy = iy0 + hy, ix = ixa + 4 * q;
+      const bool ok = tt < t_end && e < NE && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float4 x = *reinterpret_cast<const float4*>(a.in + (ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0));
+      v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (tcur < t_end) request(tcur);
+
+  // pixel m of the tile = convolution output (row 16 ty - 1 + m / 17, column 16 tx - 1 + m % 17); its 8 K-values of a
+  // filter row start at LDS column 2 (m % 17) + 2 (the zero-weight pad in front), LDS row 2 (m / 17) + ky
+  int abase[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    int m = (wave * 2 + mb) * 32 + l31;
+    m = m < STEMB_C * STEMB_C ? m : STEMB_C * STEMB_C - 1;
+    abase[mb] = (2 * (m / STEMB_C)) * (STEMB_LW / 2) + (m % STEMB_C) + 1;  // dwords
+  }
+  const float bias0 = a.bias[l31], bias1 = a.bias[32 + l31];
+  unsigned* outp = reinterpret_cast<unsigned*>(a.out);  // two bf16 channels per word
+
+  for (; tcur < t_end; tcur += per) {
+    const int b = tcur / tiles, t = tcur - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    __syncthreads();  // the previous tile's pooling has read the region (first tile: the weights are in LDS)
+    {
+      uint2* lds64 = reinterpret_cast<uint2*>(lds_raw);
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int e = tid + i * STEMB_THREADS;
+        if (e < NE)
+          lds64[e] = make_uint2(f2bf(v[i].x) | ((unsigned)f2bf(v[i].y) << 16), f2bf(v[i].z) | ((unsigned)f2bf(v[i].w) << 16));
+      }
+    }
+    __syncthreads();
+#ifndef STEMB_SKIP_LOAD
+    request(tcur + per);  // lands behind the K loop and the epilogue
+#endif
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifndef STEMB_SKIP_K
+#pragma unroll
+#endif
+    for (int s = 0; s < STEPS; ++s) {
+#ifdef STEMB_SKIP_K
+      if (a.H > 0) break;
+#endif
+      // this lane's filter row: (c, ky); a padded row (weights zero) re-reads the last real one
+      const int r0 = 2 * s < ROWS ? 2 * s : ROWS - 1, r1 = 2 * s + 1 < ROWS ? 2 * s + 1 : ROWS - 1;
+      const int off0 = ((r0 / 7) * STEMB_ROWS + (r0 % 7)) * (STEMB_LW / 2), off1 = ((r1 / 7) * STEMB_ROWS + (r1 % 7)) * (STEMB_LW / 2);
+      const int off = half ? off1 : off0;
+      uint4 av[2], bw[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const unsigned* q = lds32 + abase[mb] + off;
+        av[mb] = make_uint4(q[0], q[1], q[2], q[3]);
+      }
+      bw[0] = wl[(s * 2 + 0) * 64 + lane];
+      bw[1] = wl[(s * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) mfma_split<1>(acc[mb][nb], &av[mb], &bw[nb]);
+    }
+
+    // epilogue: per 32-channel half, tile -> LDS (fp32, post-ReLU: every value >= 0) -> 3x3/2 max-pool -> bf16.
+    // Thread (cp = tid & 15, side = (tid >> 4) & 1, j = tid >> 5 < 8) owns channels 2 cp, 2 cp + 1 of pooled row j,
+    // pooled columns 4 side .. 4 side + 3: three convolution rows reduced to 9 column maxima per channel, the four
+    // window maxima emitted from registers as one word each.
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      __syncthreads();
+      const float bias = nb ? bias1 : bias0;
+#ifdef STEMB_SKIP_TILE
+      if (a.H < 0)
+#endif
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wave * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float x = acc[mb][nb][r] + bias;
+          lds[m * STEM_TROW + l31] = x > 0.f ? x : 0.f;
+        }
+      __syncthreads();
+      const int cp = tid & 15, side = (tid >> 4) & 1, j = tid >> 5;
+      const int gpy = ty * 8 + j;
+#ifdef STEMB_SKIP_POOL
+      if (a.H < 0)
+#endif
+      if (j < 8 && gpy < a.Hp) {
+        float cm[2][9];
+#pragma unroll
+        for (int cc = 0; cc < 9; ++cc) cm[0][cc] = cm[1][cc] = -1.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int lr = 2 * j + dy, gy = ty * 16 - 1 + lr;
+          if (gy < 0 || gy >= a.Ho) continue;  // MaxPool2d pads with -inf: rows outside the convolution's output do not count
+#pragma unroll
+          for (int cc = 0; cc < 9; ++cc) {
+            const float* q = lds + (lr * STEMB_C + 8 * side + cc) * STEM_TROW + 2 * cp;
+            cm[0][cc] = fmaxf(cm[0][cc], q[0]);
+            cm[1][cc] = fmaxf(cm[1][cc], q[1]);
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 9; ++cc) {
+          const int gx = tx * 16 - 1 + 8 * side + cc;
+          if (gx < 0 || gx >= a.Wo) cm[0][cc] = cm[1][cc] = -1.f;
+        }
+        unsigned* row = outp + (((size_t)(b * a.Hp + gpy) * a.Wp + tx * 8 + 4 * side) * 64 + nb * 32) / 2 + cp;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          if (tx * 8 + 4 * side + px >= a.Wp) continue;
+          const float m0 = fmaxf(fmaxf(cm[0][2 * px], cm[0][2 * px + 1]), cm[0][2 * px + 2]);
+          const float m1 = fmaxf(fmaxf(cm[1][2 * px], cm[1][2 * px + 1]), cm[1][2 * px + 2]);
+#ifdef STEMB_SKIP_STORE
+          if (m0 == 123.456f)
+#endif
+          row[px * 32] = f2bf(m0) | ((unsigned)f2bf(m1) << 16);
+        }
+      }
+    }
   }
 }
 

@@ -757,6 +757,7 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   a.x = s.x;
   a.csx = s.csx;
   a.in_f32 = s.in_f32;
+  a.x_bytes = (unsigned)std::min<size_t>((size_t)c->B * s.H * s.W * s.csx * 2, 0xffffff00u);
   a.nchunk = s.cin_pad / k.KC;
   a.H = s.H;
   a.W = s.W;
@@ -818,6 +819,7 @@ static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, 
     a.x = x;
     a.csx = csx;
     a.in_f32 = 0;
+    a.x_bytes = (unsigned)std::min<size_t>((size_t)c->B * H * W * csx * 2, 0xffffff00u);
     a.nchunk = cin / k.KC;
     a.H = H;
     a.W = W;
@@ -860,7 +862,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   const int H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
   const bool de = c->cfg.descriptor_enabled != 0;
   bf16_t* feat = reinterpret_cast<bf16_t*>(c->cat) + 128;
-  add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 1, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
+  add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
   add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K32_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
   add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
@@ -1210,7 +1212,7 @@ static int build_plan(fpc_ctx* c) {
     op.name = "encoder.conv1+bn1+relu";
     op.flops_per_frame = 2.0 * H2 * W2 * 64 * 147;  // of the reference's 3-channel convolution, also for gray frames
     op.mfma_flops_per_frame = 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 152;
-    op.bytes_per_frame = 4.0 * ((double)c->cin * H * W + 64.0 * H4 * W4);   // frame in, pooled map out (fp32 in every mode)
+    op.bytes_per_frame = 4.0 * (double)c->cin * H * W + (c->bf16 ? 2.0 : 4.0) * 64.0 * H4 * W4;   // frame in, pooled map out
     if (c->split || c->bf16)  // stem_pool_x3_kernel: (rows + 1) / 2 K16 steps of six bf16 MFMAs
       op.mfma_flops_per_frame = (c->bf16 ? 1 : c->split_f16 ? 3 : 6) * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
     c->ops.push_back(op);
@@ -1962,8 +1964,10 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
     switch (op.type) {
       case OP_STEM: {
         if (c->fuse_stem_pool || c->cin == 1 || c->bf16) {
-          float* x0 = c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
-          hipMemsetAsync(x0, 0, (size_t)n * (H / 4) * (W / 4) * 64 * sizeof(float), sb.st);
+          // the pooled map: fp32, completed across tiles with atomicMax (hence zero-filled); FPC_BF16 writes it once, as bf16
+          float* x0 = c->bf16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c->x0) + (size_t)f0 * (H / 4) * (W / 4) * 64)
+                              : c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
+          if (!c->bf16) hipMemsetAsync(x0, 0, (size_t)n * (H / 4) * (W / 4) * 64 * sizeof(float), sb.st);
           LaunchTimer t(c, (int)i, sb.st, n);
           StemPoolArgs a{};
           a.in = frames + (size_t)f0 * c->cin * H * W;
@@ -1991,9 +1995,12 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             if (c->split_f16) {
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 2>), grid, dim3(256), 0, sb.st, x);
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 2>), grid, dim3(256), 0, sb.st, x);
-            } else if (c->bf16) {  // bf16 mode: bf16 operands like every other layer of the mode
-              if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 1>), grid, dim3(256), 0, sb.st, x);
-              else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 1>), grid, dim3(256), 0, sb.st, x);
+            } else if (c->bf16) {  // bf16 mode: bf16 operands like every other layer of the mode, bf16 out, no atomics
+              x.frames = n;
+              const int T = a.tiles_x * a.tiles_y * n;
+              const dim3 pg(std::min((T + 7) / 8 * 8, std::max(8, 2 * c->num_cus / 8 * 8)));  // two workgroups per CU, a multiple of 8
+              if (c->cin == 1) hipLaunchKernelGGL(stem_pool_bf16_kernel<1>, pg, dim3(STEMB_THREADS), StemBCfg<1>::LDS_BYTES, sb.st, x);
+              else hipLaunchKernelGGL(stem_pool_bf16_kernel<3>, pg, dim3(STEMB_THREADS), StemBCfg<3>::LDS_BYTES, sb.st, x);
             } else {
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 3>), grid, dim3(256), 0, sb.st, x);
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 3>), grid, dim3(256), 0, sb.st, x);
@@ -2320,6 +2327,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30) ||
+      // FPC_BF16 addresses a tensor of the batch with 32-bit byte offsets (the widest: 8 bytes per frame pixel)
+      (cfg->dtype == FPC_BF16 && (long long)cfg->max_batch * cfg->height * cfg->width >= (1ll << 28)) ||
       cfg->width > 3328)  // softmax_d2s_kernel keeps an 8 x W strip (48 W bytes) in the 160 KB of LDS
     return FPC_E_INVALID;
   int ndev = 0;
@@ -2431,6 +2440,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     HIPCHECK(hipFuncSetAttribute(g_fkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_fkinds[k].lds_bytes));
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                12 * cfg->width * (int)sizeof(float)));
+  HIPCHECK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<1>::LDS_BYTES));
+  HIPCHECK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<3>::LDS_BYTES));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
 #ifdef FPC_DIAG
@@ -2693,10 +2704,10 @@ int fpc_read_activation(fpc_ctx* c, const char* name, int frame0, int n, float* 
   if (!c || !name || frame0 < 0 || n < 0 || frame0 + n > c->B) return FPC_E_INVALID;
   if (c->vgg) return FPC_E_INVALID;   // the C++ network's layers are read through fpc_forward only
   const int H4 = c->H / 4, W4 = c->W / 4, Hc = c->Hc, Wc = c->Wc, H16 = c->H / 16, W16 = c->W / 16;
-  const bool lowp = c->bf16;          // bf16 tensors (all but the pooled stem output, the logits and the descriptor map)
+  const bool lowp = c->bf16;          // bf16 tensors (all but the logits and the descriptor map)
   struct Tap { const char* name; const void* p; int cs, C, H, W; bool bf; int off; };
   const Tap taps[] = {
-      {"pool", c->x0, 64, 64, H4, W4, false, 0},
+      {"pool", c->x0, 64, 64, H4, W4, lowp, 0},
       {"layer1.0", c->x1, 64, 64, H4, W4, lowp, 0},
       {"layer1.1", c->x2, 64, 64, H4, W4, lowp, 0},
       {"layer2.0", c->x3, 128, 128, Hc, Wc, lowp, 0},
@@ -2998,7 +3009,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
     if (kernels) {
       const char* k = "?";
       if (op) switch (op->type) {
-          case OP_STEM: k = (c->split || c->bf16) ? "stem_pool_x3_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
+          case OP_STEM: k = c->bf16 ? "stem_pool_bf16_kernel" : c->split ? "stem_pool_x3_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;

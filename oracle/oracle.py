@@ -156,7 +156,8 @@ def _bias(t):
 
 
 def bf16_emulated_stem(image, sd):
-    """frames -> the pooled stem output ("pool"), fp32: bf16 frame and weights, fp32 bias / ReLU / max-pool."""
+    """frames -> the pooled stem output ("pool") before it is stored (the device stores it as bf16: round_bf16 of
+    this): bf16 frame and weights, fp32 accumulation / bias / ReLU / max-pool."""
     image = np.ascontiguousarray(image, np.float32)
     b, _, hh, ww = image.shape
     s, t = _fold(sd, "encoder.bn1")

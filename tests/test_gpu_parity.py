@@ -572,8 +572,12 @@ def _check_bf16_layers(oracle, e16, frames, sd, frame_idx, what):
     """frames must be the batch of the engine's LAST forward call."""
     stem = oracle.bf16_emulated_stem(frames[frame_idx], sd)
     got0 = np.concatenate([e16.activation("pool", i, 1).cpu().numpy() for i in frame_idx], 0)
-    scale = np.maximum(np.abs(stem), 1.0)
-    assert float((np.abs(got0 - stem) / scale).max()) < 1e-5, what + ": pooled stem output"
+    # stored as bf16 (max-pool and round-to-nearest commute): the rounded emulation, up to an ulp where the order of the
+    # fp32 accumulation decided the rounding
+    want0 = oracle.round_bf16(stem)
+    rel0 = np.abs(got0.astype(np.float64) - want0) / np.maximum(np.abs(want0), 1.0)
+    assert float(rel0.max()) < BF16_LAYER_REL, (what + ": pooled stem output", float(rel0.max()))
+    assert float((rel0 > BF16_LAYER_EXACT).mean()) < BF16_LAYER_FLIPS, what + ": pooled stem output"
     worst = 0.0
     for name, ins in oracle.BF16_LAYERS:
         if not e16.descriptor_enabled and (name.startswith("desc") or name == "up"):
