@@ -58,13 +58,11 @@ struct BlockBfCfg {
   static constexpr int HW = (TW - 1) * S + EXT, HH = (TH - 1) * S + EXT;
   static constexpr int ROW16 = KC / 8 + 1;            // 16-byte units per halo pixel (+1 skew)
   static constexpr int ROWH16 = CMIDP / 8 + 1;        // per h row
-  static constexpr int ROWO4 = CMIDP / 4 + 1;         // float4 per row of the fp32 output tile
   static constexpr int M = WM * MB * 32, N = WN * NB * 32;
   static constexpr int HALO_BYTES = HH * HW * ROW16 * 16;
   static constexpr int H_BYTES = M * ROWH16 * 16;
-  static constexpr int O_BYTES = M * ROWO4 * 16;
-  static constexpr int LDS_BYTES = (HALO_BYTES > H_BYTES ? HALO_BYTES : H_BYTES) > O_BYTES
-                                       ? (HALO_BYTES > H_BYTES ? HALO_BYTES : H_BYTES) : O_BYTES;
+  static constexpr int TILE_BYTES = HALO_BYTES > H_BYTES ? HALO_BYTES : H_BYTES;   // the halo chunk, then h
+  static constexpr int LDS_BYTES = TILE_BYTES + 2 * N * 4;                         // + b1, b2
   static_assert(KC % 16 == 0 && CMIDP % 16 == 0 && CMIDP <= N, "bf16 MFMA consumes 16 channels per step");
 };
 
@@ -72,7 +70,7 @@ template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB
 __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockBfArgs a) {
   using C = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
   constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
-  constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, ROWH16 = C::ROWH16, ROWO4 = C::ROWO4, NBT = WN * NB;
+  constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, ROWH16 = C::ROWH16, NBT = WN * NB;
   extern __shared__ uint4 lds16[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,6 +93,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   }
   constexpr int stepstride = NBT * 64;
   const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
+  // The MFMAs below take the weight fragment as the A operand and the pixels as B: the accumulators then hold the tile
+  // TRANSPOSED -- a lane owns ONE pixel (l31 of its 32-pixel block) and, per 32-channel block, four groups of four
+  // consecutive channels (group g: channels 8 g + 4 half ..+3 in registers 4 g ..+3) -- so both epilogues work on whole
+  // 8- / 16-byte channel groups straight from registers: h goes to LDS in 16 ds_write_b64 per lane (it was 64 two-byte
+  // writes), the output leaves as 8-byte (bf16) or 16-byte (fp32) stores with no fp32 tile in LDS in between (67 KB of
+  // the workgroup's LDS, a barrier and ~250 VALU / LDS instructions per lane).  Biases sit in LDS, read 16 bytes at a time.
+  float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds16) + C::TILE_BYTES);   // [2][N]
+  for (int i = tid; i < 2 * C::N; i += NT) {
+    const int which = i / C::N, n = i - which * C::N;
+    bias_lds[i] = which == 0 ? a.b1[n] : (a.b2 ? a.b2[n] : 0.f);
+  }
 
   const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
   // The halo chunk through a buffer descriptor: a position outside the frame (or a chunk past the last one) gets an
@@ -135,25 +144,33 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     }
   };
 
-  f32x16 acc[MB][NB];
+  // acc: conv1 (then dead once h is written); acc2: the shortcut + conv2 = the block's output before bias / ReLU
+  f32x16 acc[MB][NB], acc2[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = acc2[mb][nb][r] = 0.f;
 
-  // ---------------------------------------------------------------- phase 1: KxK conv
+  // ---------------------------------------------------------------- phase 1: KxK conv (+ the shortcut)
+  FPC_STAMP(0)
   load_chunk(0);
   uint4 b0[NB], b1[NB];
-  constexpr int NS = 9 * K16;                                            // steps of a chunk of a 3x3 convolution
-  constexpr int D = S == 2 ? 3 : NS % 6 == 0 ? 6 : NS % 5 == 0 ? 5 : NS % 4 == 0 ? 4 : 3;   // fragment ring: D steps ahead (the stride-2 halo needs the registers)
+  // A chunk of a ResNetBlock is 9 x K16 steps of conv1 and K16 steps of the SHORTCUT on the same chunk of x: the 1x1
+  // projection (or the identity, as a unit matrix: exact in bf16 x fp32) reads exactly the pixels the 3x3's centre tap
+  // reads, which are in LDS right now -- as phase 2b it fetched them again from global memory, 16 bytes per lane at a
+  // pixel stride (32 cache lines per request): 23 k of layer_out.0's 85 k cycles per tile for 3 k cycles of MFMAs, and the
+  // identity's loads stood at the head of the epilogue (in-kernel stamps).  Its fragments follow the chunk's conv1
+  // fragments in the w1 stream ("tap 9").
+  constexpr int NS = 10 * K16;
+  constexpr int D = NS % 4 == 0 ? 4 : 5;   // fragment ring: D steps ahead
   static_assert(NS % D == 0, "the ring position of a step must not depend on the chunk");
   if (a.ntaps == 9) {
     // Two steps of fragments ahead -- 256 MFMA cycles of this wave -- do not cover an L2 round trip, and the LDS read of a
-    // step's pixels sat right in front of its MFMAs.  Here the chunk's 9 x K16 steps are unrolled, fragments run D steps
-    // ahead in a register ring whose slots are compile-time names (through a buffer descriptor too: the lane's offset in
-    // a VGPR that never changes, the step in the scalar offset, and a request past the last step returns zeros), and a
+    // step's pixels sat right in front of its MFMAs.  Here the chunk's steps are unrolled, fragments run D steps ahead
+    // in a register ring whose slots are compile-time names (through a buffer descriptor too: the lane's offset in a
+    // VGPR that never changes, the step in the scalar offset, and a request past the last step returns zeros), and a
     // step's pixels are read while the previous step's MFMAs run.
     u32x4 ring[D][NB];
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -171,6 +188,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       FPC_LDS_BARRIER();   // the previous chunk's pixels have been read
       store_chunk();
       FPC_LDS_BARRIER();
+      if (chunk == 0) { FPC_STAMP(1) }
+      if (chunk == 1) { FPC_STAMP(6) }
       load_chunk(chunk + 1);
       u32x4 av[MB], an[MB];
 #pragma unroll
@@ -178,16 +197,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #pragma unroll
       for (int st = 0; st < NS; ++st) {
         if (st + 1 < NS) {
-          const int toff = a.tapoff16[(st + 1) / K16];
+          const int tapn = (st + 1) / K16;
+          const int toff = a.tapoff16[tapn < 9 ? tapn : 4];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + toff + ((st + 1) % K16) * 2]);
         }
+        if (st / K16 < 9) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+          for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
-                                                                  __builtin_bit_cast(bf16x8, ring[st % D][nb]), acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[st % D][nb]),
+                                                                    __builtin_bit_cast(bf16x8, av[mb]), acc[mb][nb], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[st % D][nb]),
+                                                                     __builtin_bit_cast(bf16x8, av[mb]), acc2[mb][nb], 0, 0, 0);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
           ring[st % D][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + nb * 1024), wstep, 0));
@@ -225,8 +254,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
-                                                                  __builtin_bit_cast(bf16x8, b0[nb]), acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0[nb]),
+                                                                  __builtin_bit_cast(bf16x8, av[mb]), acc[mb][nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           b0[nb] = b1[nb];
@@ -237,181 +266,132 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   }
   }
 
+  FPC_STAMP(2)
   if (!a.conv_only) {
     // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (bf16)
-    // phase 2's fragments run D2 steps ahead in a ring of compile-time slots, like phase 1's; the first D2 steps -- and
-    // the first D2 steps of the projection's pixels -- are requested before h is written and land behind that.
-    constexpr int KH = CMIDP / 16, D2 = 4;
-    uint4 ring[D2][NB];
-    const uint4* wq = a.w2 + (size_t)(wn * NB) * 64 + lane;
-    int left = a.k16_h + a.k16_x + 1;
+    // phase 2's fragments (KH steps over h) are all requested before h is written and land behind that.
+    constexpr int KH = CMIDP / 16, D2 = KH < 8 ? KH : 8;
+    u32x4 ring[D2][NB];
+    const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(a.w2), 0, (int)((unsigned)(KH + 2) * (unsigned)(stepstride * 16)), 0x00020000);
+    const unsigned wlane2 = (unsigned)((wn * NB) * 64 + lane) * 16u;
 #pragma unroll
-    for (int d = 0; d < D2; ++d) {
+    for (int d = 0; d < D2; ++d)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wq[nb * 64];
-      wq += left > 0 ? stepstride : 0;
-      --left;
-    }
-    size_t xoff[MB];
-    uint4 xr[D2][MB];
-    auto load_a = [&](int mb, int k) {
-      return *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + xoff[mb] + k * 16);
-    };
-    if (a.k16_x > 0) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        int m = (wm * MB + mb) * 32 + l31;
-        m = m < TH * TW ? m : TH * TW - 1;
-        const int py = m / TW, px = m - py * TW;
-        int y = (ty * TH + py) * S, x = (tx * TW + px) * S;
-        y = y < a.H ? y : a.H - 1;
-        x = x < a.W ? x : a.W - 1;
-        xoff[mb] = ((size_t)(b * a.H + y) * a.W + x) * a.csx + half * 8;
-      }
-#pragma unroll
-      for (int d = 0; d < D2; ++d)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) xr[d][mb] = load_a(mb, d < a.k16_x ? d : a.k16_x - 1);
-    }
+      for (int nb = 0; nb < NB; ++nb)
+        ring[d][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc2, (int)(wlane2 + nb * 1024), d * stepstride * 16, 0));
     FPC_LDS_BARRIER();
     {
-      bf16_t* hl = reinterpret_cast<bf16_t*>(lds16);
+      unsigned char* hl = reinterpret_cast<unsigned char*>(lds16);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int n = (wn * NB + nb) * 32 + l31;
-        const float bias = a.b1[n];
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = (wn * NB + nb) * 32 + 8 * g + 4 * half;   // this lane's four channels of the group
+          const float4 bias = *reinterpret_cast<const float4*>(bias_lds + n0);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = acc[mb][nb][r] + bias;
-            if (n < CMIDP) hl[m * (ROWH16 * 8) + n] = f2bf(v > 0.f ? v : 0.f);
-            acc[mb][nb][r] = 0.f;
+          for (int mb = 0; mb < MB; ++mb) {
+            const int m = (wm * MB + mb) * 32 + l31;
+            float v0 = acc[mb][nb][4 * g + 0] + bias.x, v1 = acc[mb][nb][4 * g + 1] + bias.y;
+            float v2 = acc[mb][nb][4 * g + 2] + bias.z, v3 = acc[mb][nb][4 * g + 3] + bias.w;
+            v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+            if (n0 < CMIDP)
+              *reinterpret_cast<uint2*>(hl + m * (ROWH16 * 16) + n0 * 2) =
+                  make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
           }
-      }
+        }
     }
     FPC_LDS_BARRIER();
-    // -------------------------------------------------------------- phase 2a: K over h (LDS)
+    FPC_STAMP(3)
+    // -------------------------------------------------------------- phase 2: K over h (LDS), on top of the shortcut
     int hbase[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH16 + half;
     {
-      uint4 av[MB], an[MB];
+      u32x4 av[MB], an[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) av[mb] = lds16[hbase[mb]];
+      for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const u32x4*>(&lds16[hbase[mb]]);
 #pragma unroll
       for (int k = 0; k < KH; ++k) {
         if (k + 1 < KH) {
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) an[mb] = lds16[hbase[mb] + (k + 1) * 2];
+          for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const u32x4*>(&lds16[hbase[mb] + (k + 1) * 2]);
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]),
-                                                                  __builtin_bit_cast(bf16x8, ring[k % D2][nb]), acc[mb][nb], 0, 0, 0);
+            acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[k % D2][nb]),
+                                                                   __builtin_bit_cast(bf16x8, av[mb]), acc2[mb][nb], 0, 0, 0);
+        if (k + D2 < KH) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) ring[k % D2][nb] = wq[nb * 64];
-        wq += left > 0 ? stepstride : 0;
-        --left;
+          for (int nb = 0; nb < NB; ++nb)
+            ring[k % D2][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc2, (int)(wlane2 + nb * 1024), (k + D2) * stepstride * 16, 0));
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // -------------------------------------------------------------- phase 2b: K over x (projection), D2 steps per trip
-    for (int k0 = 0; k0 < a.k16_x; k0 += D2) {
 #pragma unroll
-      for (int j = 0; j < D2; ++j) {
-        if (k0 + j < a.k16_x) {  // (k16_x is a multiple of 4 for every layer of this network; uniform)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xr[j][mb]),
-                                                                    __builtin_bit_cast(bf16x8, ring[(KH + j) % D2][nb]), acc[mb][nb], 0, 0, 0);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) ring[(KH + j) % D2][nb] = wq[nb * 64];
-          wq += left > 0 ? stepstride : 0;
-          --left;
-          const int kn = k0 + j + D2;
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) xr[j][mb] = load_a(mb, kn < a.k16_x ? kn : a.k16_x - 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = acc2[mb][nb];
   }
 
-  // ---------------------------------------------------------------- epilogue: fp32 tile -> LDS -> 8-channel vectors
-  FPC_LDS_BARRIER();
+  // ---------------------------------------------------------------- epilogue: + bias, ReLU -> bf16 tile in LDS -> 16-byte stores
+  // (fp32 outputs -- the logits and the descriptor map -- leave straight from the registers, 16 bytes per lane)
+  FPC_STAMP(4)
   {
-    float* ol = reinterpret_cast<float*>(lds16);
-    const float* bptr = a.conv_only ? a.b1 : a.b2;
+    const float* bl = bias_lds + (a.conv_only ? 0 : C::N);
+    const int oyb = ty * TH, oxb = tx * TW;
+    if (!a.out_f32) FPC_LDS_BARRIER();   // phase 2 (or the last chunk) has read the region
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = (wn * NB + nb) * 32 + l31;
-      const float bias = bptr[n];
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = (wm * MB + mb) * 32 + l31;
+      const int py = m / TW, px = m - py * TW;
+      const int y = oyb + py, x = oxb + px;
+      const bool live = m < TH * TW && y < a.Ho && x < a.Wo;
+      const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (n < CMIDP) ol[m * (ROWO4 * 4) + n] = acc[mb][nb][r] + bias;
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = (wn * NB + nb) * 32 + 8 * g + 4 * half;
+          const float4 bias = *reinterpret_cast<const float4*>(bl + n0);
+          float v0 = acc[mb][nb][4 * g + 0] + bias.x, v1 = acc[mb][nb][4 * g + 1] + bias.y;
+          float v2 = acc[mb][nb][4 * g + 2] + bias.z, v3 = acc[mb][nb][4 * g + 3] + bias.w;
+          if (!a.norelu) {
+            v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+          }
+          if (n0 < CMIDP) {
+            if (a.out_f32) {
+              if (live) *reinterpret_cast<float4*>(static_cast<float*>(a.out) + opix * a.cso + n0) = make_float4(v0, v1, v2, v3);
+            } else {
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(lds16) + m * (ROWH16 * 16) + n0 * 2) =
+                  make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
+            }
+          }
         }
     }
-  }
-  {
-    constexpr int C8 = CMIDP / 8;
-    constexpr int NE = TH * TW * C8, EIT = (NE + NT - 1) / NT;
-    const float4* ol4 = reinterpret_cast<const float4*>(lds16);
-    const int oyb = ty * TH, oxb = tx * TW;
-    const bool ident = !a.conv_only && a.k16_x == 0;
-    // identity shortcut (same geometry as the output, stride 1; bf16, the only fp32 input feeds a projection block):
-    // the loads are issued BEFORE the barrier, in the registers the dead accumulators free
-    uint4 idq[EIT];
-    if (ident) {
+    if (!a.out_f32) {
+      FPC_LDS_BARRIER();
+      constexpr int C8 = CMIDP / 8;
+      constexpr int NE = TH * TW * C8, EIT = (NE + NT - 1) / NT;
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
         const int e = tid + i * NT;
         const int m = e / C8, c8 = e - m * C8;
         const int py = m / TW, px = m - py * TW;
         const int y = oyb + py, x = oxb + px;
-        const bool ok = (NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo;
-        idq[i] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.x) + (ok ? ((size_t)(b * a.H + y) * a.W + x) * a.csx + c8 * 8 : 0));
-      }
-    }
-    FPC_LDS_BARRIER();
-#pragma unroll
-    for (int i = 0; i < EIT; ++i) {
-      const int e = tid + i * NT;
-      const int m = e / C8, c8 = e - m * C8;
-      const int py = m / TW, px = m - py * TW;
-      const int y = oyb + py, x = oxb + px;
-      if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
-        float4 v0 = ol4[m * ROWO4 + c8 * 2], v1 = ol4[m * ROWO4 + c8 * 2 + 1];
-        if (ident) {
-          const uint4 q = idq[i];
-          v0.x += bf2f(q.x & 0xffff); v0.y += bf2f(q.x >> 16); v0.z += bf2f(q.y & 0xffff); v0.w += bf2f(q.y >> 16);
-          v1.x += bf2f(q.z & 0xffff); v1.y += bf2f(q.z >> 16); v1.z += bf2f(q.w & 0xffff); v1.w += bf2f(q.w >> 16);
-        }
-        if (!a.norelu) {
-          v0.x = v0.x > 0.f ? v0.x : 0.f; v0.y = v0.y > 0.f ? v0.y : 0.f; v0.z = v0.z > 0.f ? v0.z : 0.f; v0.w = v0.w > 0.f ? v0.w : 0.f;
-          v1.x = v1.x > 0.f ? v1.x : 0.f; v1.y = v1.y > 0.f ? v1.y : 0.f; v1.z = v1.z > 0.f ? v1.z : 0.f; v1.w = v1.w > 0.f ? v1.w : 0.f;
-        }
-        const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
-        if (a.out_f32) {
-          float4* o = reinterpret_cast<float4*>(static_cast<float*>(a.out) + opix * a.cso + c8 * 8);
-          o[0] = v0;
-          o[1] = v1;
-        } else {
-          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(a.out) + opix * a.cso + c8 * 8) = pack8(v0, v1);
+        if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
+          const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
+          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(a.out) + opix * a.cso + c8 * 8) = lds16[m * ROWH16 + c8];
         }
       }
     }
   }
+  FPC_STAMP(5)
 }
 
 }  // namespace fpc

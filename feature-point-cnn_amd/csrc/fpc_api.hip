@@ -206,8 +206,8 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
 #define FPC_BF16_KINDS(X)                                                                   \
   X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
-  X(F620_s2_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)   \
-  X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
+  X(F620_s2_K16_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)   \
+  X(F620_s1_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 32, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
   X(F620_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)     \
   X(F320_s2_K32_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)   \
@@ -779,18 +779,21 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
   fpc_ctx::ConvW cw;
+  // FPC_BF16 (planes == 1): the shortcut's fragments (projection, or the identity as a unit matrix) follow each chunk's
+  // conv1 fragments in the w1 stream as a tenth tap (block_bf16.h), and w2 holds conv2 only
+  const bool sc_in_w1 = k.planes == 1;
   cw.w_off[0] = *blob_off;
-  *blob_off += ((size_t)a.nchunk * 9 * K16 + 2) * k.planes * nbt * 64 * 4;
+  *blob_off += ((size_t)a.nchunk * (sc_in_w1 ? 10 : 9) * K16 + 2) * k.planes * nbt * 64 * 4;
   cw.b_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
   cw.w_off[1] = *blob_off;
-  *blob_off += ((size_t)(a.k16_h + a.k16_x) + 2) * k.planes * nbt * 64 * 4;
+  *blob_off += ((size_t)(a.k16_h + (sc_in_w1 ? 0 : a.k16_x)) + 2) * k.planes * nbt * 64 * 4;
   cw.b2_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
   op.flops_per_frame = 2.0 * a.Ho * a.Wo * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
   // split operands: six bf16 MFMAs per product
   op.mfma_flops_per_frame = (k.planes == 3 ? 6.0 : k.planes == 2 ? 3.0 : 1.0) * 2.0 * a.tiles_x * a.tiles_y * (k.WM * k.MB * 32.0) * (nbt * 32.0) *
-                            ((double)a.nchunk * k.KC * 9 + (a.k16_h + a.k16_x) * 16.0);
+                            ((double)a.nchunk * k.KC * 9 + (a.k16_h + (sc_in_w1 ? s.cin_pad / 16 : a.k16_x)) * 16.0);
   op.bytes_per_frame = (double)s.cin * s.H * s.W * ((s.in_f32 || k.planes > 1) ? 4.0 : 2.0) +
                        (double)s.cout * a.Ho * a.Wo * ((s.out_f32 || k.planes > 1) ? 4.0 : 2.0);
   c->ops.push_back(op);
@@ -864,8 +867,8 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   bf16_t* feat = reinterpret_cast<bf16_t*>(c->cat) + 128;
   add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
-  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K32_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
-  add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K32_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
   add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
   add_fblock(c, {"detector.layer.1", FK_F620_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
   {
@@ -879,8 +882,8 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
     add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K32_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
     add_fblock(c, {"descriptor.layer_in.1", FK_F320_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
     add_fconvT(c, FK_F620_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
-    add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K32_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K32_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
   }
 }
 
@@ -1756,20 +1759,30 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
       Fold f1, f2, fp;
       if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
         return FPC_E_MISSING_KEY;
-      PackSource s1{ci, a.nchunk * k.KC, 9, [&](int n, int c_, int t) { return (double)w1[((size_t)(n * ci + c_)) * 9 + t]; }, &f1.s};
-      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC, k.planes, &range_bad);
-      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
-      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
-      std::vector<PackSource> srcs;
-      srcs.push_back({co, a.k16_h * 16, 1, [&](int n, int c_, int) { return (double)w2[(size_t)n * co + c_]; }, &f2.s});
+      const bool sc_in_w1 = k.planes == 1;   // (add_fblock)
       std::vector<double> bias(f2.t);
       const float* wp = nullptr;
       if (a.k16_x > 0) {
         wp = need(p + ".identity_downsample.0.weight", {co, ci, 1, 1});
         if (!wp || !fold_bn(m, p + ".identity_downsample.1", co, &fp, missing)) return FPC_E_MISSING_KEY;
-        srcs.push_back({ci, a.k16_x * 16, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
         for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
       }
+      const std::vector<double> ones(co, 1.0);
+      // taps 0..8: conv1 x bn1's scale; tap 9 (FPC_BF16): the shortcut on the same channels -- the projection x its bn's
+      // scale, or the unit matrix
+      PackSource s1{ci, a.nchunk * k.KC, sc_in_w1 ? 10 : 9,
+                    [&](int n, int c_, int t) {
+                      if (t < 9) return (double)w1[((size_t)(n * ci + c_)) * 9 + t] * f1.s[n];
+                      return wp ? (double)wp[(size_t)n * ci + c_] * fp.s[n] : (n == c_ ? 1.0 : 0.0);
+                    },
+                    &ones};
+      std::vector<float> frag = pack_conv_bf16({s1}, co, nbt, k.KC, k.planes, &range_bad);
+      memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
+      std::vector<PackSource> srcs;
+      srcs.push_back({co, a.k16_h * 16, 1, [&](int n, int c_, int) { return (double)w2[(size_t)n * co + c_]; }, &f2.s});
+      if (wp && !sc_in_w1)
+        srcs.push_back({ci, a.k16_x * 16, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
       frag = pack_conv_bf16(srcs, co, nbt, 16, k.planes, &range_bad);
       memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
       for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
