@@ -13,6 +13,7 @@
 namespace fpc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;  // storage type
 
 __device__ __forceinline__ bf16_t f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -43,6 +44,7 @@ struct BlockBfArgs {
   void* out;             // bf16 (or fp32 when out_f32), offset to its first channel
   int cso, out_f32;
   int Ho, Wo, tiles_x, tiles_y, frame0;
+  int total_tiles;       // block_bf16_kernel (persistent grid): tiles_x * tiles_y * frames of the launch
   int OH, OW, oys, oxs, oy0, ox0;   // output pixel = (y*oys + oy0, x*oxs + ox0) in an OH x OW buffer
   int pad;               // halo origin = tile origin * S - pad
   int norelu;            // conv_only: 1 = no ReLU (the last 1x1 of a head of the C++ network)
@@ -77,11 +79,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bidx = fpc_xcd_tile_index();
-  const int bl = bidx / tiles;
-  const int b = a.frame0 + bl;
-  const int t = bidx - bl * tiles;
-  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  // Persistent grid (a multiple of 8 workgroups, a few per CU): XCD k -- the workgroups with blockIdx.x & 7 == k -- walks
+  // the tiles [k T / 8, (k + 1) T / 8) of the launch, so neighbouring tiles (which share halo rows) meet in one L2, and a
+  // workgroup requests its NEXT tile's first halo chunk before the current tile's epilogue: that request's trip to HBM
+  // was 11 % of a 128-channel tile and 28 % of a 64-channel one (in-kernel stamps).
+  const int T = a.total_tiles, per = gridDim.x >> 3, xcd = blockIdx.x & 7;
+  const int t_first = (int)(((long long)xcd * T) >> 3), t_end = (int)(((long long)(xcd + 1) * T) >> 3);
+  struct TileP { int b, ty, tx, iy0, ix0, live; unsigned xbase; };
+  auto tile_params = [&](int tt) {
+    TileP p;
+    p.live = tt < t_end;
+    const int tc = p.live ? tt : t_first;
+    const int bl = tc / tiles, t = tc - bl * tiles;
+    p.b = a.frame0 + bl;
+    p.ty = t / a.tiles_x;
+    p.tx = t - p.ty * a.tiles_x;
+    p.iy0 = p.ty * TH * S - a.pad;
+    p.ix0 = p.tx * TW * S - a.pad;
+    p.xbase = (unsigned)(((p.b * a.H + p.iy0) * a.W + p.ix0) * a.csx * 2);   // mod 2^32; exact for in-frame pixels
+    return p;
+  };
 
   int abase[MB];
 #pragma unroll
@@ -92,7 +109,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     abase[mb] = ((py * S) * HW + px * S) * ROW16 + half;
   }
   constexpr int stepstride = NBT * 64;
-  const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
   // The MFMAs below take the weight fragment as the A operand and the pixels as B: the accumulators then hold the tile
   // TRANSPOSED -- a lane owns ONE pixel (l31 of its 32-pixel block) and, per 32-channel block, four groups of four
   // consecutive channels (group g: channels 8 g + 4 half ..+3 in registers 4 g ..+3) -- so both epilogues work on whole
@@ -105,35 +121,37 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     bias_lds[i] = which == 0 ? a.b1[n] : (a.b2 ? a.b2[n] : 0.f);
   }
 
-  const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
-  // The halo chunk through a buffer descriptor: a position outside the frame (or a chunk past the last one) gets an
-  // offset beyond the descriptor's range and comes back as zeros from the hardware's bounds check.  No branch anywhere
-  // between a request and its use: around a block boundary the compiler waits for EVERY outstanding load (it did, once
-  // per chunk, for the next chunk's halo right after requesting it and for the fragments in flight: PMC showed the
-  // waves of this kernel parked 61 % of the time).
+  // The halo chunk through a buffer descriptor: a position outside the frame (or a chunk past the last one, or a tile
+  // past the workgroup's last) gets an offset beyond the descriptor's range and comes back as zeros from the hardware's
+  // bounds check.  No branch anywhere between a request and its use: around a block boundary the compiler waits for
+  // EVERY outstanding load (it did, once per chunk, for the next chunk's halo right after requesting it and for the
+  // fragments in flight: PMC showed the waves of this kernel parked 61 % of the time).
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 stage[ITER];   // (vector values: an array of uint4 structs is not promoted to registers)
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const unsigned xbase = (unsigned)(((b * a.H + iy0) * a.W + ix0) * a.csx * 2);   // mod 2^32; exact for in-frame pixels
-  auto load_chunk = [&](int chunk) {
-    const int wlim = chunk < a.nchunk ? a.W : 0;   // nothing is in range past the last chunk
+  auto load_chunk = [&](const TileP& p, int chunk) {
+    const int wlim = (chunk < a.nchunk && p.live) ? a.W : 0;   // nothing is in range past the last chunk / tile
+    int tl = tid;
+    asm volatile("" : "+v"(tl));   // (recomputed per call: hoisted out of the tile loop, the per-element offsets spill)
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-      const int e = tid + i * NT;
+      const int e = tl + i * NT;
       const int pix = e / KC8, c8 = e - pix * KC8;
       const int hy = pix / HW, hx = pix - hy * HW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
+      const int iy = p.iy0 + hy, ix = p.ix0 + hx;
       const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)wlim) & (hy < HH);   // (& not &&: no branch)
-      unsigned off = xbase + (unsigned)(((hy * a.W + hx) * a.csx + chunk * KC + c8 * 8) * 2);
+      unsigned off = p.xbase + (unsigned)(((hy * a.W + hx) * a.csx + chunk * KC + c8 * 8) * 2);
       asm volatile("" : "+v"(off));   // computed for every lane: as a conditional the compiler branches around it
       stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : 0xfffffff0u), 0, 0));
     }
   };
   auto store_chunk = [&]() {
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-      const int e = tid + i * NT;
+      const int e = tl + i * NT;
       int pix = e / KC8, c8 = e - pix * KC8;
       if (NV % NT != 0) {   // elements past the halo go to the skew column of its last pixel (never read)
         const bool in = e < NV;
@@ -144,6 +162,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     }
   };
 
+  TileP cur = tile_params(t_first + (int)(blockIdx.x >> 3));
+  load_chunk(cur, 0);
+  for (int tcur = t_first + (int)(blockIdx.x >> 3); tcur < t_end; tcur += per) {
+  const int b = cur.b, ty = cur.ty, tx = cur.tx;
+  const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;   // (the ConvTranspose phases' path below)
   // acc: conv1 (then dead once h is written); acc2: the shortcut + conv2 = the block's output before bias / ReLU
   f32x16 acc[MB][NB], acc2[MB][NB];
 #pragma unroll
@@ -155,7 +178,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 
   // ---------------------------------------------------------------- phase 1: KxK conv (+ the shortcut)
   FPC_STAMP(0)
-  load_chunk(0);
   uint4 b0[NB], b1[NB];
   // A chunk of a ResNetBlock is 9 x K16 steps of conv1 and K16 steps of the SHORTCUT on the same chunk of x: the 1x1
   // projection (or the identity, as a unit matrix: exact in bf16 x fp32) reads exactly the pixels the 3x3's centre tap
@@ -190,7 +212,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       FPC_LDS_BARRIER();
       if (chunk == 0) { FPC_STAMP(1) }
       if (chunk == 1) { FPC_STAMP(6) }
-      load_chunk(chunk + 1);
+      load_chunk(cur, chunk + 1);
       u32x4 av[MB], an[MB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + a.tapoff16[0]]);
@@ -234,10 +256,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
   wp += stepstride;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    if (chunk) FPC_LDS_BARRIER();
+    FPC_LDS_BARRIER();
     store_chunk();
     FPC_LDS_BARRIER();
-    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    if (chunk + 1 < a.nchunk) load_chunk(cur, chunk + 1);
     for (int tap = 0; tap < a.ntaps; ++tap) {
       const int toff = a.tapoff16[tap];
 #pragma unroll
@@ -269,8 +291,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   FPC_STAMP(2)
   if (!a.conv_only) {
     // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (bf16)
-    // phase 2's fragments (KH steps over h) are all requested before h is written and land behind that.
-    constexpr int KH = CMIDP / 16, D2 = KH < 8 ? KH : 8;
+    // phase 2's first D2 steps of fragments are requested before h is written and land behind that.
+    constexpr int KH = CMIDP / 16, D2 = KH < 4 ? KH : 4;
     u32x4 ring[D2][NB];
     const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(a.w2), 0, (int)((unsigned)(KH + 2) * (unsigned)(stepstride * 16)), 0x00020000);
@@ -283,19 +305,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     FPC_LDS_BARRIER();
     {
       unsigned char* hl = reinterpret_cast<unsigned char*>(lds16);
+      int nl = (wn * NB) * 32 + 4 * half, ml = (wm * MB) * 32 + l31;
+      asm volatile("" : "+v"(nl), "+v"(ml));   // (recomputed per tile: hoisted out of the tile loop, the 24 addresses below spill)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n0 = (wn * NB + nb) * 32 + 8 * g + 4 * half;   // this lane's four channels of the group
+          const int n0 = nl + nb * 32 + 8 * g;   // this lane's four channels of the group
           const float4 bias = *reinterpret_cast<const float4*>(bias_lds + n0);
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
-            const int m = (wm * MB + mb) * 32 + l31;
+            const int m = ml + mb * 32;
             float v0 = acc[mb][nb][4 * g + 0] + bias.x, v1 = acc[mb][nb][4 * g + 1] + bias.y;
             float v2 = acc[mb][nb][4 * g + 2] + bias.z, v3 = acc[mb][nb][4 * g + 3] + bias.w;
             v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-            if (n0 < CMIDP)
+            if (CMIDP == C::N || n0 < CMIDP)
               *reinterpret_cast<uint2*>(hl + m * (ROWH16 * 16) + n0 * 2) =
                   make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
           }
@@ -305,8 +329,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     FPC_STAMP(3)
     // -------------------------------------------------------------- phase 2: K over h (LDS), on top of the shortcut
     int hbase[MB];
+    {
+      int hb = ((wm * MB) * 32 + l31) * ROWH16 + half;
+      asm volatile("" : "+v"(hb));
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) hbase[mb] = ((wm * MB + mb) * 32 + l31) * ROWH16 + half;
+      for (int mb = 0; mb < MB; ++mb) hbase[mb] = hb + mb * 32 * ROWH16;
+    }
     {
       u32x4 av[MB], an[MB];
 #pragma unroll
@@ -342,56 +370,80 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   // ---------------------------------------------------------------- epilogue: + bias, ReLU -> bf16 tile in LDS -> 16-byte stores
   // (fp32 outputs -- the logits and the descriptor map -- leave straight from the registers, 16 bytes per lane)
   FPC_STAMP(4)
+  const TileP nxt = tile_params(tcur + per);
+  load_chunk(nxt, 0);   // lands behind the epilogue (all zeros past the last tile)
   {
+    // (stores through a buffer descriptor as well: a dead pixel's offset is out of range and the hardware drops the
+    // store -- an `if` around a store is a block boundary, and the compiler drains every outstanding request there,
+    // the next tile's halo included)
     const float* bl = bias_lds + (a.conv_only ? 0 : C::N);
     const int oyb = ty * TH, oxb = tx * TW;
-    if (!a.out_f32) FPC_LDS_BARRIER();   // phase 2 (or the last chunk) has read the region
+    const float floor_ = a.norelu ? -3.0e38f : 0.f;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)0xffffff00u, 0x00020000);
+    int nl = (wn * NB) * 32 + 4 * half, ml = (wm * MB) * 32 + l31;
+    asm volatile("" : "+v"(nl), "+v"(ml));
+    if (a.out_f32) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = (wm * MB + mb) * 32 + l31;
-      const int py = m / TW, px = m - py * TW;
-      const int y = oyb + py, x = oxb + px;
-      const bool live = m < TH * TW && y < a.Ho && x < a.Wo;
-      const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = ml + mb * 32;
+        const int py = m / TW, px = m - py * TW;
+        const int y = oyb + py, x = oxb + px;
+        const bool live = (m < TH * TW) & (y < a.Ho) & (x < a.Wo);
+        const unsigned obase = (unsigned)((((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * a.cso) * 4);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n0 = (wn * NB + nb) * 32 + 8 * g + 4 * half;
-          const float4 bias = *reinterpret_cast<const float4*>(bl + n0);
-          float v0 = acc[mb][nb][4 * g + 0] + bias.x, v1 = acc[mb][nb][4 * g + 1] + bias.y;
-          float v2 = acc[mb][nb][4 * g + 2] + bias.z, v3 = acc[mb][nb][4 * g + 3] + bias.w;
-          if (!a.norelu) {
-            v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+          for (int g = 0; g < 4; ++g) {
+            const int n0 = nl + nb * 32 + 8 * g;
+            const float4 bias = *reinterpret_cast<const float4*>(bl + n0);
+            f32x4b v;
+            v.x = fmaxf(acc[mb][nb][4 * g + 0] + bias.x, floor_);
+            v.y = fmaxf(acc[mb][nb][4 * g + 1] + bias.y, floor_);
+            v.z = fmaxf(acc[mb][nb][4 * g + 2] + bias.z, floor_);
+            v.w = fmaxf(acc[mb][nb][4 * g + 3] + bias.w, floor_);
+            const bool on = live & (CMIDP == C::N || n0 < CMIDP);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, (int)(on ? obase + n0 * 4 : 0xfffffff0u), 0, 0);
           }
-          if (n0 < CMIDP) {
-            if (a.out_f32) {
-              if (live) *reinterpret_cast<float4*>(static_cast<float*>(a.out) + opix * a.cso + n0) = make_float4(v0, v1, v2, v3);
-            } else {
+      }
+    } else {
+      FPC_LDS_BARRIER();   // phase 2 (or the last chunk) has read the region
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = ml + mb * 32;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n0 = nl + nb * 32 + 8 * g;
+            const float4 bias = *reinterpret_cast<const float4*>(bl + n0);
+            const float v0 = fmaxf(acc[mb][nb][4 * g + 0] + bias.x, floor_), v1 = fmaxf(acc[mb][nb][4 * g + 1] + bias.y, floor_);
+            const float v2 = fmaxf(acc[mb][nb][4 * g + 2] + bias.z, floor_), v3 = fmaxf(acc[mb][nb][4 * g + 3] + bias.w, floor_);
+            if (CMIDP == C::N || n0 < CMIDP)
               *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(lds16) + m * (ROWH16 * 16) + n0 * 2) =
                   make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
-            }
           }
-        }
-    }
-    if (!a.out_f32) {
+      }
       FPC_LDS_BARRIER();
       constexpr int C8 = CMIDP / 8;
       constexpr int NE = TH * TW * C8, EIT = (NE + NT - 1) / NT;
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
-        const int e = tid + i * NT;
+        const int e = tl + i * NT;
         const int m = e / C8, c8 = e - m * C8;
         const int py = m / TW, px = m - py * TW;
         const int y = oyb + py, x = oxb + px;
-        if ((NE % NT == 0 || e < NE) && y < a.Ho && x < a.Wo) {
-          const size_t opix = (size_t)(b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0;
-          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(a.out) + opix * a.cso + c8 * 8) = lds16[m * ROWH16 + c8];
-        }
+        const bool on = (NE % NT == 0 || e < NE) & (y < a.Ho) & (x < a.Wo);
+        const unsigned off = (unsigned)((((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * a.cso + c8 * 8) * 2);
+        const int mm = (NE % NT == 0 || e < NE) ? m : 0;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&lds16[mm * ROWH16 + c8]), orsrc, (int)(on ? off : 0xfffffff0u), 0, 0);
       }
     }
   }
   FPC_STAMP(5)
+  cur = nxt;
+  }
 }
 
 }  // namespace fpc

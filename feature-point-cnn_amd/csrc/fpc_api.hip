@@ -207,7 +207,7 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 #define FPC_BF16_KINDS(X)                                                                   \
   X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
   X(F620_s2_K16_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)   \
-  X(F620_s1_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 32, 2, 2, 2, 2, 128)   \
+  X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
   X(F620_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)     \
   X(F320_s2_K32_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)   \
@@ -337,6 +337,7 @@ struct fpc_ctx {
   hipEvent_t ev_fork = nullptr;
   int min_sub = 8;                   // smallest sub-batch worth its own stream (FPC_MIN_SUB); calls below twice this take the latency plan
   int num_cus = 256;
+  int fkind_blocks_per_cu[64] = {};   // resident workgroups per CU of every bf16 / split-operand instance (fpc_create)
   int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
   bool xcd_order = true;             // FPC_XCD_ORDER=0: plain tile order in the persistent Winograd kernel
   int nms_passes = 2;
@@ -868,7 +869,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
   add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
-  add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K32_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
   add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
   add_fblock(c, {"detector.layer.1", FK_F620_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
   {
@@ -882,8 +883,8 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
     add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K32_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
     add_fblock(c, {"descriptor.layer_in.1", FK_F320_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
     add_fconvT(c, FK_F620_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
-    add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K32_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K32_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
   }
 }
 
@@ -2099,7 +2100,13 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             c->diag_n = a.tiles_x * a.tiles_y * n;
           }
 #endif
-        g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
+        if (g_fkinds[op.fkind].planes == 1) {   // block_bf16_kernel: persistent grid, a multiple of 8 (block_bf16.h)
+          a.total_tiles = a.tiles_x * a.tiles_y * n;
+          const int g = std::min((a.total_tiles + 7) / 8 * 8, std::max(8, c->fkind_blocks_per_cu[op.fkind] * c->num_cus / 8 * 8));
+          g_fkinds[op.fkind].launch(a, dim3(g), sb.st);
+        } else {
+          g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
+        }
         break;
       }
       case OP_VCONV0: {
@@ -2449,8 +2456,18 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     HIPCHECK(hipFuncSetAttribute(g_wkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_wkinds[k].lds_bytes));
   for (int k = 0; k < BK_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_bkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bkinds[k].lds_bytes));
-  for (int k = 0; k < FK_COUNT; ++k)
+  static_assert(FK_COUNT <= 64, "fpc_ctx::fkind_blocks_per_cu");
+  for (int k = 0; k < FK_COUNT; ++k) {
     HIPCHECK(hipFuncSetAttribute(g_fkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_fkinds[k].lds_bytes));
+    int nb = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_fkinds[k].fn, g_fkinds[k].WM * g_fkinds[k].WN * 64, g_fkinds[k].lds_bytes));
+    c->fkind_blocks_per_cu[k] = std::max(1, nb);
+#ifdef FPC_DIAG
+    hipFuncAttributes fa{};
+    hipFuncGetAttributes(&fa, g_fkinds[k].fn);
+    fprintf(stderr, "[diag] %s: lds %d B, regs %d, scratch %zu, occupancy %d blocks/CU\n", g_fkinds[k].name, g_fkinds[k].lds_bytes, fa.numRegs, fa.localSizeBytes, nb);
+#endif
+  }
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                12 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<1>::LDS_BYTES));
