@@ -2205,14 +2205,17 @@ static void run_nms(fpc_ctx* c, const Sub& sb) {
 
 static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
   LaunchTimer t(c, op_index(c, OP_DESC), sb.st, sb.n);
+  // persistent grid, a multiple of 8 (kernels_misc.h): eight workgroups of four waves per CU
+  const int by_xcd = sb.n >= 8;
+  const int G = std::max(8, c->num_cus * 8 / 8 * 8);
   if (c->D == 256)
-    hipLaunchKernelGGL(descriptor_kernel<4>, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
+    hipLaunchKernelGGL(descriptor_kernel<4>, dim3(G), dim3(256), 0, sb.st,
                        dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 256, 256, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
-                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 256);
+                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 256, sb.n, by_xcd);
   else
-    hipLaunchKernelGGL(descriptor_kernel<2>, dim3((c->cap + 3) / 4, sb.n), dim3(256), 0, sb.st,
+    hipLaunchKernelGGL(descriptor_kernel<2>, dim3(G), dim3(256), 0, sb.st,
                        dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
-                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128);
+                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128, sb.n, by_xcd);
 }
 
 // Splits [0,n) over the ctx's streams; aux streams fork from / join into the main stream.

@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
 // One keypoint per wave: `base` = the frame's NHWC map + VPL * lane, (gx, gy) the grid coordinates in [-1, 1].
 template <int VPL>  // values per lane: 2 (D = 128, python net) or 4 (D = 256, cpp/src/settings.h:25)
 __device__ __forceinline__ void descriptor_sample(const float* base, int cs, int Hc, int Wc, float gx, float gy, float* dst) {
+#pragma clang fp contract(off)   // products and sums rounded separately, as grid_sample's C++ and the oracle do
   const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
   const float iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
   const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), x1 = x0 + 1, y1 = y0 + 1;
@@ -1031,19 +1032,22 @@ __device__ __forceinline__ void descriptor_sample(const float* base, int cs, int
   float v[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) v[i] = 0.f;
+  // (no branch: a corner outside the map is read at a clamped position with weight 0 -- the same sums, and the loads of
+  // two keypoints handled back to back can be in flight together)
   auto corner = [&](bool ok, int yy, int xx, float wgt) {
-    if (!ok) return;
-    const float* q = base + (size_t)(yy * Wc + xx) * cs;
+    const int yc = min(max(yy, 0), Hc - 1), xc = min(max(xx, 0), Wc - 1);
+    const float wg = ok ? wgt : 0.f;
+    const float* q = base + (size_t)(yc * Wc + xc) * cs;
     if (VPL == 2) {
       const float2 t = *reinterpret_cast<const float2*>(q);
-      v[0] += t.x * wgt;
-      v[1] += t.y * wgt;
+      v[0] += t.x * wg;
+      v[1] += t.y * wg;
     } else {
       const float4 t = *reinterpret_cast<const float4*>(q);
-      v[0] += t.x * wgt;
-      v[1] += t.y * wgt;
-      v[VPL - 2] += t.z * wgt;
-      v[VPL - 1] += t.w * wgt;
+      v[0] += t.x * wg;
+      v[1] += t.y * wg;
+      v[VPL - 2] += t.z * wg;
+      v[VPL - 1] += t.w * wg;
     }
   };
   corner(vy0 && vx0, y0, x0, wnw);
@@ -1062,20 +1066,33 @@ __device__ __forceinline__ void descriptor_sample(const float* base, int cs, int
     *reinterpret_cast<float4*>(dst) = make_float4(v[0] / nrm, v[1] / nrm, v[VPL - 2] / nrm, v[VPL - 1] / nrm);
 }
 
+// grid (G), G a multiple of 8: a persistent walk.  The keypoints of a frame come in order of confidence, i.e. in no
+// spatial order, and every one reads four 512-byte cells of the frame's descriptor map: with the workgroups of ALL
+// eight XCDs on the same frame, each XCD's L2 fetched nearly the whole map of every frame (2.1 GB of L2 misses per 64 HD
+// frames by the PMC counters for 0.47 GB of maps), and the launch held one workgroup per four slots of the CAPACITY
+// (590 k workgroups at HD, most of them leaving at once).  Here XCD k -- the workgroups with blockIdx.x & 7 == k --
+// takes the frames b = k, k + 8, ... one after the other (by_xcd; with fewer than 8 frames all XCDs share each frame),
+// and a workgroup strides over the frame's actual keypoints.
 template <int VPL>
 __global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
                                                          const int32_t* count, const int32_t* xy, int cap,
-                                                         float* out) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int K = min(count[b], cap);
-  if (k >= K) return;
-  const int px = xy[((size_t)b * cap + k) * 2], py = xy[((size_t)b * cap + k) * 2 + 1];
-  const float gx = (float)((double)px / ((double)W / 2.) - 1.);
-  const float gy = (float)((double)py / ((double)H / 2.) - 1.);
-  descriptor_sample<VPL>(dmap + (size_t)b * Hc * Wc * cs + VPL * lane, cs, Hc, Wc, gx, gy,
-                         out + ((size_t)b * cap + k) * (64 * VPL) + VPL * lane);
+                                                         float* out, int nframes, int by_xcd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int b0 = by_xcd ? xcd : 0, bstep = by_xcd ? 8 : 1;
+  const int k0 = (by_xcd ? slot : (int)blockIdx.x) * 4 + wave, kstep = (by_xcd ? nslots : (int)gridDim.x) * 4;
+  for (int b = b0; b < nframes; b += bstep) {
+    const int K = min(count[b], cap);
+    const float* base = dmap + (size_t)b * Hc * Wc * cs + VPL * lane;
+    for (int k = k0; k < K; k += 2 * kstep) {   // two keypoints per trip: their requests overlap
+      const int kb = k + kstep < K ? k + kstep : k;   // (the last trip may do the same keypoint twice)
+      const int2 pa = *reinterpret_cast<const int2*>(xy + ((size_t)b * cap + k) * 2), pb = *reinterpret_cast<const int2*>(xy + ((size_t)b * cap + kb) * 2);
+      const float gxa = (float)((double)pa.x / ((double)W / 2.) - 1.), gya = (float)((double)pa.y / ((double)H / 2.) - 1.);
+      const float gxb = (float)((double)pb.x / ((double)W / 2.) - 1.), gyb = (float)((double)pb.y / ((double)H / 2.) - 1.);
+      descriptor_sample<VPL>(base, cs, Hc, Wc, gxa, gya, out + ((size_t)b * cap + k) * (64 * VPL) + VPL * lane);
+      descriptor_sample<VPL>(base, cs, Hc, Wc, gxb, gyb, out + ((size_t)b * cap + kb) * (64 * VPL) + VPL * lane);
+    }
+  }
 }
 
 // get_descriptors on its own (netutils.py:103-121): K caller-provided points (x, y) as float64 -- the reference's
