@@ -2153,13 +2153,13 @@ static Sub on(const Sub& sb, hipStream_t st) {
   return r;
 }
 
-static void run_softmax(fpc_ctx* c, const Sub& sb) {
+static void run_softmax(fpc_ctx* c, const Sub& sb, bool dense_map = true) {
   const size_t HW = (size_t)c->H * c->W;
   hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
   LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st, sb.n);
   hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)12 * c->W * sizeof(float), sb.st,
                      c->lg + (size_t)sb.f0 * c->Hc * c->Wc * c->lgcs, c->lgcs, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
-                     c->prob + sb.f0 * HW, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
+                     dense_map ? c->prob + sb.f0 * HW : nullptr, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
 }
 
 static void run_nms(fpc_ctx* c, const Sub& sb) {
@@ -2259,7 +2259,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, in
   if (de && upto && c->nms_aside && !sb.small && sb.side) {
     // detector head and softmax in line; the (latency-bound, few-CU) NMS on the side stream next to the descriptor head
     run_network(c, frames, sb, 1, sb.st);
-    run_softmax(c, sb);
+    run_softmax(c, sb, !upto);
     hipEventRecord(sb.ev_enc, sb.st);
     hipStreamWaitEvent(sb.side, sb.ev_enc, 0);
     run_nms(c, on(sb, sb.side));
@@ -2271,7 +2271,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, in
   }
   if (!de || !(c->split_heads || sb.small) || !sb.side) {
     run_network(c, frames, sb, 1, sb.st);
-    run_softmax(c, sb);
+    run_softmax(c, sb, !upto);
     if (upto) run_nms(c, sb);
     if (de) {
       run_network(c, frames, sb, 2, sb.st);
@@ -2283,7 +2283,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, in
   hipStreamWaitEvent(sb.side, sb.ev_enc, 0);
   const Sub det = on(sb, sb.side);
   run_network(c, frames, sb, 1, sb.side);
-  run_softmax(c, det);
+  run_softmax(c, det, !upto);
   if (upto) run_nms(c, det);
   hipEventRecord(sb.ev_det, sb.side);
   run_network(c, frames, sb, 2, sb.st);

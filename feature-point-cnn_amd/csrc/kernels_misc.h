@@ -359,19 +359,29 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
     }
   }
   __syncthreads();
+  // write-out, four pixels per thread and trip (16-byte LDS reads and stores: as single floats this loop was 80 store
+  // instructions per thread at HD); `prob` is NULL in fpc_detect, whose callers never see the dense map (a third of the
+  // kernel's bytes)
   const size_t fbase = (size_t)b * H * W + (size_t)i * 8 * W;
-  for (int k = tid; k < 8 * W; k += 256) {         // 8*W is a multiple of 64: whole waves
-    const float p = strip[k];
-    const bool c = p >= thresh;
-    prob[fbase + k] = p;
-    nmsmap[fbase + k] = c ? nms_state_word(p) : 0u;
-    const unsigned long long mask = __ballot(c);
-    if (mask) {
-      int off = 0;
-      if (lane == 0) off = atomicAdd(&s_cnt, __popcll(mask));
-      off = __shfl(off, 0);
-      if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (unsigned short)k;
+  for (int k4 = tid; k4 < 2 * W; k4 += 256) {      // 8 W / 4 groups; 2 W is a multiple of 16, not always of 64
+    const float4 p4 = *reinterpret_cast<const float4*>(strip + 4 * k4);
+    const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+    uint4 st;
+    unsigned* sw = &st.x;
+    if (prob) *reinterpret_cast<float4*>(prob + fbase + 4 * k4) = p4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool c = pv[u] >= thresh;
+      sw[u] = c ? nms_state_word(pv[u]) : 0u;
+      const unsigned long long mask = __ballot(c);
+      if (mask) {
+        int off = 0;
+        if (lane == __ffsll((long long)mask) - 1) off = atomicAdd(&s_cnt, __popcll(mask));
+        off = __shfl(off, __ffsll((long long)mask) - 1);
+        if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (unsigned short)(4 * k4 + u);
+      }
     }
+    *reinterpret_cast<uint4*>(nmsmap + fbase + 4 * k4) = st;
   }
   __syncthreads();
   const int n = s_cnt;
