@@ -43,6 +43,7 @@ struct BlockArgs {
   int k8_h, k8_x;        // k8_x == 0: identity shortcut
   float* out;
   int cso, Ho, Wo, tiles_x, tiles_y, nstore, frame0;
+  unsigned x_bytes;      // bytes of the input tensor from x on (buffer descriptor range)
 #ifdef FPC_DIAG
   unsigned long long* stamps;  // diagnostic build only: 8 words per workgroup
 #endif
@@ -94,27 +95,39 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   const float4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
 
   const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
-  float4 stage[ITER];
+  // The halo chunk through a buffer descriptor: a position outside the frame (or a chunk past the last one) gets an
+  // offset beyond the descriptor's range and comes back as zeros from the hardware's bounds check, and an element past
+  // the halo is stored to the skew column of its last pixel -- no branch between a request and its use (with one
+  // `if` per element the compiler waited for EVERY outstanding request at each of them: block_bf16.h has the numbers).
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v stage[ITER];   // (vector values: an array of float4 structs is not promoted to registers)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const unsigned xbase = (unsigned)(((b * a.H + iy0) * a.W + ix0) * a.csx * 4);   // mod 2^32; exact for in-frame pixels
   auto load_chunk = [&](int chunk) {
+    const int wlim = chunk < a.nchunk ? a.W : 0;   // nothing is in range past the last chunk
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int e = tid + i * NT;
       const int pix = e / KC4, c4 = e - pix * KC4;
       const int hy = pix / HW, hx = pix - hy * HW;
       const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = (NV % NT == 0 || e < NV) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const size_t off = ok ? ((size_t)(b * a.H + iy) * a.W + ix) * a.csx + chunk * KC + c4 * 4 : 0;
-      float4 v = *reinterpret_cast<const float4*>(a.x + off);
-      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      stage[i] = v;
+      const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)wlim) & (hy < HH);   // (& not &&: no branch)
+      unsigned off = xbase + (unsigned)(((hy * a.W + hx) * a.csx + chunk * KC + c4 * 4) * 4);
+      asm volatile("" : "+v"(off));   // computed for every lane: as a conditional the compiler branches around it
+      stage[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : 0xfffffff0u), 0, 0));
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int e = tid + i * NT;
-      const int pix = e / KC4, c4 = e - pix * KC4;
-      if (NV % NT == 0 || e < NV) lds4[pix * ROW4 + c4] = stage[i];
+      int pix = e / KC4, c4 = e - pix * KC4;
+      if (NV % NT != 0) {
+        const bool in = e < NV;
+        pix = in ? pix : HH * HW - 1;
+        c4 = in ? c4 : KC4;
+      }
+      *reinterpret_cast<f32x4v*>(&lds4[pix * ROW4 + c4]) = stage[i];
     }
   };
 
@@ -136,10 +149,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
   wp += stepstride;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    if (chunk) FPC_LDS_BARRIER();
+    FPC_LDS_BARRIER();
     store_chunk();
     FPC_LDS_BARRIER();
-    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);
+    load_chunk(chunk + 1);
     if (chunk == 0) { FPC_STAMP(1) }
     // A fragments run one step ahead of the MFMAs that consume them (LDS latency would
     // otherwise sit between every group of MFMAs), B fragments two steps ahead.

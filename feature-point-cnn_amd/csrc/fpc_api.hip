@@ -206,6 +206,8 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
 #define FPC_BF16_KINDS(X)                                                                   \
   X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
+  X(F1616_s1_K32_C64, block_bf16_kernel, BlockBfCfg, 1, 16, 16, 1, 3, 32, 4, 1, 2, 2, 64)  \
+  X(F816_s1_K32_C64w, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 32, 2, 1, 2, 2, 64)   \
   X(F620_s2_K16_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
@@ -535,6 +537,7 @@ static void add_block(fpc_ctx* c, const BlockSpec& s, size_t* blob_off) {
   const int nbt = k.WN * k.NB, K8 = k.KC / 8;
   a.x = s.x;
   a.csx = s.csx;
+  a.x_bytes = (unsigned)std::min<size_t>((size_t)c->B * s.H * s.W * s.csx * 4, 0xffffff00u);
   a.nchunk = s.cin_pad / k.KC;
   a.H = s.H;
   a.W = s.W;
@@ -866,8 +869,10 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   const int H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
   const bool de = c->cfg.descriptor_enabled != 0;
   bf16_t* feat = reinterpret_cast<bf16_t*>(c->cat) + 128;
-  add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
-  add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
+  const char* l1e = getenv("FPC_BF16_L1");
+  const FKind l1k = !l1e ? FK_F816_s1_K64_C64 : atoi(l1e) == 1 ? FK_F1616_s1_K32_C64 : atoi(l1e) == 2 ? FK_F816_s1_K32_C64w : FK_F816_s1_K64_C64;
+  add_fblock(c, {"encoder.layer1.0", l1k, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
+  add_fblock(c, {"encoder.layer1.1", l1k, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
   add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
   add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
   add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
@@ -2350,8 +2355,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   if (cfg->cell != 8 || cfg->height < 16 || cfg->width < 16 || cfg->height % mult || cfg->width % mult ||
       cfg->max_batch < 1 || cfg->nms_dist < 0 || cfg->nms_dist > 64 || cfg->border_remove < 0 ||
       (long long)cfg->height * cfg->width >= (1ll << 30) ||
-      // FPC_BF16 addresses a tensor of the batch with 32-bit byte offsets (the widest: 8 bytes per frame pixel)
-      (cfg->dtype == FPC_BF16 && (long long)cfg->max_batch * cfg->height * cfg->width >= (1ll << 28)) ||
+      // the kernels address a tensor of the whole batch with 32-bit byte offsets (the widest: 16 bytes per frame pixel)
+      (long long)cfg->max_batch * cfg->height * cfg->width >= (1ll << 28) ||
       cfg->width > 3328)  // softmax_d2s_kernel keeps an 8 x W strip (48 W bytes) in the 160 KB of LDS
     return FPC_E_INVALID;
   int ndev = 0;
