@@ -134,7 +134,10 @@ int fpc_default_config(fpc_config* cfg);
 
 /* ~ SuperPoint::SuperPoint (cpp/src/superpoint.cc:9-66) / InferenceWrapper.__init__
  * (python/src/inferencewrapper.py:13-27) minus the file parsing: allocates the
- * device workspace for max_batch frames. */
+ * device workspace for max_batch frames.  FPC_E_INVALID for a geometry the kernels cannot tile (height / width below
+ * 16 or not a multiple of the network's stride, width above 3328, 2^30 pixels or more per frame) and for
+ * max_batch * height * width >= 2^28 (the kernels address the tensors of a batch with 32-bit byte offsets, up to 16
+ * bytes per frame pixel: 64 frames of 1280x960 are 2^26.2; larger jobs run as several calls or contexts). */
 int fpc_create(fpc_ctx** out, const fpc_config* cfg);
 void fpc_destroy(fpc_ctx* ctx);
 

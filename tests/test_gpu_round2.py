@@ -159,6 +159,10 @@ def test_threshold_zero_and_exact_zeros_in_the_map(torch_gpu):
         with pytest.raises(_lib.FpcError) as ei:
             engine(h, w, conf_thresh=bad)
         assert ei.value.code == -1
+    # a batch whose tensors 32-bit byte offsets cannot address is refused at fpc_create, before any allocation
+    with pytest.raises(_lib.FpcError) as ei:
+        engine(960, 1280, b=256)
+    assert ei.value.code == -1
 
 
 def test_get_points_across_the_slices_of_the_candidate_list(torch_gpu):
