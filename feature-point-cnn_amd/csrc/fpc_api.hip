@@ -206,12 +206,11 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
 #define FPC_BF16_KINDS(X)                                                                   \
   X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
-  X(F1616_s1_K32_C64, block_bf16_kernel, BlockBfCfg, 1, 16, 16, 1, 3, 32, 4, 1, 2, 2, 64)  \
-  X(F816_s1_K32_C64w, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 32, 2, 1, 2, 2, 64)   \
   X(F620_s2_K16_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
   X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
   X(F620_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)     \
+  X(F620_s1_K64_C80w, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 80)   \
   X(F320_s2_K32_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)   \
   X(F320_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)   \
   X(F620_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)   \
@@ -869,13 +868,16 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   const int H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8, H16 = H / 16, W16 = W / 16;
   const bool de = c->cfg.descriptor_enabled != 0;
   bf16_t* feat = reinterpret_cast<bf16_t*>(c->cat) + 128;
-  const char* l1e = getenv("FPC_BF16_L1");
-  const FKind l1k = !l1e ? FK_F816_s1_K64_C64 : atoi(l1e) == 1 ? FK_F1616_s1_K32_C64 : atoi(l1e) == 2 ? FK_F816_s1_K32_C64w : FK_F816_s1_K64_C64;
-  add_fblock(c, {"encoder.layer1.0", l1k, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
-  add_fblock(c, {"encoder.layer1.1", l1k, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
+  // (layer1 measured the same 0.53 ms per 64 HD frames on 8 x 16 tiles of 2 x 2 waves x (2 x 1) blocks, 16 x 16 tiles of
+  // 4 x 1 waves x (2 x 2) and 8 x 16 tiles of 2 x 1 waves x (2 x 2): not a matter of the blocking)
+  add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
+  add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
   add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
   add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
-  add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
+  // detector.layer.0 on the 2 x 2 blocking of the 128-wide layers (N = 128 for 65 channels: a quarter of the MFMAs on
+  // zeros, but four MFMAs per four operand fetches instead of three per four: 0.47 -> 0.40 ms per 64 HD frames);
+  // layer.1 (K = 80) measured the same on both shapes and keeps the narrower one
+  add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80w, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
   add_fblock(c, {"detector.layer.1", FK_F620_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
   {
     Op op;
