@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: VGA SuperPoint forward + NMS + descriptors, frames/s.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 30      (the defaults: 0.4 s timed after 0.1 s of warm-up, so that the
+                                                          clock has settled; any K / W works)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the whole hot path (fpc_detect: network, exp-softmax,
@@ -291,8 +292,8 @@ def roofline_entry(mode, sym, st, step_ms, traffic_table):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FPC_BENCH_CONTEXTS", "1")),
                     help="fpc contexts used round-robin (double buffering: batch k+1 starts while batch k drains)")
