@@ -164,6 +164,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 
   TileP cur = tile_params(t_first + (int)(blockIdx.x >> 3));
   load_chunk(cur, 0);
+  // conv1's (+ the shortcut's) fragment ring, see phase 1.  The stream is read CIRCULARLY: the last D steps of a tile
+  // request steps 0 .. D - 1 again, which are the next tile's first -- no L2 round trip at the head of a tile.
+  constexpr int NS = 10 * K16;          // steps of a chunk: 9 taps of conv1 and the shortcut, K16 each
+  constexpr int D = NS % 4 == 0 ? 4 : 5;   // fragment ring: D steps ahead
+  static_assert(NS % D == 0, "the ring position of a step must not depend on the chunk");
+  u32x4 ring[D][NB];
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint4*>(a.w1), 0, (int)((unsigned)(a.nchunk * NS + 2) * (unsigned)(stepstride * 16)), 0x00020000);
+  const unsigned wlane = (unsigned)((wn * NB) * 64 + lane) * 16u;
+  const int wtotal = a.nchunk * NS * stepstride * 16;
+  int wstep = 0;   // (scalar) byte offset of the next step to request
+  if (a.ntaps == 9) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        ring[d][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + nb * 1024), wstep, 0));
+      wstep += stepstride * 16;
+    }
+  }
   for (int tcur = t_first + (int)(blockIdx.x >> 3); tcur < t_end; tcur += per) {
   const int b = cur.b, ty = cur.ty, tx = cur.tx;
   const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;   // (the ConvTranspose phases' path below)
@@ -185,27 +205,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   // pixel stride (32 cache lines per request): 23 k of layer_out.0's 85 k cycles per tile for 3 k cycles of MFMAs, and the
   // identity's loads stood at the head of the epilogue (in-kernel stamps).  Its fragments follow the chunk's conv1
   // fragments in the w1 stream ("tap 9").
-  constexpr int NS = 10 * K16;
-  constexpr int D = NS % 4 == 0 ? 4 : 5;   // fragment ring: D steps ahead
-  static_assert(NS % D == 0, "the ring position of a step must not depend on the chunk");
   if (a.ntaps == 9) {
     // Two steps of fragments ahead -- 256 MFMA cycles of this wave -- do not cover an L2 round trip, and the LDS read of a
     // step's pixels sat right in front of its MFMAs.  Here the chunk's steps are unrolled, fragments run D steps ahead
     // in a register ring whose slots are compile-time names (through a buffer descriptor too: the lane's offset in a
     // VGPR that never changes, the step in the scalar offset, and a request past the last step returns zeros), and a
     // step's pixels are read while the previous step's MFMAs run.
-    u32x4 ring[D][NB];
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4*>(a.w1), 0, (int)((unsigned)(a.nchunk * NS + 2) * (unsigned)(stepstride * 16)), 0x00020000);
-    const unsigned wlane = (unsigned)((wn * NB) * 64 + lane) * 16u;
-    int wstep = 0;   // (scalar) byte offset of the next step to request
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        ring[d][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + nb * 1024), wstep, 0));
-      wstep += stepstride * 16;
-    }
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
       FPC_LDS_BARRIER();   // the previous chunk's pixels have been read
       store_chunk();
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         for (int nb = 0; nb < NB; ++nb)
           ring[st % D][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + nb * 1024), wstep, 0));
         wstep += stepstride * 16;
+        wstep = wstep == wtotal ? 0 : wstep;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
         __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the ring's requests to just before their use)
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     FPC_LDS_BARRIER();
     store_chunk();
     FPC_LDS_BARRIER();
-    if (chunk + 1 < a.nchunk) load_chunk(cur, chunk + 1);
+    load_chunk(cur, chunk + 1);   // (all zeros past the last chunk: no branch between a request and its use)
     for (int tap = 0; tap < a.ntaps; ++tap) {
       const int toff = a.tapoff16[tap];
 #pragma unroll
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (bf16)
     // phase 2's first D2 steps of fragments are requested before h is written and land behind that.
     constexpr int KH = CMIDP / 16, D2 = KH < 4 ? KH : 4;
-    u32x4 ring[D2][NB];
+    u32x4 ring2[D2][NB];
     const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(a.w2), 0, (int)((unsigned)(KH + 2) * (unsigned)(stepstride * 16)), 0x00020000);
     const unsigned wlane2 = (unsigned)((wn * NB) * 64 + lane) * 16u;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     for (int d = 0; d < D2; ++d)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        ring[d][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc2, (int)(wlane2 + nb * 1024), d * stepstride * 16, 0));
+        ring2[d][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc2, (int)(wlane2 + nb * 1024), d * stepstride * 16, 0));
     FPC_LDS_BARRIER();
     {
       unsigned char* hl = reinterpret_cast<unsigned char*>(lds16);
@@ -349,12 +355,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[k % D2][nb]),
+            acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring2[k % D2][nb]),
                                                                    __builtin_bit_cast(bf16x8, av[mb]), acc2[mb][nb], 0, 0, 0);
         if (k + D2 < KH) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            ring[k % D2][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc2, (int)(wlane2 + nb * 1024), (k + D2) * stepstride * 16, 0));
+            ring2[k % D2][nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc2, (int)(wlane2 + nb * 1024), (k + D2) * stepstride * 16, 0));
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
