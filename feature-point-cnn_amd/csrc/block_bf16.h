@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     p.tx = t - p.ty * a.tiles_x;
     p.iy0 = p.ty * TH * S - a.pad;
     p.ix0 = p.tx * TW * S - a.pad;
-    p.xbase = (unsigned)(((p.b * a.H + p.iy0) * a.W + p.ix0) * a.csx * 2);   // mod 2^32; exact for in-frame pixels
+    p.xbase = (unsigned)((p.b * a.H + p.iy0) * a.W + p.ix0) * (unsigned)(a.csx * 2);   // unsigned: mod 2^32, exact for in-frame pixels
     return p;
   };
 
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         const int py = m / TW, px = m - py * TW;
         const int y = oyb + py, x = oxb + px;
         const bool live = (m < TH * TW) & (y < a.Ho) & (x < a.Wo);
-        const unsigned obase = (unsigned)((((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * a.cso) * 4);
+        const unsigned obase = (unsigned)((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * (unsigned)(a.cso * 4);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         const int py = m / TW, px = m - py * TW;
         const int y = oyb + py, x = oxb + px;
         const bool on = (NE % NT == 0 || e < NE) & (y < a.Ho) & (x < a.Wo);
-        const unsigned off = (unsigned)((((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * a.cso + c8 * 8) * 2);
+        const unsigned off = (unsigned)((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * (unsigned)(a.cso * 2) + (unsigned)(c8 * 16);
         const int mm = (NE % NT == 0 || e < NE) ? m : 0;
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&lds16[mm * ROWH16 + c8]), orsrc, (int)(on ? off : 0xfffffff0u), 0, 0);
       }

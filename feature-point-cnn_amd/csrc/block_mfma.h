@@ -102,7 +102,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v stage[ITER];   // (vector values: an array of float4 structs is not promoted to registers)
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const unsigned xbase = (unsigned)(((b * a.H + iy0) * a.W + ix0) * a.csx * 4);   // mod 2^32; exact for in-frame pixels
+  const unsigned xbase = (unsigned)((b * a.H + iy0) * a.W + ix0) * (unsigned)(a.csx * 4);   // unsigned: mod 2^32, exact for in-frame pixels
   auto load_chunk = [&](int chunk) {
     const int wlim = chunk < a.nchunk ? a.W : 0;   // nothing is in range past the last chunk
 #pragma unroll

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const Ste
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int iy0 = ty * 32 - 5, ixa = tx * 32 - 8;  // image row of LDS row 0, image column of LDS column 0
     const int hlim = live ? a.H : 0;
-    const unsigned tbase = (unsigned)(((b * CIN * a.H + iy0) * a.W + ixa) * 4);
+    const unsigned tbase = (unsigned)((b * CIN * a.H + iy0) * a.W + ixa) * 4u;   // unsigned: mod 2^32, exact for in-frame pixels
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       // (per-thread constants of element i -- plane, row, column -- are loop invariants the compiler keeps in

@@ -869,7 +869,10 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   const bool de = c->cfg.descriptor_enabled != 0;
   bf16_t* feat = reinterpret_cast<bf16_t*>(c->cat) + 128;
   // (layer1 measured the same 0.53 ms per 64 HD frames on 8 x 16 tiles of 2 x 2 waves x (2 x 1) blocks, 16 x 16 tiles of
-  // 4 x 1 waves x (2 x 2) and 8 x 16 tiles of 2 x 1 waves x (2 x 2): not a matter of the blocking)
+  // 4 x 1 waves x (2 x 2) and 8 x 16 tiles of 2 x 1 waves x (2 x 2): not a matter of the blocking;
+  // single-wave workgroups (4 x 16 tiles, 1 x 1 waves x (2 x 2) blocks: no barrier waits at all) measured 0.55 ms: not
+  // the barriers either.  What these kernels run into is operand delivery: at full MFMA rate a CU's four SIMDs would
+  // pull 64 B/clk of weight fragments from L2 and 64 B/clk of pixels from LDS for a 2 x 2 register blocking.)
   add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
   add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
     const int tyy = t / a.tiles_x, txx = t - tyy * a.tiles_x;
     const int iy0 = tyy * TH - 1, ix0 = txx * TW - 1;
     const int hlim = live ? a.H : 0;                   // nothing is in range for a tile past the end
-    const unsigned base = (unsigned)(((bb * a.H + iy0) * a.W + ix0) * a.csx * 4 + chunk * 64);   // mod 2^32; exact for in-frame pixels
+    const unsigned base = (unsigned)((bb * a.H + iy0) * a.W + ix0) * (unsigned)(a.csx * 4) + (unsigned)(chunk * 64);   // unsigned: mod 2^32, exact for in-frame pixels
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tl + i * NT;
