@@ -1066,5 +1066,23 @@ def test_random_geometries_other_networks_and_modes(torch_gpu):
         la, lb = a.forward(fr)[2], b.forward(fr)[2]
         assert float((la - lb).abs().max()) < BF16_LOGIT_MAX, (h, w)
         assert len(b.detect(fr)) == 3
+        # every layer against the bf16-emulating oracle at these sizes too (partial tiles on every edge of the persistent
+        # kernels' tile walks; the last call ran the same frames)
+        _check_bf16_layers(oracle, b, fr, sd, [0, 2], "%dx%d" % (h, w))
         a.close()
         b.close()
+    # bf16 with a gray plane (stem_pool_bf16_kernel<1>): what the three-channel engine gives on the replicated plane, at bf16
+    # accuracy (the gray stem's weights are the sum over the input channels, rounded once)
+    h, w = 112, 208
+    sd = synth.make_state_dict(77, dustbin_bias=4.0)
+    rgb = np.stack([synth.make_frame(900 + i, h, w, gray=True).transpose(2, 0, 1) for i in range(2)])
+    b3 = engine(h, w, 2, dtype="bf16")
+    b1 = engine(h, w, 2, dtype="bf16", in_channels=1)
+    b3.load_state_dict(sd)
+    b1.load_state_dict(sd)
+    l3, l1 = b3.forward(rgb)[2], b1.forward(np.ascontiguousarray(rgb[:, :1]))[2]
+    assert float((l3 - l1).abs().max()) < BF16_LOGIT_MAX and float((l3 - l1).float().pow(2).mean().sqrt()) < BF16_LOGIT_RMS
+    ov, cos = _overlap_and_cosine(b3.detect(rgb)[0], b1.detect(np.ascontiguousarray(rgb[:, :1]))[0])
+    assert ov >= BF16_KP_OVERLAP and cos >= BF16_DESC_COS
+    b3.close()
+    b1.close()
