@@ -337,25 +337,32 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / Hc, i = blockIdx.x - b * Hc;
   if (tid == 0) s_cnt = 0;
-  // four cells per iteration and wave: their eight loads are in flight together (one cell at a time left every
-  // iteration exposed to a full memory round trip)
+  // Sixteen lanes per cell, four channels each (one 16-byte load; the dustbin a broadcast word): a wave's load covers
+  // four cells, the sum over a cell's channels is a 4-step butterfly inside its sixteen lanes, and a lane's four
+  // probabilities are four neighbouring pixels of the strip (one 16-byte LDS write).  As one wave per cell this phase was
+  // 6 cross-lane steps, 2 exps and 4 one-word LDS writes per lane and CELL.  Four such loads per wave are in flight.
   const float* lrow = logits + (size_t)(b * Hc + i) * Wc * cs;
-  for (int j0 = wave * 4; j0 < Wc; j0 += 16) {
-    float lv[4], ld[4];
+  const int q = lane & 15, gidx = lane >> 4;
+  for (int j0 = wave * 16; j0 < Wc; j0 += 64) {
+    float4 lv[4];
+    float ld[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u < Wc ? j0 + u : Wc - 1;
-      lv[u] = lrow[(size_t)j * cs + lane];
+      const int j = j0 + 4 * u + gidx < Wc ? j0 + 4 * u + gidx : Wc - 1;
+      lv[u] = *reinterpret_cast<const float4*>(lrow + (size_t)j * cs + 4 * q);
       ld[u] = lrow[(size_t)j * cs + 64];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float e = expf(lv[u]);
+      const int j = j0 + 4 * u + gidx;
+      const float e0 = expf(lv[u].x), e1 = expf(lv[u].y), e2 = expf(lv[u].z), e3 = expf(lv[u].w);
       const float ed = expf(ld[u]);
-      float s = e;
+      float s = (e0 + e1) + (e2 + e3);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      if (j0 + u < Wc) strip[(lane >> 3) * W + (j0 + u) * 8 + (lane & 7)] = e / ((s + ed) + .00001f);
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      const float den = (s + ed) + .00001f;
+      if (j < Wc)
+        *reinterpret_cast<float4*>(strip + (q >> 1) * W + j * 8 + 4 * (q & 1)) = make_float4(e0 / den, e1 / den, e2 / den, e3 / den);
     }
   }
   __syncthreads();
