@@ -2219,11 +2219,11 @@ static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
   const int by_xcd = sb.n >= 8;
   const int G = std::max(8, c->num_cus * 8 / 8 * 8);
   if (c->D == 256)
-    hipLaunchKernelGGL(descriptor_kernel<4>, dim3(G), dim3(256), 0, sb.st,
+    hipLaunchKernelGGL(descriptor16_kernel<16>, dim3(G), dim3(256), 0, sb.st,
                        dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 256, 256, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
                        c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 256, sb.n, by_xcd);
   else
-    hipLaunchKernelGGL(descriptor_kernel<2>, dim3(G), dim3(256), 0, sb.st,
+    hipLaunchKernelGGL(descriptor16_kernel<8>, dim3(G), dim3(256), 0, sb.st,
                        dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
                        c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128, sb.n, by_xcd);
 }
@@ -3060,7 +3060,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
           case OP_BF16: k = g_fkinds[op->fkind].symbol; break;
           case OP_SOFTMAX: k = "softmax_d2s_kernel"; break;
           case OP_NMS: k = c->nms_one_workgroup ? "nms_rounds_kernel+nms_sort_kernel" : "nms_rounds_kernel+nms_finish_kernel+nms_chunk_sort_kernel+nms_merge_kernel"; break;
-          case OP_DESC: k = "descriptor_kernel"; break;
+          case OP_DESC: k = "descriptor16_kernel"; break;
           case OP_VCONV0: k = "vgg_conv0_kernel"; break;
           case OP_POOL2: k = "maxpool2_kernel"; break;
           case OP_L2NORM: k = "l2norm256_kernel"; break;

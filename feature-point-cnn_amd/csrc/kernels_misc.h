@@ -1090,24 +1090,66 @@ __device__ __forceinline__ void descriptor_sample(const float* base, int cs, int
 // (590 k workgroups at HD, most of them leaving at once).  Here XCD k -- the workgroups with blockIdx.x & 7 == k --
 // takes the frames b = k, k + 8, ... one after the other (by_xcd; with fewer than 8 frames all XCDs share each frame),
 // and a workgroup strides over the frame's actual keypoints.
-template <int VPL>
-__global__ __launch_bounds__(256) void descriptor_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
-                                                         const int32_t* count, const int32_t* xy, int cap,
-                                                         float* out, int nframes, int by_xcd) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// SIXTEEN lanes per keypoint (CPL = D / 16 channels each, 16-byte loads) and four keypoints per wave: a quarter of the
+// instructions per keypoint (one wave per keypoint, descriptor_sample above, spends them on 8-byte loads and a 6-step
+// cross-lane sum for one norm) and four keypoints' requests in flight per wave.  Same per-channel sums in the same order; the sum of
+// squares is taken over a lane's channels first, then a 4-step butterfly inside the sixteen lanes.
+template <int CPL>
+__global__ __launch_bounds__(256) void descriptor16_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
+                                                           const int32_t* count, const int32_t* xy, int cap,
+                                                           float* out, int nframes, int by_xcd) {
+#pragma clang fp contract(off)   // products and sums rounded separately, as grid_sample's C++ and the oracle do
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, sub = lane >> 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int b0 = by_xcd ? xcd : 0, bstep = by_xcd ? 8 : 1;
-  const int k0 = (by_xcd ? slot : (int)blockIdx.x) * 4 + wave, kstep = (by_xcd ? nslots : (int)gridDim.x) * 4;
+  const int k0 = ((by_xcd ? slot : (int)blockIdx.x) * 4 + wave) * 4, kstep = (by_xcd ? nslots : (int)gridDim.x) * 16;
   for (int b = b0; b < nframes; b += bstep) {
     const int K = min(count[b], cap);
-    const float* base = dmap + (size_t)b * Hc * Wc * cs + VPL * lane;
-    for (int k = k0; k < K; k += 2 * kstep) {   // two keypoints per trip: their requests overlap
-      const int kb = k + kstep < K ? k + kstep : k;   // (the last trip may do the same keypoint twice)
-      const int2 pa = *reinterpret_cast<const int2*>(xy + ((size_t)b * cap + k) * 2), pb = *reinterpret_cast<const int2*>(xy + ((size_t)b * cap + kb) * 2);
-      const float gxa = (float)((double)pa.x / ((double)W / 2.) - 1.), gya = (float)((double)pa.y / ((double)H / 2.) - 1.);
-      const float gxb = (float)((double)pb.x / ((double)W / 2.) - 1.), gyb = (float)((double)pb.y / ((double)H / 2.) - 1.);
-      descriptor_sample<VPL>(base, cs, Hc, Wc, gxa, gya, out + ((size_t)b * cap + k) * (64 * VPL) + VPL * lane);
-      descriptor_sample<VPL>(base, cs, Hc, Wc, gxb, gyb, out + ((size_t)b * cap + kb) * (64 * VPL) + VPL * lane);
+    const float* base = dmap + (size_t)b * Hc * Wc * cs + CPL * q;
+    for (int kw = k0; kw < K; kw += kstep) {
+      const bool live = kw + sub < K;
+      const int k = live ? kw + sub : K - 1;
+      const int2 p = *reinterpret_cast<const int2*>(xy + ((size_t)b * cap + k) * 2);
+      const float gx = (float)((double)p.x / ((double)W / 2.) - 1.), gy = (float)((double)p.y / ((double)H / 2.) - 1.);
+      const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
+      const float iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
+      const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), x1 = x0 + 1, y1 = y0 + 1;
+      const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
+      const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
+      const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc, vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
+      float v[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) v[i] = 0.f;
+      const int cy[4] = {y0, y0, y1, y1}, cx[4] = {x0, x1, x0, x1};
+      const float cw[4] = {(vy0 && vx0) ? wnw : 0.f, (vy0 && vx1) ? wne : 0.f, (vy1 && vx0) ? wsw : 0.f, (vy1 && vx1) ? wse : 0.f};
+      float4 t[4][CPL / 4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // a corner outside the map: a clamped position with weight 0
+        const int yc = min(max(cy[c], 0), Hc - 1), xc = min(max(cx[c], 0), Wc - 1);
+        const float4* qp = reinterpret_cast<const float4*>(base + (size_t)(yc * Wc + xc) * cs);
+#pragma unroll
+        for (int i = 0; i < CPL / 4; ++i) t[c][i] = qp[i];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < CPL / 4; ++i) {
+          v[4 * i + 0] += t[c][i].x * cw[c];
+          v[4 * i + 1] += t[c][i].y * cw[c];
+          v[4 * i + 2] += t[c][i].z * cw[c];
+          v[4 * i + 3] += t[c][i].w * cw[c];
+        }
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) ss += v[i] * v[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      const float nrm = sqrtf(ss);
+      if (live) {
+        float4* dst = reinterpret_cast<float4*>(out + ((size_t)b * cap + k) * (16 * CPL) + CPL * q);
+#pragma unroll
+        for (int i = 0; i < CPL / 4; ++i) dst[i] = make_float4(v[4 * i] / nrm, v[4 * i + 1] / nrm, v[4 * i + 2] / nrm, v[4 * i + 3] / nrm);
+      }
     }
   }
 }
