@@ -9,6 +9,7 @@
 // fp32 path.
 #pragma once
 #include "conv_mfma.h"
+#include "nms_word.h"
 
 namespace fpc {
 
@@ -45,6 +46,13 @@ struct BlockBfArgs {
   int cso, out_f32;
   int Ho, Wo, tiles_x, tiles_y, frame0;
   int total_tiles;       // block_bf16_kernel (persistent grid): tiles_x * tiles_y * frames of the launch
+  // fused exp-softmax + depth-to-space + threshold (the detector's last block in fpc_detect; instances whose waves hold
+  // all channels of their pixels): instead of the logits, the NMS state map and the candidate lists are written
+  int softmax;
+  float thresh;
+  uint32_t* nmsmap;      // [frames of the launch][8 Ho][8 Wo], offset to the launch's first frame
+  uint32_t* cand;        // same shape
+  int32_t* ncand;        // [frames of the launch], zeroed by the host
   int OH, OW, oys, oxs, oy0, ox0;   // output pixel = (y*oys + oy0, x*oxs + ox0) in an OH x OW buffer
   int pad;               // halo origin = tile origin * S - pad
   int norelu;            // conv_only: 1 = no ReLU (the last 1x1 of a head of the C++ network)
@@ -377,7 +385,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   // (fp32 outputs -- the logits and the descriptor map -- leave straight from the registers, 16 bytes per lane)
   FPC_STAMP(4)
   const TileP nxt = tile_params(tcur + per);
-  load_chunk(nxt, 0);   // lands behind the epilogue (all zeros past the last tile)
+  bool fused = false;
+  if constexpr (WN == 1 && MB == 1 && NB == 3) fused = a.softmax != 0;
+  if (!fused) load_chunk(nxt, 0);   // lands behind the epilogue (all zeros past the last tile)
   {
     // (stores through a buffer descriptor as well: a dead pixel's offset is out of range and the hardware drops the
     // store -- an `if` around a store is a block boundary, and the compiler drains every outstanding request there,
@@ -388,7 +398,85 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)0xffffff00u, 0x00020000);
     int nl = (wn * NB) * 32 + 4 * half, ml = (wm * MB) * 32 + l31;
     asm volatile("" : "+v"(nl), "+v"(ml));
-    if (a.out_f32) {
+    if (fused) {
+      if constexpr (WN == 1 && MB == 1 && NB == 3) {
+        // exp-softmax over the 65 channels of a cell, dustbin dropped, depth-to-space, threshold (superpoint.py:111-114,
+        // netutils.py:56-75) -- softmax_d2s_kernel's arithmetic on the logits this epilogue would have stored, BIT FOR BIT:
+        // the same expf, the sum of a cell's 64 exps in the same tree (that kernel: lane q of sixteen holds channels
+        // 4 q ..+3, (e0 + e1) + (e2 + e3), then a butterfly over q ^ 8, 4, 2, 1; here q = 8 nb + 2 g + half, so the first
+        // three levels are sums of this lane's own registers and the last one is the partner lane of the other half),
+        // the same (s + ed) + 1e-5 and division.  The 295 MB of fp32 logits per 64 HD frames are neither written nor
+        // read back, and a launch disappears.
+        __shared__ int s_cnt, s_base;
+        unsigned short* s_list = reinterpret_cast<unsigned short*>(lds16);   // [TH * TW * 64] local ids (m << 6 | c)
+        if (tid == 0) s_cnt = 0;
+        FPC_LDS_BARRIER();   // phase 2 has read h; the counter is visible
+        const int m = ml;
+        const int py = m / TW, px = m - py * TW;
+        const int y = oyb + py, x = oxb + px;
+        const bool live = (m < TH * TW) & (y < a.Ho) & (x < a.Wo);
+        const int W8 = a.Wo * 8;
+        const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(a.nmsmap, 0, (int)0xffffff00u, 0x00020000);
+        float e[2][16], P[2][4];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 bias = *reinterpret_cast<const float4*>(bl + nl + nb * 32 + 8 * g);
+            e[nb][4 * g + 0] = expf(fmaxf(acc[0][nb][4 * g + 0] + bias.x, floor_));
+            e[nb][4 * g + 1] = expf(fmaxf(acc[0][nb][4 * g + 1] + bias.y, floor_));
+            e[nb][4 * g + 2] = expf(fmaxf(acc[0][nb][4 * g + 2] + bias.z, floor_));
+            e[nb][4 * g + 3] = expf(fmaxf(acc[0][nb][4 * g + 3] + bias.w, floor_));
+            P[nb][g] = (e[nb][4 * g] + e[nb][4 * g + 1]) + (e[nb][4 * g + 2] + e[nb][4 * g + 3]);
+          }
+        float ed = expf(fmaxf(acc[0][2][0] + bl[64], floor_));   // the dustbin: channel 64 = block 2, register 0 of the half-0 lanes
+        ed = __shfl(ed, l31);
+        const float a0 = P[0][0] + P[1][0], a1 = P[0][1] + P[1][1], a2 = P[0][2] + P[1][2], a3 = P[0][3] + P[1][3];
+        const float b0_ = a0 + a2, b1_ = a1 + a3;
+        float ssum = b0_ + b1_;
+        ssum += __shfl_xor(ssum, 32);
+        const float den = (ssum + ed) + .00001f;
+        const unsigned mapbase = (unsigned)(((b - a.frame0) * a.Ho * 8 + 8 * y) * W8 + 8 * x + 4 * half);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x4 wv;
+            unsigned* wp_ = reinterpret_cast<unsigned*>(&wv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float p = e[nb][4 * g + j] / den;
+              const bool c = live & (p >= a.thresh);
+              wp_[j] = c ? nms_state_word(p) : 0u;
+              const unsigned long long mask = __ballot(c);
+              if (mask) {
+                const int lead = __ffsll((long long)mask) - 1;
+                int off = 0;
+                if (lane == lead) off = atomicAdd(&s_cnt, __popcll(mask));
+                off = __shfl(off, lead);
+                if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (unsigned short)((m << 6) | (nb * 32 + 8 * g + 4 * half + j));
+              }
+            }
+            const unsigned off = (mapbase + (unsigned)((4 * nb + g) * W8)) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(wv, mrsrc, (int)(live ? off : 0xfffffff0u), 0, 0);
+          }
+        FPC_LDS_BARRIER();
+        const int ncl = s_cnt;
+        if (tid == 0 && ncl) s_base = atomicAdd(&a.ncand[b - a.frame0], ncl);   // ONE global atomic per tile
+        FPC_LDS_BARRIER();
+        if (ncl) {
+          uint32_t* dst = a.cand + (size_t)(b - a.frame0) * a.Ho * 8 * W8 + s_base;
+          for (int i = tid; i < ncl; i += NT) {
+            const int id = s_list[i], mm = id >> 6, cc = id & 63;
+            const int yy = oyb + mm / TW, xx = oxb + mm % TW;
+            dst[i] = (uint32_t)((8 * yy + (cc >> 3)) * W8 + 8 * xx + (cc & 7));
+          }
+        }
+        // (the branches above are block boundaries, where the compiler waits for every outstanding request: the next
+        // tile's first halo chunk is requested here, after them)
+        load_chunk(nxt, 0);
+      }
+    } else if (a.out_f32) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int m = ml + mb * 32;

@@ -300,6 +300,7 @@ struct Op {
   int grid_y = 1, grid_z = 1;
   double flops_per_frame = 0;  // algorithmic: 2 * MACs of the real (unpadded) convolution
   double mfma_flops_per_frame = 0;  // issued on the matrix cores (padding included; Winograd: 16/36 of the 3x3)
+  bool fused_softmax_capable = false;   // FPC_BF16's detector.layer.1 (block_bf16.h: fused exp-softmax epilogue)
   double bytes_per_frame = 0;       // algorithmic HBM bytes: the launch's input tensor(s) read once + its output written once
   bool descriptor_branch = false;
 };
@@ -342,6 +343,7 @@ struct fpc_ctx {
   int persist_min_tiles = 1;         // FPC_PERSIST_MIN: tiles per CU from which the Winograd kernel runs persistent (0 = never)
   bool xcd_order = true;             // FPC_XCD_ORDER=0: plain tile order in the persistent Winograd kernel
   int nms_passes = 2;
+  bool fuse_softmax = true;        // !FPC_PLAN_NO_FUSED_SOFTMAX (FPC_BF16's detector.layer.1, block_bf16.h)
   bool nms_one_workgroup = false;  // FPC_PLAN_NMS_ONE_WORKGROUP: round 1's sort (one workgroup per frame) for every frame
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
@@ -882,6 +884,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   // layer.1 (K = 80) measured the same on both shapes and keeps the narrower one
   add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80w, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
   add_fblock(c, {"detector.layer.1", FK_F620_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
+  c->ops.back().fused_softmax_capable = c->fuse_softmax;
   {
     Op op;
     op.type = OP_SOFTMAX;
@@ -1941,6 +1944,7 @@ static hipEvent_t next_event(fpc_ctx* c) {
 struct Sub {
   int f0, n;
   bool small = false;              // the whole call is a few frames: the latency plan (heads side by side, fused layer_in.1)
+  bool fuse_softmax = false;       // run_network(which = 1): the detector's last block also does exp-softmax / depth-to-space / threshold
   hipStream_t st;                  // encoder, descriptor head, descriptor sampling
   hipStream_t side = nullptr;      // detector head + NMS, concurrent with the descriptor head
   hipEvent_t ev_enc = nullptr, ev_det = nullptr;
@@ -2112,6 +2116,15 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
 #endif
         if (g_fkinds[op.fkind].planes == 1) {   // block_bf16_kernel: persistent grid, a multiple of 8 (block_bf16.h)
           a.total_tiles = a.tiles_x * a.tiles_y * n;
+          if (sb.fuse_softmax && op.fused_softmax_capable) {
+            const size_t HW = (size_t)c->H * c->W;
+            hipMemsetAsync(c->ncand + f0, 0, sizeof(int32_t) * n, sb.st);
+            a.softmax = 1;
+            a.thresh = c->cfg.conf_thresh;
+            a.nmsmap = c->nmsmap + f0 * HW;
+            a.cand = c->cand + f0 * HW;
+            a.ncand = c->ncand + f0;
+          }
           const int g = std::min((a.total_tiles + 7) / 8 * 8, std::max(8, c->fkind_blocks_per_cu[op.fkind] * c->num_cus / 8 * 8));
           g_fkinds[op.fkind].launch(a, dim3(g), sb.st);
         } else {
@@ -2264,12 +2277,16 @@ static int for_each_sub(fpc_ctx* c, int n, F&& body) {
 // The whole path for one sub-batch.  The detector head and its post-processing (latency-bound,
 // few CUs) run on a side stream next to the descriptor head (MFMA-bound); both only need the
 // encoder output.  `upto`: 0 = dense maps only (fpc_forward), 1 = keypoints + descriptors.
-static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, int upto) {
+static void run_path(fpc_ctx* c, const float* frames, const Sub& sb0, bool de, int upto) {
+  // fpc_detect in FPC_BF16: the detector's last block writes the NMS state map and the candidate lists itself (the
+  // logits and the dense probability map, which only fpc_forward's callers see, are not produced)
+  Sub sb = sb0;
+  for (const Op& op : c->ops) sb.fuse_softmax |= upto && op.fused_softmax_capable;
   run_network(c, frames, sb, 0, sb.st);
   if (de && upto && c->nms_aside && !sb.small && sb.side) {
     // detector head and softmax in line; the (latency-bound, few-CU) NMS on the side stream next to the descriptor head
     run_network(c, frames, sb, 1, sb.st);
-    run_softmax(c, sb, !upto);
+    if (!sb.fuse_softmax) run_softmax(c, sb, !upto);
     hipEventRecord(sb.ev_enc, sb.st);
     hipStreamWaitEvent(sb.side, sb.ev_enc, 0);
     run_nms(c, on(sb, sb.side));
@@ -2281,7 +2298,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, in
   }
   if (!de || !(c->split_heads || sb.small) || !sb.side) {
     run_network(c, frames, sb, 1, sb.st);
-    run_softmax(c, sb, !upto);
+    if (!sb.fuse_softmax) run_softmax(c, sb, !upto);
     if (upto) run_nms(c, sb);
     if (de) {
       run_network(c, frames, sb, 2, sb.st);
@@ -2293,7 +2310,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb, bool de, in
   hipStreamWaitEvent(sb.side, sb.ev_enc, 0);
   const Sub det = on(sb, sb.side);
   run_network(c, frames, sb, 1, sb.side);
-  run_softmax(c, det, !upto);
+  if (!sb.fuse_softmax) run_softmax(c, det, !upto);
   if (upto) run_nms(c, det);
   hipEventRecord(sb.ev_det, sb.side);
   run_network(c, frames, sb, 2, sb.st);
@@ -2415,6 +2432,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_WINOGRAD_GEN")) c->winograd_gen = atoi(e) == 1 ? 1 : 2;
     c->latency_tiles = !(pf & FPC_PLAN_NO_LATENCY_TILES);
     if (const char* e = getenv("FPC_LATENCY_TILES")) c->latency_tiles = atoi(e) != 0;
+    c->fuse_softmax = !(pf & FPC_PLAN_NO_FUSED_SOFTMAX);
+    if (const char* e = getenv("FPC_FUSE_SOFTMAX")) c->fuse_softmax = atoi(e) != 0;
     c->nms_one_workgroup = (pf & FPC_PLAN_NMS_ONE_WORKGROUP) != 0;
     if (const char* e = getenv("FPC_NMS_CHUNKED")) c->nms_one_workgroup = atoi(e) == 0;
     if (cfg->min_sub_batch > 0) c->min_sub = cfg->min_sub_batch;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "conv_mfma.h"
+#include "nms_word.h"
 
 namespace fpc {
 
@@ -318,11 +319,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* 
 // (float bits of p where p >= thresh, else 0) and appends candidates to the
 // frame's list (order irrelevant: NMS below is order-free, the sort is total).
 // ---------------------------------------------------------------------------------
-// NMS state word of a candidate with probability p >= 0: float bits + 1, so that an undecided candidate is never the
-// word 0 ("empty / suppressed") -- with conf_thresh == 0 a candidate may have p == +0.0 -- and never has the sign bit
-// ("kept").  -0.0 counts as +0.0.  Bits of non-negative floats order like the floats, and so do bits + 1.
-__device__ __forceinline__ uint32_t nms_state_word(float p) { return (p == 0.f ? 0u : __float_as_uint(p)) + 1u; }
-__device__ __forceinline__ float nms_state_conf(uint32_t word) { return __uint_as_float((word & 0x7fffffffu) - 1u); }
+// (nms_state_word / nms_state_conf: nms_word.h)
 
 __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
                                                           float thresh, float* prob, uint32_t* nmsmap,

@@ -614,8 +614,14 @@ def test_bf16_path_against_fp32_and_oracle(torch_gpu, golden_dir):
     assert np.max(np.abs(d16.cpu().numpy().ravel()[::11] - g["desc_map_probe"])) < BF16_LOGIT_MAX
     _check_bf16_layers(oracle_mod(), e16, frame, sd, [0], "VGA")     # e16's last forward was on `frame`
     r32, r16 = e32.detect(frame)[0], e16.detect(frame)[0]
-    # post-processing is exact on the bf16 engine's own dense maps
+    # post-processing is exact on the bf16 engine's own dense maps (fpc_detect's detector block does the exp-softmax itself,
+    # bit for bit what softmax_d2s_kernel makes of the logits fpc_forward returned)
     _check_frame_against_oracle_postproc(oracle_mod(), p16[0].cpu().numpy(), d16[0].cpu().numpy(), r16, h, w)
+    e16u = engine(h, w, dtype="bf16", plan_flags=["no_fused_softmax"])
+    e16u.load_state_dict(sd)
+    for got, want in zip(e16u.detect(frame)[0], r16):
+        np.testing.assert_array_equal(got, want)
+    e16u.close()
     ov, cos = _overlap_and_cosine(r32, r16)
     assert ov >= BF16_KP_OVERLAP and cos >= BF16_DESC_COS
     # and against the reference's keypoints
