@@ -326,6 +326,10 @@ __global__ __launch_bounds__(512, 2) void wblock16_kernel(const WBlockArgs a) {
       if (wg == wg_stamp && c == 2) { FPC_STAMP(7) }
       FPC_LDS_BARRIER();
     };
+    // (all of this wave's requests -- the ring's first entries among them -- are waited for HERE, once per tile: at the
+    // loop header the compiler merges the counters of the two ways in, and with the ring just requested on one of them
+    // it waited for every outstanding request at the top of EVERY trip, i.e. it drained the ring every two chunks)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     for (int c = 0; c < nchunk; c += 2) {
       chunk_body(std::integral_constant<int, 0>{}, c);
       chunk_body(std::integral_constant<int, 1>{}, c + 1);
