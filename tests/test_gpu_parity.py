@@ -1092,3 +1092,18 @@ def test_random_geometries_other_networks_and_modes(torch_gpu):
     assert ov >= BF16_KP_OVERLAP and cos >= BF16_DESC_COS
     b3.close()
     b1.close()
+    # conf_thresh = 0 in bf16: every pixel is a candidate -- the fused exp-softmax epilogue of the detector's last block
+    # fills its per-tile candidate list to capacity; same keypoints, bit for bit, as the separate softmax launch
+    h, w = 48, 176
+    sd = synth.make_state_dict(78, dustbin_bias=1.0)
+    fr = synth.make_batch(950, 2, h, w)
+    f1 = engine(h, w, 2, dtype="bf16", conf_thresh=0.0)
+    f0 = engine(h, w, 2, dtype="bf16", conf_thresh=0.0, plan_flags=["no_fused_softmax"])
+    f1.load_state_dict(sd)
+    f0.load_state_dict(sd)
+    for ra, rb in zip(f1.detect(fr), f0.detect(fr)):
+        assert ra[3] == rb[3] == h * w
+        for x, y in zip(ra[:3], rb[:3]):
+            np.testing.assert_array_equal(x, y)
+    f1.close()
+    f0.close()
