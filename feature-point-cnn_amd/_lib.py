@@ -20,7 +20,7 @@ CSRC = os.path.join(_DIR, "csrc")
 
 # every symbol include/fpc.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "fpc_abi_version", "fpc_strerror", "fpc_last_hip_error", "fpc_default_config", "fpc_create",
+    "fpc_abi_version", "fpc_build_flags", "fpc_strerror", "fpc_last_hip_error", "fpc_default_config", "fpc_create",
     "fpc_destroy", "fpc_load_weights", "fpc_packed_size", "fpc_packed_device_ptr",
     "fpc_export_packed", "fpc_import_packed", "fpc_mark_weights_loaded", "fpc_set_stream",
     "fpc_get_stream", "fpc_sync", "fpc_forward", "fpc_detect", "fpc_get_points", "fpc_results",
@@ -92,6 +92,7 @@ def load():
     l = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     l.fpc_abi_version.restype = ci
+    l.fpc_build_flags.restype = ctypes.c_char_p
     l.fpc_strerror.restype = ctypes.c_char_p
     l.fpc_strerror.argtypes = [ci]
     l.fpc_last_hip_error.restype = ctypes.c_char_p

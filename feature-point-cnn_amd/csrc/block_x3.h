@@ -625,7 +625,11 @@ __device__ __forceinline__ unsigned stemb_pk_max(unsigned x, unsigned y) {
   return r;
 }
 
-template <int CIN>
+// ABL: phases removed for the ablation runs of DESIGN.md section 3.7 -- a TEMPLATE argument that only
+// experiments/harness/stem_bf16_bench.hip ever sets (the library instantiates <CIN> alone, so no -D can make the
+// product skip work; round 2 had these as preprocessor switches inside this header).
+enum : unsigned { STEMB_ABL_LOAD = 1, STEMB_ABL_K = 2, STEMB_ABL_TILE = 4, STEMB_ABL_POOL = 8, STEMB_ABL_STORE = 16 };
+template <int CIN, unsigned ABL = 0>
 __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const StemX3Args a) {
   using C = StemBCfg<CIN>;
   constexpr int ROWS = C::ROWS, STEPS = C::STEPS, IT = C::IT, NQ = C::NQ, NE = C::NE;
@@ -702,9 +706,7 @@ __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const Ste
       }
     }
     __syncthreads();
-#ifndef STEMB_SKIP_LOAD
-    request(tcur + per);  // lands behind the K loop and the epilogue
-#endif
+    if constexpr (!(ABL & STEMB_ABL_LOAD)) request(tcur + per);  // lands behind the K loop and the epilogue
 
     // accumulators start at the bias; a pixel of the 17 x 17 outside the convolution's output starts (and stays) hugely
     // negative, so the max-pool ignores it as it ignores MaxPool2d's padding
@@ -726,13 +728,8 @@ __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const Ste
           acc[mb][nb][4 * g + 3] = inside ? bq.w : -3.0e38f;
         }
     }
-#ifndef STEMB_SKIP_K
 #pragma unroll
-#endif
-    for (int s = 0; s < STEPS; ++s) {
-#ifdef STEMB_SKIP_K
-      if (a.H > 0) break;
-#endif
+    for (int s = 0; s < ((ABL & STEMB_ABL_K) ? 0 : STEPS); ++s) {
       // this lane's filter row: (c, ky); a padded row (weights zero) re-reads the last real one
       const int r0 = 2 * s < ROWS ? 2 * s : ROWS - 1, r1 = 2 * s + 1 < ROWS ? 2 * s + 1 : ROWS - 1;
       const int off0 = ((r0 / 7) * STEMB_ROWS + (r0 % 7)) * (STEMB_LW / 2), off1 = ((r1 / 7) * STEMB_ROWS + (r1 % 7)) * (STEMB_LW / 2);
@@ -753,11 +750,8 @@ __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const Ste
 
     // the tile -> LDS as bf16: [pixel m][64 channels], 8 bytes per write
     __syncthreads();  // every wave has read its pixels of the input window
-#ifdef STEMB_SKIP_TILE
-    if (a.H < 0)
-#endif
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < ((ABL & STEMB_ABL_TILE) ? 0 : 2); ++mb) {
       unsigned char* row = lds_raw + ((wave * 2 + mb) * 32 + l31) * STEMB_PIX + 8 * half;
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
@@ -770,10 +764,7 @@ __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const Ste
     __syncthreads();
     // 3x3/2 max-pool + ReLU on packed bf16 pairs (as signed 16-bit integers, see above)
     const int gpy = ty * 8 + pj;
-#ifdef STEMB_SKIP_POOL
-    if (a.H < 0)
-#endif
-    if (pj < 8 && gpy < a.Hp) {
+    if (!(ABL & STEMB_ABL_POOL) && pj < 8 && gpy < a.Hp) {
       u32x4 cm[5];
 #pragma unroll
       for (int cc = 0; cc < 5; ++cc) {
@@ -793,9 +784,7 @@ __global__ __launch_bounds__(STEMB_THREADS) void stem_pool_bf16_kernel(const Ste
         o.y = stemb_pk_max(stemb_pk_max(stemb_pk_max(cm[2 * px].y, cm[2 * px + 1].y), cm[2 * px + 2].y), 0u);
         o.z = stemb_pk_max(stemb_pk_max(stemb_pk_max(cm[2 * px].z, cm[2 * px + 1].z), cm[2 * px + 2].z), 0u);
         o.w = stemb_pk_max(stemb_pk_max(stemb_pk_max(cm[2 * px].w, cm[2 * px + 1].w), cm[2 * px + 2].w), 0u);
-#ifdef STEMB_SKIP_STORE
-        if (o.x == 0x12345678u)
-#endif
+        if (!(ABL & STEMB_ABL_STORE) || o.x == 0x12345678u)
         if (tx * 8 + 2 * pg + px < a.Wp) *reinterpret_cast<u32x4*>(orow + px * 64) = o;
       }
     }

@@ -344,6 +344,7 @@ struct fpc_ctx {
   bool xcd_order = true;             // FPC_XCD_ORDER=0: plain tile order in the persistent Winograd kernel
   int nms_passes = 2;
   bool fuse_softmax = true;        // !FPC_PLAN_NO_FUSED_SOFTMAX (FPC_BF16's detector.layer.1, block_bf16.h)
+  bool logits_valid = false;       // the last call wrote the logits ("det.1" of fpc_read_activation): false after a fused-softmax fpc_detect
   bool nms_one_workgroup = false;  // FPC_PLAN_NMS_ONE_WORKGROUP: round 1's sort (one workgroup per frame) for every frame
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
@@ -357,7 +358,7 @@ struct fpc_ctx {
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool latency_tiles = true;         // calls of a few frames run the 128-channel Winograd blocks on 4 x 16 tiles (FPC_LATENCY_TILES=0: 8 x 16)
   int winograd_gen = 2;              // 64- and 128-channel Winograd layers on wblock16_kernel (2) or wblock_mfma_kernel (1; FPC_WINOGRAD_GEN)
-  bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)                // parallel NMS launches before the per-frame finish
+  bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)
   bool weights_loaded = false;
   bool plan_error = false;           // a layer asked for a kernel instance that does not exist (fpc_create -> FPC_E_INVALID)
 
@@ -380,6 +381,7 @@ struct fpc_ctx {
   // packed weights
   float* blob = nullptr;
   size_t blob_floats = 0;
+  uint32_t* bcast_tag = nullptr;   // 64 bytes of the slab: fpc_broadcast_weights' first collective (allocated here so that it cannot fail there)
   std::vector<float> host_blob;
 
   std::vector<Op> ops;
@@ -1000,7 +1002,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   const size_t o_lg = cv.take<float>(npix8 * 80), o_desc = cv.take<float>(npix8 * 256), o_descin = cv.take<float>(npix8 * 256);
   const size_t o_prob = cv.take<float>((size_t)B * H * W);
   const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
-  const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4);
+  const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4 + BLOB_HEADER_FLOATS);   // + the 64-byte tag of fpc_broadcast_weights
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>((size_t)B * c->cap * 256);
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
@@ -1019,6 +1021,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   c->ncand = reinterpret_cast<int32_t*>(c->slab + o_ncand);
   c->count = reinterpret_cast<int32_t*>(c->slab + o_count);
   c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
+  c->bcast_tag = reinterpret_cast<uint32_t*>(c->status + 4);
   c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
@@ -1188,7 +1191,7 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_desc = cv.take<float>(npix8 * 128), o_descin = cv.take<float>(npix8 * 128);
   const size_t o_prob = cv.take<float>((size_t)B * H * W);
   const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
-  const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4);
+  const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4 + BLOB_HEADER_FLOATS);   // + the 64-byte tag of fpc_broadcast_weights
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>(de ? (size_t)B * c->cap * 128 : 64);
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
@@ -1211,6 +1214,7 @@ static int build_plan(fpc_ctx* c) {
   c->ncand = reinterpret_cast<int32_t*>(c->slab + o_ncand);
   c->count = reinterpret_cast<int32_t*>(c->slab + o_count);
   c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
+  c->bcast_tag = reinterpret_cast<uint32_t*>(c->status + 4);
   c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
@@ -2282,6 +2286,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb0, bool de, i
   // logits and the dense probability map, which only fpc_forward's callers see, are not produced)
   Sub sb = sb0;
   for (const Op& op : c->ops) sb.fuse_softmax |= upto && op.fused_softmax_capable;
+  c->logits_valid = !sb.fuse_softmax;
   run_network(c, frames, sb, 0, sb.st);
   if (de && upto && c->nms_aside && !sb.small && sb.side) {
     // detector head and softmax in line; the (latency-bound, few-CU) NMS on the side stream next to the descriptor head
@@ -2326,6 +2331,23 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb0, bool de, i
 extern "C" {
 
 int fpc_abi_version(void) { return FPC_ABI_VERSION; }
+
+// What this binary was compiled with: the target, whether it is the diagnostic build (in-kernel stamps: never the
+// product), and that no experiment switch of earlier rounds reached it (they are gone from the headers; a build
+// that defines one of their names anyway does not compile).
+#if defined(STEMB_SKIP_LOAD) || defined(STEMB_SKIP_K) || defined(STEMB_SKIP_TILE) || defined(STEMB_SKIP_POOL) || \
+    defined(STEMB_SKIP_STORE) || defined(W16_YOUNG_PRIO) || defined(W16_PRIO_SPLIT) || defined(FPC_NO_PIN)
+#error "ablation switches are not part of the library: see experiments/harness/"
+#endif
+const char* fpc_build_flags(void) {
+  return "arch=gfx950"
+#ifdef FPC_DIAG
+         ";diag=1"
+#else
+         ";diag=0"
+#endif
+         ";ablations=none";
+}
 
 const char* fpc_strerror(int code) {
   switch (code) {
@@ -2660,8 +2682,9 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
   const bool is_root = rank == root;
   // Step 1: the 64-byte tag alone, into scratch -- every rank learns what the root is about to send BEFORE the
   // collective whose size depends on it.  A root without weights sends a tag with the weights-present flag clear.
-  uint32_t* tag_dev = nullptr;
-  HIPCHECK(hipMalloc((void**)&tag_dev, sizeof(uint32_t) * BLOB_HEADER_FLOATS));
+  // (the tag's device buffer is 64 bytes of the slab carved at fpc_create: an allocation HERE could fail on one rank,
+  // which would return early and leave the others waiting in the collective)
+  uint32_t* tag_dev = c->bcast_tag;
   uint32_t tag[BLOB_HEADER_FLOATS];
   if (is_root) {
     fill_blob_header(c, tag);
@@ -2671,7 +2694,6 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
   int nrc = g_rccl.bcast(tag_dev, tag_dev, sizeof(tag), /*ncclUint8*/ 1, root, nccl_comm, c->stream);
   hipError_t he = hipMemcpyAsync(tag, tag_dev, sizeof(tag), hipMemcpyDeviceToHost, c->stream);
   if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-  hipFree(tag_dev);
   if (nrc != 0 || he != hipSuccess) {
     g_hip_err = nrc ? "ncclBroadcast(tag) failed: ncclResult " + std::to_string(nrc) : std::string("tag copy: ") + hipGetErrorString(he);
     return FPC_E_HIP;
@@ -2687,13 +2709,27 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
   const bool match = check_blob_header(c, tag, &why);
   void* dst = c->blob;
   void* scratch = nullptr;
+  bool clobbered = false;
   if (!match) {
-    HIPCHECK(hipMalloc(&scratch, root_bytes));
-    dst = scratch;
+    // somewhere to receive root_bytes: scratch; if that cannot be had, this rank's own blob when it is large enough
+    // (its weights are then gone and it says so) -- what it must NOT do is return before the collective
+    if (hipMalloc(&scratch, root_bytes) == hipSuccess) {
+      dst = scratch;
+    } else {
+      (void)hipGetLastError();
+      scratch = nullptr;
+      if (root_bytes <= c->blob_floats * sizeof(float)) {
+        clobbered = true;
+      } else {
+        g_hip_err = "no memory to take part in the weight broadcast (" + std::to_string(root_bytes) + " bytes); the other ranks of this communicator will wait for this one";
+        return FPC_E_HIP;
+      }
+    }
   }
   nrc = g_rccl.bcast(dst, dst, root_bytes, 1, root, nccl_comm, c->stream);
   he = hipStreamSynchronize(c->stream);
   if (scratch) hipFree(scratch);
+  if (clobbered) c->weights_loaded = false;
   if (nrc != 0 || he != hipSuccess) {
     g_hip_err = nrc ? "ncclBroadcast(weights) failed: ncclResult " + std::to_string(nrc) : std::string("broadcast: ") + hipGetErrorString(he);
     return FPC_E_HIP;
@@ -2785,6 +2821,8 @@ int fpc_read_activation(fpc_ctx* c, const char* name, int frame0, int n, float* 
   for (const Tap& t : taps) {
     if (strcmp(t.name, name)) continue;
     if (!c->cfg.descriptor_enabled && (!strncmp(name, "desc", 4) || !strcmp(name, "up"))) return FPC_E_INVALID;
+    // FPC_BF16's fpc_detect fuses exp-softmax into detector.layer.1: that call writes NMS state and candidates, no logits
+    if (!strcmp(name, "det.1") && !c->logits_valid) return FPC_E_INVALID;
     if (channels) *channels = t.C;
     if (height) *height = t.H;
     if (width) *width = t.W;

@@ -641,6 +641,7 @@ __global__ __launch_bounds__(NMS_ROUNDS_THREADS) void nms_rounds_kernel(const Nm
   } else {
     constexpr int D = 2 * R + 1;
     __shared__ unsigned long long lists[NMS_LIST_SLOTS][NMS_ROUNDS_THREADS];  // slot k of a thread: its k-th candidate
+    static_assert(sizeof(lists) <= 64 * 1024, "static LDS of a kernel is limited to 64 KiB: fewer list slots or dynamic LDS");
     const int W = a.W, H = a.H;
 #pragma unroll
     for (int k = 0; k < NMS_LIST_SLOTS; ++k) lists[k][threadIdx.x] = 0ull;

@@ -66,9 +66,7 @@ __device__ __forceinline__ float4 fpc_ldg_su(const float4* ubase, unsigned lane_
   typedef const char __attribute__((address_space(1))) * gptr;
   typedef float f4v __attribute__((ext_vector_type(4)));
   gptr b = (gptr) reinterpret_cast<const char*>(ubase);
-#ifndef FPC_NO_PIN
   asm("" : "+s"(b));
-#endif
   const f4v v = *reinterpret_cast<const f4v __attribute__((address_space(1)))*>(b + lane_bytes);
   return make_float4(v.x, v.y, v.z, v.w);
 }

@@ -264,7 +264,8 @@ class Engine:
 
     def activation(self, name, frame0=0, n=1):
         """Intermediate tensor of the LAST forward / detect call as a forward hook on the reference module would return
-        it: float32 CUDA tensor [n,C,h,w] (fpc_read_activation)."""
+        it: float32 CUDA tensor [n,C,h,w] (fpc_read_activation).  "det.1" (the logits) raises after a `detect` in
+        dtype="bf16" with the fused softmax epilogue -- that call never writes logits; `forward` always does."""
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(self._l.fpc_read_activation(self._ctx, name.encode(), frame0, n, None, ctypes.byref(c), ctypes.byref(h),
                                                ctypes.byref(w)), "fpc_read_activation")

@@ -126,18 +126,30 @@ class HomographyConfig:
         self.patch_ratio = 0.85
 
 
+def truncated_normal(n, mean=0.0, stddev=1.0, rng=None):
+    """truncated_normal (python/src/homographies.py:64-67) AS THE REFERENCE REALLY DRAWS IT: scipy's
+    `truncnorm(a, b)` with a = mean - 2 sigma, b = mean + 2 sigma and NO loc / scale -- i.e. a STANDARD normal cut to
+    the interval [mean - 2 sigma, mean + 2 sigma], not N(mean, sigma^2) cut at +-2 sigma.  For the sigmas its caller
+    passes (0.05 ... 0.1) that is nearly uniform over the interval (for the scales, centred on 1: a slightly falling
+    density on [0.8, 1.2]).  Reproduced, not corrected: the label distribution of homography adaptation depends on it
+    (round 2 drew the textbook distribution instead; SURVEY appendix B has no line for this quirk).  float32 [n]."""
+    from scipy.stats import truncnorm
+    if not stddev > 0:
+        return np.full(n, mean, np.float32)
+    return truncnorm(mean - 2 * stddev, mean + 2 * stddev).rvs(n, random_state=rng).astype(np.float32)
+
+
 def sample_homography(shape, config=None, rng=None):
     """sample_homography (python/src/homographies.py:78-182) step by step: a centred patch is perturbed
     (perspective, scale, translation, rotation), each step keeping the corners inside the unit square unless
     allow_artifacts, and the 8 coefficients mapping output points to input points are solved for.  Random numbers come
     from `rng` (numpy Generator) instead of torch's / scipy's global state, so a run is reproducible from a seed but
     not bit-identical to the reference's stream.  shape = (H, W).  -> float32 [8]."""
-    from scipy.stats import truncnorm
     cfg = config or HomographyConfig()
     rng = rng or np.random.default_rng()
 
-    def tn(n, mean, std):       # truncated_normal :64-67: +-2 sigma
-        return truncnorm(-2, 2, loc=mean, scale=std).rvs(n, random_state=rng).astype(np.float32) if std > 0 else np.full(n, mean, np.float32)
+    def tn(n, mean, std):       # truncated_normal :64-67 (see above: a standard normal cut to mean +- 2 sigma)
+        return truncated_normal(n, mean, std, rng)
 
     margin = (1 - cfg.patch_ratio) / 2
     pts1 = margin + np.array([[0, 0], [0, cfg.patch_ratio], [cfg.patch_ratio, cfg.patch_ratio], [cfg.patch_ratio, 0]], np.float32)

@@ -126,6 +126,9 @@ typedef struct fpc_device_results {
 typedef struct fpc_ctx fpc_ctx;
 
 int fpc_abi_version(void);
+/* "arch=gfx950;diag=0;ablations=none" for the product library: the code-object target, whether in-kernel stamps are
+ * compiled in (the diagnostic build, never shipped), and that no experiment switch reached the build.  Static string. */
+const char* fpc_build_flags(void);
 const char* fpc_strerror(int code);
 /* Text of the last HIP error seen by this thread (for FPC_E_HIP). */
 const char* fpc_last_hip_error(void);
@@ -191,7 +194,9 @@ int fpc_forward(fpc_ctx* ctx, const float* frames_dev, int n, float* prob_map_de
  * descriptor map).  Frames frame0 .. frame0+n-1 as float32 NCHW into out_dev [n,C,h,w] (bf16 tensors of the FPC_BF16
  * mode are widened exactly); channels / height / width receive the tensor's shape (out_dev may be NULL to query it).
  * The fused kernels never write a block's inner tensor h nor the un-pooled stem output to memory: those have no name
- * here.  FPC_ARCH_RESNET only.  Asynchronous on the ctx stream. */
+ * here.  "det.1" exists only when the last call produced logits: fpc_forward always does; fpc_detect does except in
+ * FPC_BF16 with the fused softmax epilogue (the default there; FPC_PLAN_NO_FUSED_SOFTMAX turns it off), where the
+ * name returns FPC_E_INVALID instead of stale memory.  FPC_ARCH_RESNET only.  Asynchronous on the ctx stream. */
 int fpc_read_activation(fpc_ctx* ctx, const char* name, int frame0, int n, float* out_dev, int* channels, int* height,
                         int* width);
 

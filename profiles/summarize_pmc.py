@@ -29,6 +29,13 @@ for path in paths:
     for r in csv.DictReader(open(path)):
         tab[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 counters = sorted({c for k in tab.values() for c in k})
+# a pass that failed silently would leave a summary without its counters, which bench.py would then read as measured
+# traffic: every kernel must carry all three groups
+need = ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE")
+missing = {k: [c for c in need if c not in v] for k, v in tab.items() if not k.startswith("__amd") and any(c not in v for c in need)}
+if missing or not tab:
+    sys.stderr.write("summarize_pmc: counter groups missing (a rocprofv3 --pmc pass failed?): %s\n" % (missing or "no input rows"))
+    sys.exit(1)
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "dispatches"] + counters + ["hbm_bytes_per_dispatch", "mfma_util", "frames_per_dispatch"])
 for k, v in tab.items():

@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) <= exported
 
 
+def test_product_library_was_built_without_experiment_switches():
+    """The shipped libfpc.so is the plain build: no in-kernel stamps (the `make diag` library is a different file) and
+    none of the ablation switches earlier rounds kept in the headers (they are template arguments of the harness now;
+    a build that defines one of the old names does not compile -- checked here on the header alone)."""
+    lib = _lib.load()
+    assert lib.fpc_build_flags() == b"arch=gfx950;diag=0;ablations=none"
+    csrc = os.path.join(ROOT, "feature-point-cnn_amd", "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".h", ".hip")):
+            text = open(os.path.join(csrc, name)).read()
+            for m in re.finditer(r"#\s*if(?:n?def)?\s+(?:!?\s*defined\s*\(?\s*)?(\w+)", text):
+                assert m.group(1) in ("FPC_DIAG", "defined", "STEMB_SKIP_LOAD"), (name, m.group(0))
+
+
 def test_library_contains_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
@@ -215,6 +229,27 @@ def test_sample_homography_restatement():
         assert -0.25 * w <= c[0] <= 1.25 * w and -0.25 * h <= c[1] <= 1.25 * h
     cfg.init_for_preprocess()          # preprocess_coco.py:57-58
     assert sample_homography((h, w), cfg, rng).shape == (8,)
+
+
+def test_truncated_normal_draws_what_the_reference_draws():
+    """python/src/homographies.py:64-67 builds `truncnorm(a, b)` with a = mean - 2 sigma, b = mean + 2 sigma and no
+    loc / scale: a STANDARD normal cut to [a, b] (nearly uniform for the sigmas its caller passes), not N(mean, sigma^2)
+    cut at two sigmas.  The module cannot be imported (cv2 / torchvision), so its four lines are restated here exactly
+    and 10 000 draws of fpc_amd.inference.truncated_normal are held to that distribution: Kolmogorov-Smirnov distance,
+    support, mean and variance -- and they must be FAR from the textbook distribution round 2 drew."""
+    from scipy import stats
+    from fpc_amd.inference import truncated_normal
+    for mean, sd in ((0.0, 0.1), (0.0, 0.05), (1.0, 0.1), (1.0, 0.05)):
+        a, b = mean - 2 * sd, mean + 2 * sd
+        ref = stats.truncnorm(a, b)                                  # the reference's object, argument for argument
+        x = truncated_normal(10000, mean, sd, np.random.default_rng(11)).astype(np.float64)
+        assert x.min() >= a - 1e-6 and x.max() <= b + 1e-6
+        ks = stats.kstest(x, ref.cdf).statistic
+        assert ks < 0.02, (mean, sd, ks)                             # 10 000 draws: 1 % critical value is 0.0163
+        assert abs(x.mean() - ref.mean()) < 4 * ref.std() / 100 and abs(x.var() / ref.var() - 1) < 0.05
+        textbook = stats.truncnorm(-2, 2, loc=mean, scale=sd)
+        assert stats.kstest(x, textbook.cdf).statistic > 0.05        # and it is NOT N(mean, sigma^2) cut at 2 sigma
+    assert np.all(truncated_normal(5, 0.3, 0.0) == np.float32(0.3))
 
 
 def test_checkpoint_reader_rejects_damaged_files_cleanly(tmp_path):

@@ -126,3 +126,38 @@ def test_single_process_needs_no_group():
     eng = FakeEngine()
     fdist.broadcast_packed_weights(eng, {"blob": bytes(eng.packed_size())})
     assert eng.loaded
+
+
+def _bench(args, **env):
+    import subprocess
+    e = dict(os.environ, **env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` without torch.distributed.run around it: the parent starts two ranks, they
+    rendezvous (gloo here), rank 0 prints ONE line and the parent exits 0."""
+    import json
+    r = _bench(["--gpus", "2"], FPC_BENCH_RENDEZVOUS_ONLY="1", FPC_DIST_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"rendezvous": "ok", "world": 2, "ranks": [0, 1], "backend": "gloo"}
+
+
+def test_bench_parent_reports_a_failing_rank():
+    """Without a GPU every rank fails when it creates its engine: the parent must come back promptly with a non-zero
+    status (not wait in a collective) and print no result line."""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    t0 = __import__("time").time()
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], FPC_DIST_BACKEND="gloo")
+    assert r.returncode != 0
+    assert "a rank exited with status" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert __import__("time").time() - t0 < 120

@@ -428,3 +428,49 @@ def test_two_ranks_with_real_engines_on_one_gpu(torch_gpu, tmp_path):
         np.testing.assert_array_equal(res[1]["mine"][k - 3][0][:, 0], oxs)
         np.testing.assert_array_equal(res[1]["mine"][k - 3][0][:, 1], oys)
     e.close()
+
+
+def test_bench_gpus_2_launches_its_own_ranks_on_one_gpu(torch_gpu):
+    """`python bench.py --gpus 2` with no launcher around it (what a SCALE run may do): the parent starts the two
+    ranks itself; both share this box's one GPU, so the rendezvous is gloo (RCCL refuses two ranks on one device).
+    One JSON line, n_gpus = 2, both ranks reported, exit status 0."""
+    import json
+    env = dict(os.environ, FPC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-steady-state"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["per_rank"]["frames_per_s"]) == 2
+    assert out["config"]["frames_per_step_per_gpu"] == 32
+
+
+def test_logits_tap_after_a_fused_softmax_detect(torch_gpu):
+    """FPC_BF16's fpc_detect takes exp-softmax / threshold in detector.layer.1's epilogue and writes no logits: the
+    "det.1" tap must say so (FPC_E_INVALID) rather than hand out stale memory; after fpc_forward, or with the fused
+    epilogue switched off, it is the logits again."""
+    from fpc_amd import _lib
+    h, w = 64, 96
+    sd = synth.make_state_dict(3, dustbin_bias=4.0)
+    frames = synth.make_batch(5, 2, h, w)
+    e = engine(h, w, 2, dtype="bf16")
+    e.load_state_dict(sd)
+    _, _, logits = e.forward(frames)
+    tap = e.activation("det.1", 0, 2)
+    np.testing.assert_array_equal(tap.cpu().numpy(), logits.cpu().numpy())
+    e.detect(frames)
+    with pytest.raises(_lib.FpcError):
+        e.activation("det.1", 0, 2)
+    assert e.activation("det.0", 0, 2).shape[1] == 65          # the other taps are what the detect call left
+    e.forward(frames)
+    np.testing.assert_array_equal(e.activation("det.1", 0, 2).cpu().numpy(), logits.cpu().numpy())
+    e.close()
+    e2 = engine(h, w, 2, dtype="bf16", plan_flags=["no_fused_softmax"])
+    e2.load_state_dict(sd)
+    e2.detect(frames)
+    np.testing.assert_array_equal(e2.activation("det.1", 0, 2).cpu().numpy(), logits.cpu().numpy())
+    e2.close()
