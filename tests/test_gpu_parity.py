@@ -644,13 +644,14 @@ def test_bf16_hd_batch_properties(torch_gpu):
     frames = np.concatenate([np.roll(base, 16 * k, axis=3) for k in range(n // 8)], 0)
     e = engine(h, w, n, dtype="bf16")
     e.load_state_dict(sd)
-    prob, desc, _ = e.forward(frames)
     res = e.detect(frames)
+    prob, desc, _ = e.forward(frames)
     oracle = oracle_mod()
     for i in (0, 29, n - 1):
         _check_frame_against_oracle_postproc(oracle, prob[i].cpu().numpy(), desc[i].cpu().numpy(), res[i], h, w)
     # every layer of three frames of the batch (first, one at the sub-batch boundary, last) against the bf16-emulating
-    # oracle, each on the device's own input tensor (the last call, detect, ran the same 64 frames)
+    # oracle, each on the device's own input tensor.  The last call is fpc_forward: fpc_detect in this mode writes no
+    # logits (fused softmax epilogue), so the "det.1" tap exists only after a forward (test_logits_tap_after_...)
     _check_bf16_layers(oracle, e, frames, sd, [0, 31, n - 1], "HD x64")
     for i in (3, 40):
         one = e.detect(frames[i:i + 1])[0]
@@ -1072,6 +1073,7 @@ def test_random_geometries_other_networks_and_modes(torch_gpu):
         la, lb = a.forward(fr)[2], b.forward(fr)[2]
         assert float((la - lb).abs().max()) < BF16_LOGIT_MAX, (h, w)
         assert len(b.detect(fr)) == 3
+        b.forward(fr)     # (the taps below include the logits, which only a forward writes in this mode)
         # every layer against the bf16-emulating oracle at these sizes too (partial tiles on every edge of the persistent
         # kernels' tile walks; the last call ran the same frames)
         _check_bf16_layers(oracle, b, fr, sd, [0, 2], "%dx%d" % (h, w))
