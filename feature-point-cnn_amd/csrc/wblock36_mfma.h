@@ -1,0 +1,523 @@
+// wblock36_mfma.h -- third generation of the Winograd ResNetBlock kernel: F(4x4, 3x3).
+//
+//     V = B^T d B   (6x6 input patch of every 4x4 output tile, per channel)        VALU, LDS -> LDS
+//     M_xi = V_xi . U_xi   for the 36 patch positions xi, U = G g G^T (host, double) 36 GEMMs on MFMA
+//     Y = A^T M A   (+ folded-BN bias, ReLU)  -> h                                  VALU, registers -> LDS
+//     out = relu(conv1x1(h) + shortcut(x))                                         as wblock16_mfma.h
+//
+// 36 multiplications per 16 outputs and channel pair instead of 144: the 3x3 costs 4x fewer MFMAs than the direct
+// convolution (F(2x2,3x3): 2.25x).  Interpolation points 0, +-1, +-2, inf; measured on He-scaled 128-channel layers
+// against fp64: 6e-6 of the layer's scale (F(2x2,3x3): 4e-7; direct fp32: 2e-7) -- inside the 1e-4 bar with a factor
+// of ten to spare per layer (experiments/harness/wino43_numerics.py).
+//
+// What shapes the kernel is a measurement (experiments/harness/mfma_f32_coissue.hip): on gfx950 the fp32 MFMA and the
+// VALU exclude each other on a SIMD.  v_mfma_f32_16x16x4_f32 issues back to back at 32 cycles; one independent
+// v_fma_f32 between two of them costs +15.5 cycles, every further one +4, with one wave or with two waves per SIMD
+// alike -- a partner wave's VALU work does NOT hide under this wave's MFMAs.  LDS instructions do overlap (3
+// ds_read_b32 or 2 ds_write_b32 per MFMA and wave are free).  So the time of a chunk is
+//         32 x MFMAs  +  4 x VALU instructions  +  ~11 per switch from the matrix pipe to the VALU and back
+// whatever the wave arrangement, and the levers are: fewer MFMAs (this transform), fewer VALU instructions, and VALU
+// work in a few long bursts instead of dealt out between the MFMAs (generation 2 dealt it out: a switch per MFMA).
+//
+// Structure: ONE wave per SIMD (256 threads, up to 512 registers per lane).  A workgroup owns a tile of 16 Winograd
+// tiles (TYT x TXT of 4x4 pixels) x ALL output channels; wave w owns 16 NB output channels for all 36 positions:
+// 36 NB accumulator blocks of v_mfma_f32_16x16x4_f32 (NB = 2: 288 registers, N = 128; NB = 1: 144, N = 64).  As in
+// generation 2 the output transform is then register arithmetic, and the input side is software-pipelined into the
+// GEMM over chunks of 16 input channels (two V buffers, two halo buffers, the next tile's first chunks during this
+// tile's last ones), with the transform of chunk c + 1 as ONE burst of 144 VALU instructions in the middle of chunk
+// c's MFMAs, its 36 LDS reads dealt out before it and its 36 LDS writes after it.
+//
+// The MFMA's row index m (0..15) carries Winograd tile T(m) = 8 ((m >> 1) & 1) + 2 (m >> 2) + (m & 1): a lane's
+// four accumulator rows 4 kq + r then hold two tiles of the tile's first half (r = 0, 1) and two of its second half
+// (r = 2, 3), so the 1x1 phase can run per half (128 pixels: h for all 256 would not fit beside the next tile's
+// pipelined input) with every lane at work in both halves.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "wblock16_mfma.h"
+
+namespace fpc {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in
+// every trip whatever the optimiser's unrolling thresholds say (left to `#pragma unroll`, the 36-step chunk loop stayed
+// a loop: ring slots and accumulators indexed at run time, i.e. in scratch memory)
+template <int... I, class F>
+__device__ __forceinline__ void fpc_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void fpc_static_for(F&& f) {
+  fpc_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int NB_, int TYT_, int TXT_>
+struct W36Cfg {
+  static constexpr int NB = NB_, TYT = TYT_, TXT = TXT_;
+  static_assert(TYT * TXT == 16 && (TYT == 4 || TYT == 2), "16 Winograd tiles per workgroup tile: 4 x 4 or 2 x 8");
+  static_assert(NB == 1 || NB == 2, "a wave owns 16 or 32 output channels");
+  static constexpr int NT = 256, NPOS = 36, KC = 16;
+  static constexpr int TH = 4 * TYT, TW = 4 * TXT, HH = TH + 2, HW = TW + 2, NHALO = HH * HW;
+  static constexpr int N = 64 * NB;
+  static constexpr int HROW = 20;                                   // halo row: 16 channels + 4 floats of skew
+  static constexpr int HIT = (NHALO * 4 + NT - 1) / NT;             // float4 per thread and chunk (6)
+  static constexpr int HALO_FLOATS = HIT * NT / 4 * HROW;           // every thread stores all its float4 (slots >= NHALO are padding)
+  static constexpr int V_FLOATS = NPOS * 16 * 16;
+  // V0 | halo1 | halo0 | V1: at a tile's end V0 and halo1 hold the next tile's first chunks; halo0, V1 and the rest
+  // of the LDS are free for h, the shortcut's x tile and the output tile of one half
+  static constexpr int OFF_V0 = 0, OFF_H1 = V_FLOATS, OFF_H0 = OFF_H1 + HALO_FLOATS, OFF_V1 = OFF_H0 + HALO_FLOATS;
+  static constexpr int RH = N + 8;                                  // h / output row (floats)
+  static constexpr int RX = 128 + 8;                                // x staging row (up to 128 channels per pass)
+  static constexpr int HPX = 128;                                   // pixels of one half
+  static constexpr int T_FLOATS = HPX * (RH > RX ? RH : RX);
+  static constexpr int LDS_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
+  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  // one ring step = 8 MFMAs: one position x 2 channel blocks (NB = 2) or two positions x 1 block (NB = 1: two
+  // accumulators alternate, a single dependent chain would run at 40 instead of 32 cycles per MFMA)
+  static constexpr int STEPS = NB == 2 ? 36 : 18;
+  // Ring depth in steps (8 registers each; must divide STEPS so that slot indices are compile-time constants across
+  // chunks).  vmcnt retires in order: a fragment requested after the chunk's halo request waits for it, so the ring has
+  // to hold the fragments of that whole latency (RING - 1 steps of 256 cycles).
+  static constexpr int RING = NB == 2 ? 9 : 18;
+  static_assert(STEPS % RING == 0, "ring slots must line up across chunks");
+  static constexpr int WPAD = 2 * RING;                             // zero POSITIONS behind every channel group's stream
+  static constexpr int WPAD2 = 16;                                  // ... and steps behind the 1x1 streams (as generation 2)
+};
+
+template <int NB, int TYT, int TXT>
+__global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
+  using C = W36Cfg<NB, TYT, TXT>;
+  constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HW = C::HW, HH = C::HH, HROW = C::HROW, HIT = C::HIT;
+  constexpr int N = C::N, RH = C::RH, RX = C::RX, RING = C::RING, STEPS = C::STEPS, HPX = C::HPX;
+  extern __shared__ float lds[];
+  float* const TL = lds + C::OFF_H0;        // h, x staging, output tile of one half
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int nchunk = a.nchunk;              // Cin / 16, even, >= 4
+  // second half of a 256-wide conv-only layer (gridDim.y == 2)
+  const float4* const w1h = a.w1 + (size_t)blockIdx.y * (a.ysplit_floats / 4);
+  const float* const b1h = a.b1 + (size_t)blockIdx.y * a.ysplit_floats;
+  float* const outh = a.out + blockIdx.y * N;
+
+  // tile walk (persistent, XCD-aware): as wblock16_kernel
+  const bool xcd_order = a.xcd_order && (gridDim.x & 7) == 0;
+  const int wg_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int xchunk = (a.total + 7) >> 3;
+  const int wg_first = xcd_order ? (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int wg_end = xcd_order ? min(a.total, ((int)(blockIdx.x & 7) + 1) * xchunk) : a.total;
+  if (wg_first >= wg_end) return;
+
+  // ---------------------------------------------------------------- input side: L (global -> registers), S (-> halo), T (halo -> V)
+  // As generation 2: buffer loads with the hardware's bounds check (out-of-frame pixels, padding slots and tiles behind
+  // the workgroup's last one get an offset outside the descriptor's range and come back as zeros).
+  f32x4 stage[HIT];
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  auto load_halo = [&](int wg, int chunk) {            // chunk `chunk` of tile wg
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const bool live = wg < wg_end;
+    const int wgc = live ? wg : wg_first;
+    const int bl = wgc / tiles;
+    const int bb = a.frame0 + bl;
+    const int t = wgc - bl * tiles;
+    const int tyy = t / a.tiles_x, txx = t - tyy * a.tiles_x;
+    const int iy0 = tyy * TH - 1, ix0 = txx * TW - 1;
+    const int hlim = live ? a.H : 0;
+    const unsigned base = (unsigned)((bb * a.H + iy0) * a.W + ix0) * (unsigned)(a.csx * 4) + (unsigned)(chunk * 64);
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) {
+      const int e = tl + i * NT;
+      const int pix = e >> 2, c4 = e & 3;
+      const int hy = HW == 18 ? (pix * 3641) >> 16 : (pix * 1928) >> 16;     // pix / 18 (pix < 469), pix / 34 (pix < 441)
+      const int hx = pix - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = ((unsigned)iy < (unsigned)hlim) & ((unsigned)ix < (unsigned)a.W) & (hy < HH);
+      unsigned in_off = base + (unsigned)((hy * a.W + hx) * a.csx * 4 + c4 * 16);
+      asm volatile("" : "+v"(in_off));
+      const unsigned voff = ok ? in_off : 0xfffffff0u;
+      stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff, 0, 0));
+    }
+  };
+  auto store_halo = [&](int hoff) {
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) {
+      const int e = tl + i * NT;
+      *reinterpret_cast<f32x4*>(lds + hoff + (e >> 2) * HROW + (e & 3) * 4) = stage[i];
+    }
+  };
+  // the transform item of this thread: Winograd tile wt (0..15), channel ch (0..15) of the chunk; V row m = Tinv(wt)
+  const int wt_t = tid >> 4, ch_t = tid & 15;
+  const int m_t = ((wt_t & 7) >> 1) * 4 + (wt_t >> 3) * 2 + (wt_t & 1);
+  const int trd = ((4 * (wt_t / TXT)) * HW + 4 * (wt_t % TXT)) * HROW + ch_t;                          // halo read base
+  const int twr = m_t * 16 + ((((ch_t >> 2) ^ (2 * ((m_t >> 3) & 1))) << 2) | (ch_t & 3));            // V write base (swizzled)
+  float td[6][6];
+  auto t_read = [&](int rd, int i, int j) { td[i][j] = lds[rd + (i * HW + j) * HROW]; };
+  // B^T x for the six values x0..x5 (in place): the F(4x4,3x3) input transform along one axis, 12 operations
+  auto bt6 = [&](float& x0, float& x1, float& x2, float& x3, float& x4, float& x5) {
+    const float p = __builtin_fmaf(-4.f, x2, x4), q = __builtin_fmaf(-4.f, x1, x3);
+    const float r = x4 - x2, s = x3 - x1;
+    const float y0 = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));
+    const float y5 = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));
+    x0 = y0;
+    x1 = p + q;
+    x2 = p - q;
+    x3 = __builtin_fmaf(2.f, s, r);
+    x4 = __builtin_fmaf(-2.f, s, r);
+    x5 = y5;
+  };
+  auto t_burst = [&]() {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bt6(td[0][j], td[1][j], td[2][j], td[3][j], td[4][j], td[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bt6(td[i][0], td[i][1], td[i][2], td[i][3], td[i][4], td[i][5]);
+  };
+  auto t_write = [&](int wr, int i, int j) { lds[wr + (i * 6 + j) * 256] = td[i][j]; };
+  auto transform_all = [&](int hoff, int voff) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t_read(trd + hoff, i, j);
+    t_burst();
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t_write(twr + voff, i, j);
+  };
+
+  // ---------------------------------------------------------------- operands of the GEMMs
+  // A: V[pos][m][16 ch] -- lane (row m = l & 15, k quarter kq = l >> 4) reads one float4
+  const int aoff = (lane & 15) * 16 + (((lane >> 4) ^ (2 * ((lane & 15) >> 3))) << 2);
+  // B: the fragment streams of this wave's NB channel groups, [chunk][pos][64 lanes] float4 each
+  const unsigned gstride = ((unsigned)nchunk * 36u + (unsigned)C::WPAD) * 1024u;        // bytes per channel group
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(w1h), 0, (int)(4u * (unsigned)NB * gstride), 0x00020000);
+  const unsigned wlane = (unsigned)(wave * NB) * gstride + lane16;
+  const int gs_s = __builtin_amdgcn_readfirstlane((int)gstride);
+  struct BF { f32x4 v[2]; };
+  auto ldb = [&](int s) {      // ring step s (counted from the tile's first chunk)
+    BF r;
+    if (NB == 2) {
+      r.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024, 0));
+      r.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024 + gs_s, 0));
+    } else {
+      r.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 2048, 0));
+      r.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 2048 + 1024, 0));
+    }
+    return r;
+  };
+
+  // ---------------------------------------------------------------- pipeline fill for the first tile
+  load_halo(wg_first, 0);
+  store_halo(C::OFF_H0);
+  load_halo(wg_first, 1);
+  FPC_LDS_BARRIER();
+  transform_all(C::OFF_H0, C::OFF_V0);
+  store_halo(C::OFF_H1);
+  load_halo(wg_first, 2);
+  FPC_LDS_BARRIER();
+  // state at the top of iteration c of a tile: V[c & 1] = chunk c transformed; halo[(c + 1) & 1] = chunk c + 1 stored;
+  // stage = chunk c + 2 requested
+
+  const int wg_stamp = wg_first + 2 * wg_step < wg_end ? wg_first + 2 * wg_step : wg_first;
+  for (int wg = wg_first; wg < wg_end; wg += wg_step) {
+    const int bl = wg / tiles;
+    const int b = a.frame0 + bl;
+    const int t = wg - bl * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    if (wg == wg_stamp) { FPC_STAMP(0) }
+
+    f32x4 acc[36][NB];
+#pragma unroll
+    for (int p = 0; p < 36; ++p)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[p][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    BF bq[RING];
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) bq[i] = ldb(i);
+
+    // ---------------------------------------------------------------- phase 1: 36 GEMMs per chunk, input side of the next chunks in between
+    auto chunk_body = [&](auto PAR, const int c) {
+      constexpr int par = decltype(PAR)::value;
+      constexpr int VB_OFF = par ? C::OFF_V1 : C::OFF_V0, VN_OFF = par ? C::OFF_V0 : C::OFF_V1;
+      constexpr int HS_OFF = par ? C::OFF_H1 : C::OFF_H0;   // halo[c & 1]: receives chunk c + 2
+      constexpr int HN_OFF = par ? C::OFF_H0 : C::OFF_H1;   // halo[(c + 1) & 1]: chunk c + 1, transformed now
+      const int c3 = c + 3;
+      const int l_wg = c3 < nchunk ? wg : wg + wg_step;
+      const int l_c = c3 < nchunk ? c3 : c3 - nchunk;
+      int ao = aoff + VB_OFF, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
+      asm volatile("" : "+v"(ao), "+v"(trd_c), "+v"(twr_c));
+      // A operand: two register sets, the next step's read while this step's MFMAs run
+      constexpr int AQ = NB == 2 ? 1 : 2;       // positions per step
+      f32x4 ac[2][AQ];
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) ac[0][q] = *reinterpret_cast<const f32x4*>(lds + ao + q * 256);
+      fpc_static_for<STEPS>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        bq[(s + RING - 1) % RING] = ldb(c * STEPS + s + RING - 1);
+        const BF bv = bq[s % RING];
+        if (s + 1 < STEPS) {
+#pragma unroll
+          for (int q = 0; q < AQ; ++q) ac[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(lds + ao + ((s + 1) * AQ + q) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int p = NB == 2 ? s : 2 * s + q, nb = NB == 2 ? q : 0;
+            const f32x4 av = ac[s & 1][NB == 2 ? 0 : q];
+            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv.v[q][j], acc[p][nb], 0, 0, 0);
+          }
+        // input side, dealt over the steps in `slots` (36 per chunk): LDS instructions ride beside the MFMAs, VALU work
+        // comes in two bursts (the halo request's address arithmetic, the transform)
+        constexpr int SPS = 36 / STEPS;   // slots per step
+#pragma unroll
+        for (int u = 0; u < SPS; ++u) {
+          const int slot = s * SPS + u;
+          if (slot == 0) store_halo(HS_OFF);
+          else if (slot == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_halo(l_wg, l_c);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (slot >= 2 && slot < 14) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const int e = (slot - 2) * 3 + k; t_read(trd_c, e / 6, e % 6); }
+          } else if (slot == 14) {
+            __builtin_amdgcn_sched_barrier(0);
+            t_burst();
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (slot >= 15 && slot < 33) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int e = (slot - 15) * 2 + k; t_write(twr_c, e / 6, e % 6); }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      FPC_LDS_BARRIER();
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): once per tile (see wblock16_kernel)
+    for (int c = 0; c < nchunk; c += 2) {
+      chunk_body(std::integral_constant<int, 0>{}, c);
+      chunk_body(std::integral_constant<int, 1>{}, c + 1);
+    }
+    if (wg == wg_stamp) { FPC_STAMP(1) }
+
+    // ---------------------------------------------------------------- output transform in registers; then the two halves of the tile
+    int tid_t = tid;
+    asm volatile("" : "+v"(tid_t));
+    const int lane_t = tid_t & 63, n16 = lane_t & 15, kq = lane_t >> 4;
+    const bool proj = a.k8_x > 0;
+    // Y = A^T M A + bias, ReLU: the first half's two tiles of every lane go to LDS (h) at once, the second half's wait in
+    // registers (64) while the first half runs its 1x1 -- so that the 288 accumulators are dead before phase 2 starts
+    float yh1[NB][2][16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const float bias1 = b1h[16 * (wave * NB + nb) + n16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tt[4][6];     // A^T M: rows 0..3, columns 0..5
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float m0 = acc[0 * 6 + j][nb][r], m1 = acc[1 * 6 + j][nb][r], m2 = acc[2 * 6 + j][nb][r];
+          const float m3 = acc[3 * 6 + j][nb][r], m4 = acc[4 * 6 + j][nb][r], m5 = acc[5 * 6 + j][nb][r];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          tt[0][j] = m0 + s12 + s34;
+          tt[1][j] = __builtin_fmaf(2.f, d34, d12);
+          tt[2][j] = __builtin_fmaf(4.f, s34, s12);
+          tt[3][j] = __builtin_fmaf(8.f, d34, d12) + m5;
+        }
+        const int th = 2 * kq + (r & 1);                  // tile within its half: T & 7 with T = 8 (r >> 1) + 2 kq + (r & 1)
+        const int hp0 = (4 * (th / TXT)) * TW + 4 * (th % TXT);
+        float* hp = TL + hp0 * RH + 16 * (wave * NB + nb) + n16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float m0 = tt[i][0], m1 = tt[i][1], m2 = tt[i][2], m3 = tt[i][3], m4 = tt[i][4], m5 = tt[i][5];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          float yv[4];
+          yv[0] = m0 + s12 + s34 + bias1;
+          yv[1] = __builtin_fmaf(2.f, d34, d12) + bias1;
+          yv[2] = __builtin_fmaf(4.f, s34, s12) + bias1;
+          yv[3] = __builtin_fmaf(8.f, d34, d12) + m5 + bias1;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float v = yv[jj] > 0.f ? yv[jj] : 0.f;
+            if (r < 2) hp[(i * TW + jj) * RH] = v;
+            else yh1[nb][r - 2][i * 4 + jj] = v;
+          }
+        }
+      }
+    }
+
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int y0 = ty * TH + half * (TH / 2), x0 = tx * TW;       // first pixel of the half: HPX = (TH / 2) x TW pixels, row-major
+      if (half == 1) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int th = 2 * kq + rr;
+            const int hp0 = (4 * (th / TXT)) * TW + 4 * (th % TXT);
+            float* hp = TL + hp0 * RH + 16 * (wave * NB + nb) + n16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) hp[(i * TW + jj) * RH] = yh1[nb][rr][i * 4 + jj];
+          }
+      }
+      FPC_LDS_BARRIER();
+      // ------------------------------------------------ shortcut operands requested now, used after the GEMM over h
+      constexpr int C4 = N / 4, EIT = HPX * C4 / NT;                // output float4 per thread: 16 (N = 128) or 8
+      constexpr int XIT = HPX * 32 / NT;                            // x staging float4 per thread and pass: 16
+      f32x4 xst[XIT];
+      auto load_x = [&](int pass) {    // projection: up to 128 channels of the half's pixels, [px][32 float4]
+        const int kx4 = min(32, a.k8_x * 2 - pass * 32);
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+          const int e = tid_t + i * NT;
+          const int m = e >> 5, c4 = e & 31;
+          int y = y0 + m / TW, x = x0 + m % TW;
+          y = y < a.H ? y : a.H - 1;
+          x = x < a.W ? x : a.W - 1;
+          const bool ok = c4 < kx4;
+          xst[i] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + (ok ? pass * 128 + c4 * 4 : 0));
+        }
+      };
+      if (!a.conv_only) {
+        if (proj) load_x(0);
+        else {                          // identity: x in the layout of the output stores, added in the epilogue
+#pragma unroll
+          for (int i = 0; i < EIT; ++i) {
+            const int e = tid_t + i * NT;
+            const int m = e / C4, c4 = e - m * C4;
+            int y = y0 + m / TW, x = x0 + m % TW;
+            y = y < a.H ? y : a.H - 1;
+            x = x < a.W ? x : a.W - 1;
+            xst[i] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4);
+          }
+        }
+      }
+      if (wg == wg_stamp && half == 0) { FPC_STAMP(2) }
+
+      if (a.conv_only) {  // h is the result: [128 px][N] in LDS -> 16-byte stores
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+          const int e = tid_t + i * NT;
+          const int m = e / C4, c4 = e - m * C4;
+          const int y = y0 + m / TW, x = x0 + m % TW;
+          if (y < a.H && x < a.W)
+            *reinterpret_cast<f32x4*>(outh + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(TL + m * RH + c4 * 4);
+        }
+        FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
+        continue;
+      }
+
+      // ------------------------------------------------ phase 2: 1x1 over h (+ projection over x), 8 pixel blocks x NB channel blocks per wave
+      f32x4 acc2[8][NB];
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const size_t g2stride = ((size_t)(a.k8_h + a.k8_x) / 2 + C::WPAD2) * 64;     // float4 per channel group
+      const float4* const w2s = a.w2 + (size_t)(wave * NB) * g2stride;
+      auto ldb2 = [&](int s, int nb) { return fpc_ldg_su(w2s + (size_t)nb * g2stride + (size_t)s * 64, lane16); };
+      constexpr int KH = N / 16;
+      auto gemm_step = [&](const float* rows, int rstride, int kcol, const float4* bv) {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(rows + (16 * mb + n16) * rstride + kcol + 4 * kq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const float bf = j == 0 ? bv[nb].x : j == 1 ? bv[nb].y : j == 2 ? bv[nb].z : bv[nb].w;
+              acc2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bf, acc2[mb][nb], 0, 0, 0);
+            }
+        }
+      };
+      {
+        float4 cb[4][NB];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) cb[i][nb] = ldb2(i, nb);
+#pragma unroll
+        for (int g = 0; g < KH; ++g) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) cb[(g + 3) & 3][nb] = ldb2(g + 3, nb);
+          __builtin_amdgcn_sched_barrier(0);
+          gemm_step(TL, RH, 16 * g, cb[g & 3]);
+        }
+      }
+      if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
+      if (proj) {
+        const int npass = (a.k8_x + 15) >> 4;
+        for (int pass = 0; pass < npass; ++pass) {
+          FPC_LDS_BARRIER();   // h (or the previous pass's x) has been read by every wave
+#pragma unroll
+          for (int i = 0; i < XIT; ++i) {
+            const int e = tid_t + i * NT;
+            *reinterpret_cast<f32x4*>(TL + (e >> 5) * RX + (e & 31) * 4) = xst[i];
+          }
+          FPC_LDS_BARRIER();
+          if (pass + 1 < npass) load_x(pass + 1);
+          const int steps = min(8, a.k8_x / 2 - pass * 8);   // 16-channel steps of this pass: 4 or 8
+          const int s0 = KH + pass * 8;
+          float4 cb[4][NB];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) cb[i][nb] = ldb2(s0 + i, nb);
+          for (int g = 0; g < steps; g += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) cb[(u + 3) & 3][nb] = ldb2(s0 + g + u + 3, nb);
+              __builtin_amdgcn_sched_barrier(0);
+              gemm_step(TL, RX, 16 * (g + u), cb[u & 3]);
+            }
+          }
+        }
+      }
+
+      // ------------------------------------------------ epilogue: output tile through LDS -> 16-byte stores
+      if (wg == wg_stamp && half == 0) { FPC_STAMP(4) }
+      FPC_LDS_BARRIER();
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float bias = a.b2[16 * (wave * NB + nb) + n16];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) TL[(16 * mb + 4 * kq + r) * RH + 16 * (wave * NB + nb) + n16] = acc2[mb][nb][r] + bias;
+      }
+      FPC_LDS_BARRIER();
+#pragma unroll
+      for (int i = 0; i < EIT; ++i) {
+        const int e = tid_t + i * NT;
+        const int m = e / C4, c4 = e - m * C4;
+        const int y = y0 + m / TW, x = x0 + m % TW;
+        if (y < a.H && x < a.W) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(TL + m * RH + c4 * 4);
+          if (!proj) v += xst[i];
+          v.x = v.x > 0.f ? v.x : 0.f;
+          v.y = v.y > 0.f ? v.y : 0.f;
+          v.z = v.z > 0.f ? v.z : 0.f;
+          v.w = v.w > 0.f ? v.w : 0.f;
+          *reinterpret_cast<f32x4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) = v;
+        }
+      }
+      if (wg == wg_stamp && half == 0) { FPC_STAMP(5) }
+      FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
+    }  // halves
+  }  // persistent tile loop
+}
+
+}  // namespace fpc
