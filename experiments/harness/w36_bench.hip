@@ -10,6 +10,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#include <algorithm>
 #include "../../feature-point-cnn_amd/csrc/wblock36_mfma.h"
 using namespace fpc;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -83,6 +84,9 @@ static double run(const Problem& P, bool check, int reps, int grid_override = 0)
   a.tiles_x = (P.W + C::TW - 1) / C::TW; a.tiles_y = (P.H + C::TH - 1) / C::TH; a.frame0 = 0;
   a.total = a.tiles_x * a.tiles_y * P.B; a.xcd_order = 1; a.ysplit_floats = (int)half_floats;
   a.x_bytes = (unsigned)(x.size() * 4); a.conv_only = P.conv_only ? 1 : 0;
+#ifdef FPC_DIAG
+  unsigned long long* dst_; CK(hipMalloc(&dst_, 1024 * 8 * 8 + 1024 * 4 * 16 * 8)); CK(hipMemset(dst_, 0, 1024 * 8 * 8 + 1024 * 4 * 16 * 8)); a.stamps = dst_;
+#endif
   CK(hipFuncSetAttribute((const void*)wblock36_kernel<NB, TYT, TXT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
   int grid = grid_override ? grid_override : 256;
   if (grid > a.total) grid = a.total >= 8 ? (a.total / 8) * 8 : a.total;
@@ -147,6 +151,35 @@ static double run(const Problem& P, bool check, int reps, int grid_override = 0)
     printf("  time NB=%d %dx%d tiles  B=%d %dx%d Cin=%d N=%d Cx=%d conv_only=%d grid=%d: best %.4f ms, mean %.4f ms, %d tiles, %.1f TFLOP/s algorithmic\n", NB, TYT, TXT,
            P.B, P.H, P.W, P.Cin, N, P.Cx, (int)P.conv_only, grid, best, sum / reps, a.total, 2 * macs / (best * 1e-3) / 1e12);
     result = best;
+#ifdef FPC_DIAG
+    {
+      std::vector<unsigned long long> st(1024 * 8);
+      CK(hipMemcpy(st.data(), a.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+      // stamps 0..5 of a workgroup's third tile: tile start, chunk loop end, h written (half 0), 1x1 over h done, GEMMs done, half 0 stored
+      const char* nm[5] = {"chunk loop", "out transform + h", "1x1 over h", "projection", "epilogue half 0"};
+      for (int k = 0; k < 5; ++k) {
+        std::vector<double> d;
+        for (int g2 = 0; g2 < grid; ++g2) if (st[g2 * 8 + k + 1] > st[g2 * 8 + k] && st[g2 * 8 + k]) d.push_back((double)(st[g2 * 8 + k + 1] - st[g2 * 8 + k]));
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        printf("      stamp %-20s median %8.0f ticks  (min %.0f, max %.0f, n %zu)\n", nm[k], d[d.size() / 2], d.front(), d.back(), d.size());
+      }
+      // inside chunk 2 of that tile, per wave: stamps at every (STEPS / 9)-th step, loop end, behind the barrier
+      std::vector<unsigned long long> tq(1024 * 4 * 16);
+      CK(hipMemcpy(tq.data(), a.stamps + 1024 * 8, tq.size() * 8, hipMemcpyDeviceToHost));
+      for (int w = 0; w < 4; ++w) {
+        printf("      chunk 2, wave %d:", w);
+        for (int k = 0; k < 10; ++k) {
+          std::vector<double> d;
+          for (int g2 = 0; g2 < grid; ++g2) { const unsigned long long* q = &tq[(g2 * 4 + w) * 16]; if (q[k + 1] > q[k] && q[k]) d.push_back((double)(q[k + 1] - q[k])); }
+          if (d.empty()) { printf("     -"); continue; }
+          std::sort(d.begin(), d.end());
+          printf(" %5.0f", d[d.size() / 2]);
+        }
+        printf("\n");
+      }
+    }
+#endif
   }
   hipFree(dx); hipFree(dw1); hipFree(dw2); hipFree(db2); hipFree(dout);
   return result;

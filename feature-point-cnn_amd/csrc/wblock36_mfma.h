@@ -60,8 +60,11 @@ struct W36Cfg {
   static constexpr int TH = 4 * TYT, TW = 4 * TXT, HH = TH + 2, HW = TW + 2, NHALO = HH * HW;
   static constexpr int N = 64 * NB;
   static constexpr int HROW = 20;                                   // halo row: 16 channels + 4 floats of skew
-  static constexpr int HIT = (NHALO * 4 + NT - 1) / NT;             // float4 per thread and chunk (6)
-  static constexpr int HALO_FLOATS = HIT * NT / 4 * HROW;           // every thread stores all its float4 (slots >= NHALO are padding)
+  // The halo arrives by LDS-DMA (buffer_load_dwordx4 ... lds): a wave instruction writes 64 consecutive 16-byte slots,
+  // so the buffer is addressed in slots -- five per pixel (four channel quads + the skew slot, which receives zeros) --
+  // and thread t requests slots t, t + 256, ... : HIT per thread and chunk (7), no staging registers, no ds_write.
+  static constexpr int HIT = (NHALO * 5 + NT - 1) / NT;
+  static constexpr int HALO_FLOATS = HIT * NT * 4;
   static constexpr int V_FLOATS = NPOS * 16 * 16;
   // V0 | halo1 | halo0 | V1: at a tile's end V0 and halo1 hold the next tile's first chunks; halo0, V1 and the rest
   // of the LDS are free for h, the shortcut's x tile and the output tile of one half
@@ -81,17 +84,47 @@ struct W36Cfg {
   // to hold the fragments of that whole latency (RING - 1 steps of 256 cycles).
   static constexpr int RING = NB == 2 ? 9 : 18;
   static_assert(STEPS % RING == 0, "ring slots must line up across chunks");
+  static constexpr int PAG = NB == 2 ? 30 : 36;                     // positions whose accumulators live in AGPRs (240 of 256; the other 48 registers in VGPRs)
   static constexpr int WPAD = 2 * RING;                             // zero POSITIONS behind every channel group's stream
   static constexpr int WPAD2 = 16;                                  // ... and steps behind the 1x1 streams (as generation 2)
 };
+
+// Eight v_mfma_f32_16x16x4_f32 as ONE asm statement: two accumulators alternate (a single dependent chain would run at
+// 40 instead of 32 cycles per MFMA), each pinned to the AGPR half (AG) or the VGPR half of the register file.
+//  * 288 accumulators do not fit the 256 AGPRs; left to the compiler (the builtin), the ones that do not fit travel
+//    between the two halves around every MFMA (220 v_accvgpr moves per chunk, each a VALU instruction, and the VALU
+//    excludes the MFMA, see above) and the chains of one accumulator are issued back to back.
+//  * With one wave per SIMD ANY instruction between two MFMAs delays the second by ~6 cycles (co-issue harness: one
+//    ds_read per MFMA 38.5 cycles instead of 32, three 39.6): the non-MFMA instructions of a step belong in ONE gap, in
+//    front of its eight MFMAs.  As separate asm statements the compiler put its own s_nop / s_waitcnt / address
+//    arithmetic between them: a step took 295 cycles instead of 256 + one gap.
+template <bool AG0, bool AG1>
+__device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
+#define FPC_MFMA8                                                                                                      \
+  "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %14, %1\n\t"                                \
+  "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"                                \
+  "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"                                \
+  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %17, %1"
+#define FPC_MFMA8_IN                                                                                                   \
+  "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b0[0]), "v"(b0[1]), \
+      "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3])
+  if constexpr (AG0 && AG1) asm volatile(FPC_MFMA8 : "+a"(c0), "+a"(c1) : FPC_MFMA8_IN);
+  else if constexpr (AG0) asm volatile(FPC_MFMA8 : "+a"(c0), "+v"(c1) : FPC_MFMA8_IN);
+  else if constexpr (AG1) asm volatile(FPC_MFMA8 : "+v"(c0), "+a"(c1) : FPC_MFMA8_IN);
+  else asm volatile(FPC_MFMA8 : "+v"(c0), "+v"(c1) : FPC_MFMA8_IN);
+#undef FPC_MFMA8
+#undef FPC_MFMA8_IN
+}
 
 template <int NB, int TYT, int TXT>
 __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   using C = W36Cfg<NB, TYT, TXT>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HW = C::HW, HH = C::HH, HROW = C::HROW, HIT = C::HIT;
   constexpr int N = C::N, RH = C::RH, RX = C::RX, RING = C::RING, STEPS = C::STEPS, HPX = C::HPX;
-  extern __shared__ float lds[];
-  float* const TL = lds + C::OFF_H0;        // h, x staging, output tile of one half
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  f32x4* const lds4 = reinterpret_cast<f32x4*>(lds);
+  constexpr int TL4 = C::OFF_H0 / 4;        // h, x staging, output tile of one half (float4 units)
+  float* const TL = lds + C::OFF_H0;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -101,7 +134,6 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   // second half of a 256-wide conv-only layer (gridDim.y == 2)
   const float4* const w1h = a.w1 + (size_t)blockIdx.y * (a.ysplit_floats / 4);
   const float* const b1h = a.b1 + (size_t)blockIdx.y * a.ysplit_floats;
-  float* const outh = a.out + blockIdx.y * N;
 
   // tile walk (persistent, XCD-aware): as wblock16_kernel
   const bool xcd_order = a.xcd_order && (gridDim.x & 7) == 0;
@@ -114,41 +146,53 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   // ---------------------------------------------------------------- input side: L (global -> registers), S (-> halo), T (halo -> V)
   // As generation 2: buffer loads with the hardware's bounds check (out-of-frame pixels, padding slots and tiles behind
   // the workgroup's last one get an offset outside the descriptor's range and come back as zeros).
-  f32x4 stage[HIT];
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  auto load_halo = [&](int wg, int chunk) {            // chunk `chunk` of tile wg
+  // Slot q = t + 256 i of this thread: halo pixel q / 5 = (hy, hx), channel quad q % 5 (4 = the skew slot).  Its byte
+  // offset from the tile's FIRST PIXEL is a constant of the thread; whether it lies inside the frame depends on the tile.
+  // okoff[i] = that offset, or a huge positive number where the slot must read as zero (outside the frame, skew or
+  // padding slot, a tile behind the workgroup's last); the request adds the tile's (uniform, non-negative) base with
+  // SIGNED SATURATION, which leaves the huge ones outside the descriptor's range (zeros from the hardware's bounds
+  // check): one VALU instruction per slot and chunk (the first version recomputed rows, columns and flags per chunk: 13
+  // instructions per element in the MFMA stream, and the VALU excludes the MFMA).
+  int okoff[HIT];
+  struct TilePos { int b, ty, tx, live; };
+  auto tile_pos = [&](int wg) {                          // uniform (SALU) arithmetic: once per tile, not per chunk
+    TilePos q;
+    q.live = wg < wg_end;
+    const int wgc = q.live ? wg : wg_first;
+    const int bl = wgc / tiles;
+    const int t = wgc - bl * tiles;
+    q.b = a.frame0 + bl;
+    q.ty = t / a.tiles_x;
+    q.tx = t - q.ty * a.tiles_x;
+    return q;
+  };
+  auto halo_base = [&](const TilePos& q) {               // byte offset of the tile's first pixel, channel 0
+    return __builtin_amdgcn_readfirstlane(((q.b * a.H + q.ty * TH) * a.W + q.tx * TW) * a.csx * 4);
+  };
+  auto halo_tile = [&](const TilePos& q) {               // okoff[] for that tile
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    const bool live = wg < wg_end;
-    const int wgc = live ? wg : wg_first;
-    const int bl = wgc / tiles;
-    const int bb = a.frame0 + bl;
-    const int t = wgc - bl * tiles;
-    const int tyy = t / a.tiles_x, txx = t - tyy * a.tiles_x;
-    const int iy0 = tyy * TH - 1, ix0 = txx * TW - 1;
-    const int hlim = live ? a.H : 0;
-    const unsigned base = (unsigned)((bb * a.H + iy0) * a.W + ix0) * (unsigned)(a.csx * 4) + (unsigned)(chunk * 64);
+    const int iy0 = q.ty * TH - 1, ix0 = q.tx * TW - 1;
+    const int hlim = q.live ? a.H : 0;
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
       const int e = tl + i * NT;
-      const int pix = e >> 2, c4 = e & 3;
+      const int pix = (e * 13108) >> 16, c4 = e - pix * 5;                    // e / 5 (e < 1792: 13108 / 65536 = 0.2 + 1.2e-5)
       const int hy = HW == 18 ? (pix * 3641) >> 16 : (pix * 1928) >> 16;     // pix / 18 (pix < 469), pix / 34 (pix < 441)
       const int hx = pix - hy * HW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = ((unsigned)iy < (unsigned)hlim) & ((unsigned)ix < (unsigned)a.W) & (hy < HH);
-      unsigned in_off = base + (unsigned)((hy * a.W + hx) * a.csx * 4 + c4 * 16);
-      asm volatile("" : "+v"(in_off));
-      const unsigned voff = ok ? in_off : 0xfffffff0u;
-      stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff, 0, 0));
+      const bool ok = ((unsigned)(iy0 + hy) < (unsigned)hlim) & ((unsigned)(ix0 + hx) < (unsigned)a.W) & (hy < HH) & (c4 < 4);
+      const int off = (((hy - 1) * a.W + (hx - 1)) * a.csx + c4 * 4) * 4;
+      okoff[i] = ok ? off : 0x7fffff00;
     }
   };
-  auto store_halo = [&](int hoff) {
-    int tl = tid;
-    asm volatile("" : "+v"(tl));
+  auto load_halo = [&](int base, int hoff) {             // base: halo_base of the tile + 64 bytes per chunk; hoff: the halo buffer (floats)
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
-      const int e = tl + i * NT;
-      *reinterpret_cast<f32x4*>(lds + hoff + (e >> 2) * HROW + (e & 3) * 4) = stage[i];
+      int voff;
+      asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(okoff[i]), "s"(base));
+      // (the instruction's LDS address is M0 + 16 lane: M0 = this wave's 64 slots of request i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(lds + hoff + (i * NT + wave * 64) * 4), 16, voff, 0, 0, 0);
     }
   };
   // the transform item of this thread: Winograd tile wt (0..15), channel ch (0..15) of the chunk; V row m = Tinv(wt)
@@ -157,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   const int trd = ((4 * (wt_t / TXT)) * HW + 4 * (wt_t % TXT)) * HROW + ch_t;                          // halo read base
   const int twr = m_t * 16 + ((((ch_t >> 2) ^ (2 * ((m_t >> 3) & 1))) << 2) | (ch_t & 3));            // V write base (swizzled)
   float td[6][6];
-  auto t_read = [&](int rd, int i, int j) { td[i][j] = lds[rd + (i * HW + j) * HROW]; };
+    auto t_read = [&](int rd, int i, int j) { td[i][j] = lds[rd + (i * HW + j) * HROW]; };
   // B^T x for the six values x0..x5 (in place): the F(4x4,3x3) input transform along one axis, 12 operations
   auto bt6 = [&](float& x0, float& x1, float& x2, float& x3, float& x4, float& x5) {
     const float p = __builtin_fmaf(-4.f, x2, x4), q = __builtin_fmaf(-4.f, x1, x3);
@@ -192,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
 
   // ---------------------------------------------------------------- operands of the GEMMs
   // A: V[pos][m][16 ch] -- lane (row m = l & 15, k quarter kq = l >> 4) reads one float4
-  const int aoff = (lane & 15) * 16 + (((lane >> 4) ^ (2 * ((lane & 15) >> 3))) << 2);
+  const int aoff4 = (lane & 15) * 4 + ((lane >> 4) ^ (2 * ((lane & 15) >> 3)));      // in float4 units
   // B: the fragment streams of this wave's NB channel groups, [chunk][pos][64 lanes] float4 each
   const unsigned gstride = ((unsigned)nchunk * 36u + (unsigned)C::WPAD) * 1024u;        // bytes per channel group
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(w1h), 0, (int)(4u * (unsigned)NB * gstride), 0x00020000);
@@ -201,6 +245,9 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   struct BF { f32x4 v[2]; };
   auto ldb = [&](int s) {      // ring step s (counted from the tile's first chunk)
     BF r;
+#ifdef W36_EXPERIMENT_SAME_FRAGMENTS
+    s &= 7;     // (harness only: every step re-reads the same 16 KB per wave -- how much of a step is L2 -> CU traffic?)
+#endif
     if (NB == 2) {
       r.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024, 0));
       r.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024 + gs_s, 0));
@@ -212,23 +259,28 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   };
 
   // ---------------------------------------------------------------- pipeline fill for the first tile
-  load_halo(wg_first, 0);
-  store_halo(C::OFF_H0);
-  load_halo(wg_first, 1);
+  TilePos pos_cur = tile_pos(wg_first);
+  int base_cur = halo_base(pos_cur);
+  halo_tile(pos_cur);
+  load_halo(base_cur, C::OFF_H0);
+  load_halo(base_cur + 64, C::OFF_H1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HIT) : "memory");      // chunk 0 has landed (this wave's part of it)
   FPC_LDS_BARRIER();
   transform_all(C::OFF_H0, C::OFF_V0);
-  store_halo(C::OFF_H1);
-  load_halo(wg_first, 2);
   FPC_LDS_BARRIER();
-  // state at the top of iteration c of a tile: V[c & 1] = chunk c transformed; halo[(c + 1) & 1] = chunk c + 1 stored;
-  // stage = chunk c + 2 requested
+  // state at the top of iteration c of a tile: V[c & 1] = chunk c transformed; halo[(c + 1) & 1] = chunk c + 1 requested
+  // (landed, as far as this wave's own requests go, by the barrier that ended iteration c - 1)
+
+  // the tail's per-thread constants: output float4 e = tid + 256 i of a half lies at pixel m0 + PPI i, channel quad c4
+  constexpr int C4 = N / 4, EIT = HPX * C4 / NT, PPI = NT / C4;       // float4 per pixel; float4 per thread (16 / 8); pixels per i (8 / 16)
+  constexpr int CPR = TW / PPI;                                      // column steps per pixel row (1, 2 or 4)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + blockIdx.y * N, 0, 0x7ffffff0, 0x00020000);
 
   const int wg_stamp = wg_first + 2 * wg_step < wg_end ? wg_first + 2 * wg_step : wg_first;
   for (int wg = wg_first; wg < wg_end; wg += wg_step) {
-    const int bl = wg / tiles;
-    const int b = a.frame0 + bl;
-    const int t = wg - bl * tiles;
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int b = pos_cur.b, ty = pos_cur.ty, tx = pos_cur.tx;
+    const TilePos pos_next = tile_pos(wg + wg_step);
+    const int base_next = halo_base(pos_next);
     if (wg == wg_stamp) { FPC_STAMP(0) }
 
     f32x4 acc[36][NB];
@@ -247,58 +299,76 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       constexpr int VB_OFF = par ? C::OFF_V1 : C::OFF_V0, VN_OFF = par ? C::OFF_V0 : C::OFF_V1;
       constexpr int HS_OFF = par ? C::OFF_H1 : C::OFF_H0;   // halo[c & 1]: receives chunk c + 2
       constexpr int HN_OFF = par ? C::OFF_H0 : C::OFF_H1;   // halo[(c + 1) & 1]: chunk c + 1, transformed now
-      const int c3 = c + 3;
-      const int l_wg = c3 < nchunk ? wg : wg + wg_step;
-      const int l_c = c3 < nchunk ? c3 : c3 - nchunk;
-      int ao = aoff + VB_OFF, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
+      const int c3 = c + 2;                                 // the chunk requested now: c + 2 of this tile or c + 2 - nchunk of the next one
+      const bool nxt = c3 >= nchunk;
+      const int l_base = (nxt ? base_next : base_cur) + (nxt ? c3 - nchunk : c3) * 64;
+      int ao = aoff4 + VB_OFF / 4, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
       asm volatile("" : "+v"(ao), "+v"(trd_c), "+v"(twr_c));
       // A operand: two register sets, the next step's read while this step's MFMAs run
       constexpr int AQ = NB == 2 ? 1 : 2;       // positions per step
       f32x4 ac[2][AQ];
 #pragma unroll
-      for (int q = 0; q < AQ; ++q) ac[0][q] = *reinterpret_cast<const f32x4*>(lds + ao + q * 256);
+      for (int q = 0; q < AQ; ++q) ac[0][q] = lds4[ao + q * 64];
+#ifdef FPC_DIAG
+      unsigned long long tq[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FPC_TQ(i) if (a.stamps) asm volatile("s_memtime %0" : "=s"(tq[i]));
+#else
+#define FPC_TQ(i)
+#endif
       fpc_static_for<STEPS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
+#ifdef W36_TQ0      // (harness: stamps at steps W36_TQ0, W36_TQ0 + 1, ... instead of every fourth)
+        if constexpr (s >= W36_TQ0 && s < W36_TQ0 + 9) { FPC_TQ(s - W36_TQ0) }
+#else
+        if constexpr (s % (STEPS / 9) == 0) { FPC_TQ(s / (STEPS / 9)) }
+#endif
+        // ---- the step's gap: everything that is not an MFMA, in front of the eight MFMAs
         bq[(s + RING - 1) % RING] = ldb(c * STEPS + s + RING - 1);
-        const BF bv = bq[s % RING];
         if (s + 1 < STEPS) {
 #pragma unroll
-          for (int q = 0; q < AQ; ++q) ac[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(lds + ao + ((s + 1) * AQ + q) * 256);
+          for (int q = 0; q < AQ; ++q) ac[(s + 1) & 1][q] = lds4[ao + ((s + 1) * AQ + q) * 64];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int p = NB == 2 ? s : 2 * s + q, nb = NB == 2 ? q : 0;
-            const f32x4 av = ac[s & 1][NB == 2 ? 0 : q];
-            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv.v[q][j], acc[p][nb], 0, 0, 0);
-          }
-        // input side, dealt over the steps in `slots` (36 per chunk): LDS instructions ride beside the MFMAs, VALU work
-        // comes in two bursts (the halo request's address arithmetic, the transform)
+        // input side, dealt over the steps in `slots` (36 per chunk): LDS instructions ride in the gaps, VALU work comes
+        // in two bursts (the halo request, the transform)
         constexpr int SPS = 36 / STEPS;   // slots per step
 #pragma unroll
         for (int u = 0; u < SPS; ++u) {
           const int slot = s * SPS + u;
-          if (slot == 0) store_halo(HS_OFF);
-          else if (slot == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            load_halo(l_wg, l_c);
-            __builtin_amdgcn_sched_barrier(0);
+          if (slot == 1) {
+            if (c3 == nchunk) halo_tile(pos_next);      // (uniform; no memory operation inside, so the join merges identical counter states)
+            load_halo(l_base, HS_OFF);
           } else if (slot >= 2 && slot < 14) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) { const int e = (slot - 2) * 3 + k; t_read(trd_c, e / 6, e % 6); }
           } else if (slot == 14) {
-            __builtin_amdgcn_sched_barrier(0);
             t_burst();
-            __builtin_amdgcn_sched_barrier(0);
           } else if (slot >= 15 && slot < 33) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int e = (slot - 15) * 2 + k; t_write(twr_c, e / 6, e % 6); }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        // ---- eight MFMAs
+        {
+          const BF& bv = bq[s % RING];
+          constexpr int p0 = NB == 2 ? s : 2 * s, p1 = NB == 2 ? s : 2 * s + 1, n1 = NB == 2 ? 1 : 0;
+          fpc_mfma_step<(p0 < C::PAG), (p1 < C::PAG)>(acc[p0][0], acc[p1][n1], ac[s & 1][0], ac[s & 1][AQ - 1], bv.v[0], bv.v[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       });
+      FPC_TQ(9)
+      // this wave's halo requests of the chunk have landed in LDS: everything but the ring's newest fragments is complete
+      // (vmcnt counts in order; the ring waits above already imply it -- stated for the hardware, free)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING - 1)) : "memory");
       FPC_LDS_BARRIER();
+      FPC_TQ(10)
+#ifdef FPC_DIAG
+      if (a.stamps && wg == wg_stamp && c == 2 && (threadIdx.x & 63) == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned long long* q = a.stamps + 1024 * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+        for (int i = 0; i < 11; ++i) q[i] = tq[i];
+      }
+#endif
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): once per tile (see wblock16_kernel)
     for (int c = 0; c < nchunk; c += 2) {
@@ -306,6 +376,9 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       chunk_body(std::integral_constant<int, 1>{}, c + 1);
     }
     if (wg == wg_stamp) { FPC_STAMP(1) }
+    // (the last MFMAs' results are read by VALU instructions below: a wait the compiler manages for its own MFMAs and
+    // cannot see through the asm -- 8 passes need at most 18 wait states)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 
     // ---------------------------------------------------------------- output transform in registers; then the two halves of the tile
     int tid_t = tid;
@@ -315,12 +388,19 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
     // Y = A^T M A + bias, ReLU: the first half's two tiles of every lane go to LDS (h) at once, the second half's wait in
     // registers (64) while the first half runs its 1x1 -- so that the 288 accumulators are dead before phase 2 starts
     float yh1[NB][2][16];
-    __builtin_amdgcn_sched_barrier(0);
+    // h position of (tile-in-half th, pixel (0, 0), this lane's channel of block nb = 0): + (i TW + j) RH per pixel, + 16 per block
+    int hw_base[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int th = 2 * kq + rr;
+      hw_base[rr] = C::OFF_H0 + ((4 * (th / TXT)) * TW + 4 * (th % TXT)) * RH + 16 * (wave * NB) + n16;
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const float bias1 = b1h[16 * (wave * NB + nb) + n16];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        __builtin_amdgcn_sched_barrier(0);          // one (block, tile) at a time: reading all 288 accumulators ahead spills
         float tt[4][6];     // A^T M: rows 0..3, columns 0..5
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -332,9 +412,6 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           tt[2][j] = __builtin_fmaf(4.f, s34, s12);
           tt[3][j] = __builtin_fmaf(8.f, d34, d12) + m5;
         }
-        const int th = 2 * kq + (r & 1);                  // tile within its half: T & 7 with T = 8 (r >> 1) + 2 kq + (r & 1)
-        const int hp0 = (4 * (th / TXT)) * TW + 4 * (th % TXT);
-        float* hp = TL + hp0 * RH + 16 * (wave * NB + nb) + n16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float m0 = tt[i][0], m1 = tt[i][1], m2 = tt[i][2], m3 = tt[i][3], m4 = tt[i][4], m5 = tt[i][5];
@@ -347,46 +424,50 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             const float v = yv[jj] > 0.f ? yv[jj] : 0.f;
-            if (r < 2) hp[(i * TW + jj) * RH] = v;
+            if (r < 2) lds[hw_base[r & 1] + 16 * nb + (i * TW + jj) * RH] = v;
             else yh1[nb][r - 2][i * 4 + jj] = v;
           }
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // per-thread parts of the tail's global addresses (bytes), for this tile
+    const int m0 = tid_t / C4, c4t = tid_t - m0 * C4;
+    const int xpart = (m0 * a.csx + c4t * 4) * 4, opart = (m0 * a.cso + c4t * 4) * 4;
+    int ocol[CPR];                              // opart + column step k, or a huge positive number where that column is outside the frame
+#pragma unroll
+    for (int k = 0; k < CPR; ++k) ocol[k] = (tx * TW + m0 + k * PPI < a.W) ? opart + k * PPI * a.cso * 4 : 0x7fffff00;
 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int y0 = ty * TH + half * (TH / 2), x0 = tx * TW;       // first pixel of the half: HPX = (TH / 2) x TW pixels, row-major
+      const int rows_valid = min(TH / 2, a.H - y0);                 // (uniform) pixel rows of the half inside the frame
+      const int xbase = __builtin_amdgcn_readfirstlane(((b * a.H + y0) * a.W + x0) * a.csx * 4);
+      const int obase = __builtin_amdgcn_readfirstlane(((b * a.H + y0) * a.W + x0) * a.cso * 4);
       if (half == 1) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            const int th = 2 * kq + rr;
-            const int hp0 = (4 * (th / TXT)) * TW + 4 * (th % TXT);
-            float* hp = TL + hp0 * RH + 16 * (wave * NB + nb) + n16;
+          for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) hp[(i * TW + jj) * RH] = yh1[nb][rr][i * 4 + jj];
-          }
+              for (int jj = 0; jj < 4; ++jj) lds[hw_base[rr] + 16 * nb + (i * TW + jj) * RH] = yh1[nb][rr][i * 4 + jj];
       }
       FPC_LDS_BARRIER();
+      if (wg == wg_stamp && half == 0) { FPC_STAMP(2) }
       // ------------------------------------------------ shortcut operands requested now, used after the GEMM over h
-      constexpr int C4 = N / 4, EIT = HPX * C4 / NT;                // output float4 per thread: 16 (N = 128) or 8
       constexpr int XIT = HPX * 32 / NT;                            // x staging float4 per thread and pass: 16
       f32x4 xst[XIT];
-      auto load_x = [&](int pass) {    // projection: up to 128 channels of the half's pixels, [px][32 float4]
+      auto load_x = [&](int pass) {    // projection: up to 128 channels of the half's pixels, [px][32 float4]; pixel m = (tid >> 5) + 8 i
         const int kx4 = min(32, a.k8_x * 2 - pass * 32);
+        const int xp = ((tid_t >> 5) * a.csx + ((tid_t & 31) < kx4 ? pass * 128 + (tid_t & 31) * 4 : 0)) * 4;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-          const int e = tid_t + i * NT;
-          const int m = e >> 5, c4 = e & 31;
-          int y = y0 + m / TW, x = x0 + m % TW;
-          y = y < a.H ? y : a.H - 1;
-          x = x < a.W ? x : a.W - 1;
-          const bool ok = c4 < kx4;
-          xst[i] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + (ok ? pass * 128 + c4 * 4 : 0));
+          constexpr int XCPR = TW / 8;
+          const int so = xbase + ((i / XCPR) * a.W + (i % XCPR) * 8) * a.csx * 4;      // (uniform)
+          xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xp + so, 0, 0));
         }
       };
       if (!a.conv_only) {
@@ -394,27 +475,36 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
         else {                          // identity: x in the layout of the output stores, added in the epilogue
 #pragma unroll
           for (int i = 0; i < EIT; ++i) {
-            const int e = tid_t + i * NT;
-            const int m = e / C4, c4 = e - m * C4;
-            int y = y0 + m / TW, x = x0 + m % TW;
-            y = y < a.H ? y : a.H - 1;
-            x = x < a.W ? x : a.W - 1;
-            xst[i] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.csx + c4 * 4);
+            const int so = xbase + ((i / CPR) * a.W + (i % CPR) * PPI) * a.csx * 4;     // (uniform)
+            xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xpart + so, 0, 0));
           }
         }
       }
-      if (wg == wg_stamp && half == 0) { FPC_STAMP(2) }
-
-      if (a.conv_only) {  // h is the result: [128 px][N] in LDS -> 16-byte stores
+      // output float4 i of this thread: LDS [m0 + PPI i][c4t], global row i / CPR, column step i % CPR
+      int erd = TL4 + m0 * (RH / 4) + c4t;
+      asm volatile("" : "+v"(erd));
+      auto store_out = [&](bool add_x) {
 #pragma unroll
         for (int i = 0; i < EIT; ++i) {
-          const int e = tid_t + i * NT;
-          const int m = e / C4, c4 = e - m * C4;
-          const int y = y0 + m / TW, x = x0 + m % TW;
-          if (y < a.H && x < a.W)
-            *reinterpret_cast<f32x4*>(outh + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) =
-                *reinterpret_cast<const f32x4*>(TL + m * RH + c4 * 4);
+          if (i / CPR < rows_valid) {                                     // (uniform)
+            f32x4 v = lds4[erd + i * PPI * (RH / 4)];
+            if (add_x) v += xst[i];
+            if (!a.conv_only) {
+              v.x = v.x > 0.f ? v.x : 0.f;
+              v.y = v.y > 0.f ? v.y : 0.f;
+              v.z = v.z > 0.f ? v.z : 0.f;
+              v.w = v.w > 0.f ? v.w : 0.f;
+            }
+            int voff;
+            const int so = obase + (i / CPR) * a.W * a.cso * 4;           // (uniform)
+            asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(ocol[i % CPR]), "s"(so));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), orsrc, voff, 0, 0);
+          }
         }
+      };
+
+      if (a.conv_only) {  // h is the result: [128 px][N] in LDS -> 16-byte stores (ReLU already applied)
+        store_out(false);
         FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
         continue;
       }
@@ -427,96 +517,110 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const size_t g2stride = ((size_t)(a.k8_h + a.k8_x) / 2 + C::WPAD2) * 64;     // float4 per channel group
       const float4* const w2s = a.w2 + (size_t)(wave * NB) * g2stride;
-      auto ldb2 = [&](int s, int nb) { return fpc_ldg_su(w2s + (size_t)nb * g2stride + (size_t)s * 64, lane16); };
-      constexpr int KH = N / 16;
-      auto gemm_step = [&](const float* rows, int rstride, int kcol, const float4* bv) {
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(rows + (16 * mb + n16) * rstride + kcol + 4 * kq);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              const float bf = j == 0 ? bv[nb].x : j == 1 ? bv[nb].y : j == 2 ? bv[nb].z : bv[nb].w;
-              acc2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bf, acc2[mb][nb], 0, 0, 0);
-            }
-        }
+      auto ldb2 = [&](int s, int nb) {
+        const float4 v = fpc_ldg_su(w2s + (size_t)nb * g2stride + (size_t)s * 64, lane16);
+        return f32x4{v.x, v.y, v.z, v.w};
       };
-      {
-        float4 cb[4][NB];
+      constexpr int KH = N / 16;
+      // one 16-channel step of the GEMM: blocks of eight MFMAs (one pixel block x 2 channel blocks, or two pixel blocks x 1),
+      // the next block's A fragment(s) read in the gap in front of this block's MFMAs
+      constexpr int NBLK = NB == 2 ? 8 : 4, APB = NB == 2 ? 1 : 2;      // blocks per step, A fragments per block
+      auto gemm_step = [&](int arow4, const f32x4* bv, f32x4 (&af)[2][APB], bool prefetch_next_step, int arow4_next) {
+        // arow4: float4 index of (pixel n16 of block 0, channels 16 g + 4 kq) ; pixel block mb lies 16 rows further
+        fpc_static_for<NBLK>([&](auto B_) __attribute__((always_inline)) {
+          constexpr int blk = decltype(B_)::value;
+          if (blk + 1 < NBLK) {
+#pragma unroll
+            for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[arow4 + ((blk + 1) * APB + q) * 16 * (RX / 4)];
+          } else if (prefetch_next_step) {
+#pragma unroll
+            for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[arow4_next + q * 16 * (RX / 4)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NB == 2) fpc_mfma_step<true, true>(acc2[blk][0], acc2[blk][1], af[blk & 1][0], af[blk & 1][0], bv[0], bv[1]);
+          else fpc_mfma_step<true, true>(acc2[2 * blk][0], acc2[2 * blk + 1][0], af[blk & 1][0], af[blk & 1][APB - 1], bv[0], bv[0]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      static_assert(RH == RX || NB == 1, "the h tile and the x tile share the row pitch (N = 128)");
+      // (rows of RH floats for h, RX for x: gemm_step is written for RX; for N = 64 the h rows are 72 floats and h uses its own pitch below)
+      auto gemm_over = [&](int row_pitch4, int ksteps, int s_first) {
+        int ar = TL4 + n16 * row_pitch4 + kq;
+        asm volatile("" : "+v"(ar));
+        f32x4 cb[4][NB];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) cb[i][nb] = ldb2(i, nb);
+          for (int nb = 0; nb < NB; ++nb) cb[i][nb] = ldb2(s_first + i, nb);
+        f32x4 af[2][APB];
 #pragma unroll
-        for (int g = 0; g < KH; ++g) {
+        for (int q = 0; q < APB; ++q) af[0][q] = lds4[ar + q * 16 * row_pitch4];
+        for (int g = 0; g < ksteps; g += 4) {
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) cb[(g + 3) & 3][nb] = ldb2(g + 3, nb);
-          __builtin_amdgcn_sched_barrier(0);
-          gemm_step(TL, RH, 16 * g, cb[g & 3]);
+          for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) cb[(u + 3) & 3][nb] = ldb2(s_first + g + u + 3, nb);
+            // (same body as gemm_step, with this tile's row pitch)
+            fpc_static_for<NBLK>([&](auto B_) __attribute__((always_inline)) {
+              constexpr int blk = decltype(B_)::value;
+              if (blk + 1 < NBLK) {
+#pragma unroll
+                for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[ar + (g + u) * 4 + ((blk + 1) * APB + q) * 16 * row_pitch4];
+              } else {
+#pragma unroll
+                for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[ar + (g + u + 1) * 4 + q * 16 * row_pitch4];   // (next step; past the last one: read and dropped)
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (NB == 2) fpc_mfma_step<true, true>(acc2[blk][0], acc2[blk][1], af[blk & 1][0], af[blk & 1][0], cb[u][0], cb[u][NB - 1]);
+              else fpc_mfma_step<true, true>(acc2[2 * blk][0], acc2[2 * blk + 1][0], af[blk & 1][0], af[blk & 1][APB - 1], cb[u][0], cb[u][0]);
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          }
         }
-      }
+      };
+      (void)gemm_step;
+      gemm_over(RH / 4, KH, 0);
       if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
       if (proj) {
         const int npass = (a.k8_x + 15) >> 4;
         for (int pass = 0; pass < npass; ++pass) {
           FPC_LDS_BARRIER();   // h (or the previous pass's x) has been read by every wave
+          {
+            int xw = TL4 + (tid_t >> 5) * (RX / 4) + (tid_t & 31);
+            asm volatile("" : "+v"(xw));
 #pragma unroll
-          for (int i = 0; i < XIT; ++i) {
-            const int e = tid_t + i * NT;
-            *reinterpret_cast<f32x4*>(TL + (e >> 5) * RX + (e & 31) * 4) = xst[i];
+            for (int i = 0; i < XIT; ++i) lds4[xw + i * 8 * (RX / 4)] = xst[i];
           }
           FPC_LDS_BARRIER();
           if (pass + 1 < npass) load_x(pass + 1);
           const int steps = min(8, a.k8_x / 2 - pass * 8);   // 16-channel steps of this pass: 4 or 8
-          const int s0 = KH + pass * 8;
-          float4 cb[4][NB];
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) cb[i][nb] = ldb2(s0 + i, nb);
-          for (int g = 0; g < steps; g += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-              for (int nb = 0; nb < NB; ++nb) cb[(u + 3) & 3][nb] = ldb2(s0 + g + u + 3, nb);
-              __builtin_amdgcn_sched_barrier(0);
-              gemm_step(TL, RX, 16 * (g + u), cb[u & 3]);
-            }
-          }
+          gemm_over(RX / 4, steps, KH + pass * 8);
         }
       }
 
       // ------------------------------------------------ epilogue: output tile through LDS -> 16-byte stores
       if (wg == wg_stamp && half == 0) { FPC_STAMP(4) }
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // (asm MFMA results read by the VALU, as above)
       FPC_LDS_BARRIER();
+      {
+        int ew = C::OFF_H0 + (4 * kq) * RH + 16 * (wave * NB) + n16;
+        asm volatile("" : "+v"(ew));
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const float bias = a.b2[16 * (wave * NB + nb) + n16];
+        for (int nb = 0; nb < NB; ++nb) {
+          const float bias = a.b2[16 * (wave * NB + nb) + n16];
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
+          for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) TL[(16 * mb + 4 * kq + r) * RH + 16 * (wave * NB + nb) + n16] = acc2[mb][nb][r] + bias;
-      }
-      FPC_LDS_BARRIER();
-#pragma unroll
-      for (int i = 0; i < EIT; ++i) {
-        const int e = tid_t + i * NT;
-        const int m = e / C4, c4 = e - m * C4;
-        const int y = y0 + m / TW, x = x0 + m % TW;
-        if (y < a.H && x < a.W) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(TL + m * RH + c4 * 4);
-          if (!proj) v += xst[i];
-          v.x = v.x > 0.f ? v.x : 0.f;
-          v.y = v.y > 0.f ? v.y : 0.f;
-          v.z = v.z > 0.f ? v.z : 0.f;
-          v.w = v.w > 0.f ? v.w : 0.f;
-          *reinterpret_cast<f32x4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.cso + c4 * 4) = v;
+            for (int r = 0; r < 4; ++r) lds[ew + 16 * nb + (16 * mb + r) * RH] = acc2[mb][nb][r] + bias;
         }
       }
+      FPC_LDS_BARRIER();
+      store_out(!proj);
       if (wg == wg_stamp && half == 0) { FPC_STAMP(5) }
       FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
     }  // halves
+    pos_cur = pos_next;
+    base_cur = base_next;
   }  // persistent tile loop
 }
 
