@@ -77,6 +77,7 @@ static double run(const Problem& P, bool check, int reps, int grid_override = 0)
   CK(hipMemcpy(dw2, w2p.data(), w2p.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(db2, b2.data(), N * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dout, 0xff, nout_el * 4));
+  if (getenv("W36_PTRS")) printf("x %p..%p  w1 %p..%p  w2 %p..%p  b2 %p  out %p..%p\n", dx, dx + x.size(), dw1, dw1 + w1p.size(), dw2, dw2 + w2p.size(), db2, dout, dout + nout_el);
   WBlockArgs a{};
   a.x = dx; a.csx = P.Cin; a.nchunk = nchunk; a.H = P.H; a.W = P.W;
   a.w1 = (const float4*)dw1; a.b1 = dw1 + (size_t)ncg * gstride; a.w2 = (const float4*)dw2; a.b2 = db2;
@@ -188,6 +189,7 @@ static double run(const Problem& P, bool check, int reps, int grid_override = 0)
 int main(int argc, char** argv) {
   const bool check = argc < 2 || !strcmp(argv[1], "check");
   if (check) {
+    if (argc <= 2) {
     run<2, 4, 4>({2, 20, 36, 128, 128, 0, false, 1}, true, 0);
     run<2, 4, 4>({1, 33, 17, 256, 128, 256, false, 1}, true, 0);
     run<2, 4, 4>({1, 16, 48, 64, 128, 0, true, 2}, true, 0);
@@ -195,6 +197,20 @@ int main(int argc, char** argv) {
     run<1, 2, 8>({2, 24, 70, 64, 64, 0, false, 1}, true, 0);
     run<1, 2, 8>({1, 13, 40, 64, 64, 64, false, 1}, true, 0);
     run<1, 4, 4>({1, 30, 30, 64, 64, 0, false, 1}, true, 0);
+    }
+    if (argc > 2) {   // tiny maps (tiles larger than the frame), one case per process
+      const int k = atoi(argv[2]);
+      if (k == 0) run<1, 2, 8>({2, 16, 24, 64, 64, 64, false, 1}, true, 0);
+      if (k == 1) run<1, 4, 4>({1, 8, 12, 64, 64, 0, false, 1}, true, 0);
+      if (k == 2) run<2, 4, 4>({2, 8, 12, 128, 128, 0, false, 1}, true, 0);
+      if (k == 3) run<2, 4, 4>({1, 4, 6, 128, 128, 0, false, 1}, true, 0);
+      if (k == 4) run<2, 4, 4>({1, 4, 6, 256, 128, 256, false, 1}, true, 0);
+      if (k == 5) run<2, 4, 4>({1, 2, 3, 256, 128, 0, true, 2}, true, 0);
+      if (k == 6) run<2, 4, 4>({1, 16, 16, 128, 128, 0, false, 1}, true, 0);
+      if (k == 7) run<2, 4, 4>({1, 20, 16, 128, 128, 0, false, 1}, true, 0);
+      if (k == 8) run<2, 4, 4>({3, 16, 32, 128, 128, 0, false, 1}, true, 0);
+      return 0;
+    }
   } else {
     const int B = argc > 2 ? atoi(argv[2]) : 32;
     run<2, 4, 4>({B, 60, 80, 128, 128, 0, false, 1}, false, 10);       // layer2.1, layer_out.1

@@ -23,6 +23,7 @@
 #include "block_x3.h"
 #include "wblock_mfma.h"
 #include "wblock16_mfma.h"
+#include "wblock36_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "match.h"
@@ -154,11 +155,19 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
   X(W16_C64, 4, 8)       \
   X(W16_C128, 8, 8)      \
   X(W16_C128H, 8, 4)
+// W36KIND(name, NB, TYT, TXT): wblock36_kernel (generation 3: Winograd F(4x4,3x3), one wave per SIMD, 16 Winograd tiles
+// of 4x4 pixels arranged TYT x TXT per workgroup), N = 64 NB output channels.
+#define FPC_W36_KINDS(X) \
+  X(W36_C64_4x4, 1, 4, 4)  \
+  X(W36_C64_2x8, 1, 2, 8)  \
+  X(W36_C128_4x4, 2, 4, 4) \
+  X(W36_C128_2x8, 2, 2, 8)
 
 enum WKind {
 #define X(name, ...) WK_##name,
   FPC_WBLOCK_KINDS(X)
   FPC_W16_KINDS(X)
+  FPC_W36_KINDS(X)
 #undef X
       WK_COUNT
 };
@@ -166,10 +175,12 @@ enum WKind {
 struct WKindInfo {
   const char* name;
   const char* symbol;
-  int gen;               // 1: wblock_mfma_kernel, 2: wblock16_kernel
+  int gen;               // 1: wblock_mfma_kernel, 2: wblock16_kernel, 3: wblock36_kernel
   int KC, NBT, CMID, lds_bytes;
-  int NCG;               // generation 2: channel groups of 16
-  int TH;                // tile height in pixels (8; 4 for the latency instance)
+  int NCG;               // generations 2, 3: channel groups of 16
+  int TH;                // tile height in pixels (8; 4 for the latency instance; generation 3: 16 or 8)
+  int TW;                // tile width in pixels (16; generation 3: 16 or 32)
+  int threads;           // workgroup size (512; generation 3: 256)
   const void* fn;
   void (*launch)(const WBlockArgs&, dim3, hipStream_t);
 };
@@ -188,19 +199,55 @@ FPC_WBLOCK_KINDS(X)
   }
 FPC_W16_KINDS(X)
 #undef X
+#define X(name, NB, TYT, TXT)                                                                             \
+  static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
+    constexpr int lds = W36Cfg<NB, TYT, TXT>::LDS_BYTES;                                                  \
+    hipLaunchKernelGGL((wblock36_kernel<NB, TYT, TXT>), grid, dim3(256), lds, st, a);                     \
+  }
+FPC_W36_KINDS(X)
+#undef X
 
 static const WKindInfo g_wkinds[WK_COUNT] = {
 #define X(name, KC, NBT, CMID)                                                                            \
   {#name, "wblock_mfma_kernel<" #KC ", " #NBT ", " #CMID ">", 1, KC, NBT, CMID,                           \
-   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, 0, 8, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
+   WBlockCfg<KC, NBT, CMID>::LDS_BYTES, 0, 8, 16, 512, (const void*)wblock_mfma_kernel<KC, NBT, CMID>, launchw_##name},
     FPC_WBLOCK_KINDS(X)
 #undef X
 #define X(name, NCG, TH)                                                                                  \
   {#name, "wblock16_kernel<" #NCG ", " #TH ">", 2, 16, NCG / 2, NCG * 16,                                  \
-   W16Cfg<NCG, TH>::LDS_BYTES, NCG, TH, (const void*)wblock16_kernel<NCG, TH>, launchw_##name},
+   W16Cfg<NCG, TH>::LDS_BYTES, NCG, TH, 16, 512, (const void*)wblock16_kernel<NCG, TH>, launchw_##name},
     FPC_W16_KINDS(X)
 #undef X
+#define X(name, NB, TYT, TXT)                                                                             \
+  {#name, "wblock36_kernel<" #NB ", " #TYT ", " #TXT ">", 3, 16, 2 * NB, 64 * NB,                          \
+   W36Cfg<NB, TYT, TXT>::LDS_BYTES, 4 * NB, 4 * TYT, 4 * TXT, 256, (const void*)wblock36_kernel<NB, TYT, TXT>, launchw_##name},
+    FPC_W36_KINDS(X)
+#undef X
 };
+
+// blob floats of a generation-2 / generation-3 kernel's conv1 fragments: [channel group][chunk of 16][position][64 lanes]
+// float4 + zero positions behind every group (the fragment rings read ahead)
+static size_t w1_floats(const WKindInfo& k, int nchunk) {
+  if (k.gen == 3) return (size_t)k.NCG * ((size_t)nchunk * 36 + (k.NCG == 8 ? W36Cfg<2, 4, 4>::WPAD : W36Cfg<1, 4, 4>::WPAD)) * 256;
+  return (size_t)k.NCG * ((size_t)nchunk * 16 + W16Cfg<8>::WPAD) * 256;
+}
+// MFMA FLOPs one frame's tiles issue: positions x Winograd tiles x channels x K for the 3x3, pixels x channels x K for the 1x1
+static double wkind_mfma_flops(const WKindInfo& k, int tiles, int nchunk, int k8_1x1) {
+  const double px = (double)k.TH * k.TW, n = k.NBT * 32.0;
+  if (k.gen == 3) return 2.0 * tiles * n * (36.0 * (px / 16) * nchunk * k.KC + px * k8_1x1 * 8.0);
+  return 2.0 * tiles * n * (16.0 * (px / 4) * nchunk * k.KC + px * k8_1x1 * 8.0);
+}
+// Generation 3 addresses its tensors with signed 32-bit byte offsets below W36_MARKER (wblock36_mfma.h): a layer whose
+// input or output tensor is larger falls back to generation 2.
+static bool w36_fits(int B, int H, int W, int cs_in, int cs_out) {
+  return (unsigned long long)B * H * W * (unsigned long long)std::max(cs_in, cs_out) * sizeof(float) < (unsigned long long)W36_MARKER;
+}
+// Generation 3: the arrangement of the 16 Winograd tiles (4 x 4 or 2 x 8) that covers the map with fewer tiles
+static WKind w36_kind(int cout, int H, int W) {
+  const int t44 = ((H + 15) / 16) * ((W + 15) / 16), t28 = ((H + 7) / 8) * ((W + 31) / 32);
+  if (cout == 64) return t28 < t44 ? WK_W36_C64_2x8 : WK_W36_C64_4x4;
+  return t28 < t44 ? WK_W36_C128_2x8 : WK_W36_C128_4x4;
+}
 
 // bf16 / split-operand instances.  FKIND(name, KERNEL, CFG, PLANES, TH,TW, S,EXT, KC, WM,WN, MB,NB, CMIDP)
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
@@ -357,7 +404,7 @@ struct fpc_ctx {
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool latency_tiles = true;         // calls of a few frames run the 128-channel Winograd blocks on 4 x 16 tiles (FPC_LATENCY_TILES=0: 8 x 16)
-  int winograd_gen = 2;              // 64- and 128-channel Winograd layers on wblock16_kernel (2) or wblock_mfma_kernel (1; FPC_WINOGRAD_GEN)
+  int winograd_gen = 3;              // 64- and 128-channel Winograd layers on wblock36_kernel (3: F(4x4,3x3)), wblock16_kernel (2) or wblock_mfma_kernel (1; FPC_WINOGRAD_GEN)
   bool fuse_blocks = true;           // one launch per ResNetBlock (FPC_FUSE=0: conv1 / conv2 launches)
   bool weights_loaded = false;
   bool plan_error = false;           // a layer asked for a kernel instance that does not exist (fpc_create -> FPC_E_INVALID)
@@ -612,7 +659,7 @@ static void retile_last(fpc_ctx* c, Kind small) {
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
 }
 
-static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_off) {
+static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_off, bool small_only = false) {
   const WKindInfo& k = g_wkinds[wk];
   Op op;
   op.type = OP_WBLOCK;
@@ -635,28 +682,48 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   if (a.k8_x % 4) { fprintf(stderr, "fpc: winograd block %s: projection over %d channels is not a multiple of 32\n", s.prefix.c_str(), s.cin_pad); abort(); }
   a.out = s.out;
   a.cso = s.cso;
-  a.tiles_x = (s.W + 15) / 16;
+  a.tiles_x = (s.W + k.TW - 1) / k.TW;
   a.tiles_y = (s.H + k.TH - 1) / k.TH;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
-  if (k.gen == 2) {   // [channel group][chunk of 16][position][64 lanes] float4 + zero pad per group (wblock16_mfma.h)
+  if (k.gen >= 2) {   // [channel group][chunk of 16][position][64 lanes] float4 + zero pad per group (wblock16_mfma.h, wblock36_mfma.h)
     if (a.nchunk < 4 || (a.nchunk & 1)) { c->plan_error = true; return; }
-    *blob_off += (size_t)k.NCG * ((size_t)a.nchunk * 16 + W16Cfg<8>::WPAD) * 256;
+    *blob_off += w1_floats(k, a.nchunk);
   } else {
     *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
   }
   cw.b_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   cw.w_off[1] = *blob_off;
-  if (k.gen == 2) *blob_off += (size_t)k.NCG * ((size_t)(a.k8_h + a.k8_x) / 2 + W16Cfg<8>::WPAD) * 256;
+  if (k.gen >= 2) *blob_off += (size_t)k.NCG * ((size_t)(a.k8_h + a.k8_x) / 2 + W16Cfg<8>::WPAD) * 256;
   else *blob_off += ((size_t)(a.k8_h + a.k8_x) + 2) * k.NBT * 64 * 4;
   cw.b2_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   op.flops_per_frame = 2.0 * s.H * s.W * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
-  // 16 GEMMs of 32 rows per 128-pixel tile instead of 9 taps x 128 rows; then the 1x1 on 128 rows
-  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) *
-                            (16.0 * (4 * k.TH) * a.nchunk * k.KC + (16.0 * k.TH) * (a.k8_h + a.k8_x) * 8.0);
+  // 16 (36) GEMMs over the tile's Winograd tiles instead of 9 taps over its pixels; then the 1x1 on its pixels
+  op.mfma_flops_per_frame = wkind_mfma_flops(k, a.tiles_x * a.tiles_y, a.nchunk, a.k8_h + a.k8_x);
   op.bytes_per_frame = 4.0 * ((double)s.cin * s.H * s.W + (double)s.cout * s.H * s.W);
+  if (k.gen == 3 && c->latency_tiles) {
+    // Generation 3's tile is 256 pixels: a frame has 20 of them at 60 x 80, and the latency of a single frame's layer is
+    // one tile's time.  Calls of a few frames keep generation 2 (its own fragments: 16 positions instead of 36), on its
+    // 4 x 16 latency tiles where that instance exists.
+    op.when = 2;
+    c->ops.push_back(op);
+    c->convw.push_back(cw);
+    add_wblock(c, s, s.cout == 64 ? WK_W16_C64 : WK_W16_C128, blob_off, true);
+    return;
+  }
+  if (small_only && wk == WK_W16_C128) {   // (the caller's large-call op exists already: only the 4 x 16 instance)
+    const WKindInfo& kh = g_wkinds[WK_W16_C128H];
+    op.when = 1;
+    op.wkind = WK_W16_C128H;
+    op.wargs.tiles_y = (s.H + kh.TH - 1) / kh.TH;
+    op.mfma_flops_per_frame = wkind_mfma_flops(kh, op.wargs.tiles_x * op.wargs.tiles_y, a.nchunk, a.k8_h + a.k8_x);
+    c->ops.push_back(op);
+    c->convw.push_back(cw);
+    return;
+  }
+  if (small_only) op.when = 1;
   c->ops.push_back(op);
   c->convw.push_back(cw);
   if (wk == WK_W16_C128 && c->latency_tiles) {
@@ -667,8 +734,7 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
     oh.when = 1;
     oh.wkind = WK_W16_C128H;
     oh.wargs.tiles_y = (s.H + kh.TH - 1) / kh.TH;
-    oh.mfma_flops_per_frame = 2.0 * oh.wargs.tiles_x * oh.wargs.tiles_y * (kh.NBT * 32.0) *
-                              (16.0 * (4 * kh.TH) * a.nchunk * kh.KC + (16.0 * kh.TH) * (a.k8_h + a.k8_x) * 8.0);
+    oh.mfma_flops_per_frame = wkind_mfma_flops(kh, oh.wargs.tiles_x * oh.wargs.tiles_y, a.nchunk, a.k8_h + a.k8_x);
     c->ops.push_back(oh);
     c->convw.push_back(cw);
   }
@@ -703,22 +769,22 @@ static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, 
   a.conv_only = 1;
   a.out = out + n0;
   a.cso = cso;
-  a.tiles_x = (W + 15) / 16;
+  a.tiles_x = (W + k.TW - 1) / k.TW;
   a.tiles_y = (H + k.TH - 1) / k.TH;
   fpc_ctx::ConvW cw;
   cw.w_off[0] = *blob_off;
-  if (k.gen == 2) {
+  if (k.gen >= 2) {
     if (a.nchunk < 4 || (a.nchunk & 1)) { c->plan_error = true; return; }
-    *blob_off += (size_t)k.NCG * ((size_t)a.nchunk * 16 + W16Cfg<8>::WPAD) * 256;
+    *blob_off += w1_floats(k, a.nchunk);
   } else {
     *blob_off += ((size_t)a.nchunk * 16 * K8 + 16 * K8 + 2) * k.NBT * 64 * 4;
   }
   cw.b_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
   op.flops_per_frame = 2.0 * H * W * (double)k.CMID * cin * 9;
-  op.mfma_flops_per_frame = 2.0 * a.tiles_x * a.tiles_y * (k.NBT * 32.0) * (16.0 * 32 * a.nchunk * k.KC);
+  op.mfma_flops_per_frame = wkind_mfma_flops(k, a.tiles_x * a.tiles_y, a.nchunk, 0);
   op.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)std::min(k.CMID, cout - n0) * H * W);
-  if (k.gen == 2 && n0 == k.CMID && cout == 2 * k.CMID && !c->ops.empty() && c->ops.back().wconv && c->ops.back().prefix == prefix &&
+  if (k.gen >= 2 && n0 == k.CMID && cout == 2 * k.CMID && !c->ops.empty() && c->ops.back().wconv && c->ops.back().prefix == prefix &&
       c->ops.back().n0 == 0 && c->ops.back().wkind == wk) {
     // second half of a 256-wide layer: ONE launch computes both halves (gridDim.y = 2); this op only carries the
     // half's checkpoint -> fragment packing
@@ -1043,7 +1109,8 @@ static int build_vgg_plan(fpc_ctx* c) {
       return;
     }
     if (ksize == 3 && relu && c->winograd) {  // Winograd F(2x2,3x3), conv-only; 256 outputs = two 128-channel launches
-      const WKind wk = c->winograd_gen == 2 ? (cout == 64 ? WK_W16_C64 : WK_W16_C128) : (cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128);
+      // (the C++ network's layers stay on generation 2: no small-call variants exist on this path)
+      const WKind wk = c->winograd_gen >= 2 ? (cout == 64 ? WK_W16_C64 : WK_W16_C128) : (cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128);
       for (int n0 = 0; n0 < cout; n0 += g_wkinds[wk].CMID)
         add_wconv(c, prefix, false, wk, x, cin, cin, Hx, Wx, out, cso, cout, n0, desc, &bo);
       return;
@@ -1256,8 +1323,9 @@ static int build_plan(fpc_ctx* c) {
       const BlockSpec bs{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc};
       WKind wk = WK_COUNT;
       if (c->winograd && stride == 1) {
-        if (cinp % 32 == 0 && cout == 64) wk = c->winograd_gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
-        else if (cinp % 32 == 0 && cout == 128) wk = c->winograd_gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
+        const int gen = c->winograd_gen == 3 && !w36_fits(c->B, Hx, Wx, csx, csy) ? 2 : c->winograd_gen;
+        if (cinp % 32 == 0 && cout == 64) wk = gen == 3 ? w36_kind(64, Hx, Wx) : gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
+        else if (cinp % 32 == 0 && cout == 128) wk = gen == 3 ? w36_kind(128, Hx, Wx) : gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
         else if (c->winograd_det && cinp % 32 == 0 && coutp == 72) wk = WK_W816_K32_C72;
         else if (c->winograd_det && cinp == 72 && coutp == 72) wk = WK_W816_K24_C72;
       }
@@ -1349,7 +1417,7 @@ static int build_plan(fpc_ctx* c) {
       // launches of 128 output channels each, then conv2 + identity + ReLU as a 1x1 launch (h makes one round trip)
       const std::string p = "descriptor.layer_in.1";
       for (int n0 = 0; n0 < 256; n0 += 128)
-        add_wconv(c, p, true, c->winograd_gen == 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+        add_wconv(c, p, true, c->winograd_gen == 3 && w36_fits(c->B, H16, W16, 256, 256) ? w36_kind(128, H16, W16) : c->winograd_gen >= 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
       ConvSpec t{};
       t.name = p + ".conv2+bn2+identity+relu";
       t.kind = K_T620_1x1_K64_N128; t.ksize = 1; t.stride = 1;
@@ -1359,7 +1427,7 @@ static int build_plan(fpc_ctx* c) {
       t.desc_branch = true;
       add_conv(c, t, &bo);
       retile_last(c, K_T320_1x1_K64_N128);
-      if (c->winograd_gen == 2 && c->latency_tiles) {
+      if (g_wkinds[c->ops[c->ops.size() - 3].wkind].gen == 2 && c->latency_tiles) {
         // calls of a few frames: the same two-half launch on 4 x 16 tiles (24 tiles x 2 halves per frame instead of
         // 12 x 2), then the same 1x1 -- 0.10 ms for one frame against 0.16 ms for the fused direct block on 20 tiles
         const size_t ia = c->ops.size() - 3;   // [two-half launch, its shadow, 1x1]
@@ -1372,7 +1440,8 @@ static int build_plan(fpc_ctx* c) {
         const fpc_ctx::ConvW cwa = c->convw[ia];
         c->ops.insert(c->ops.begin() + ia + 1, oh);
         c->convw.insert(c->convw.begin() + ia + 1, cwa);
-      } else {
+      } else if (c->latency_tiles || c->winograd_gen == 1) {
+      // (generation 3 comes here too: its fragments have 36 positions, so a 4 x 16 instance of generation 2 could not share them)
       for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
       // a call of a few frames has 12 tiles per frame here: three dependent launches cost more latency than they save
       // work, so small calls take the fused direct block instead (its weights sit in the blob next to the others)
@@ -1498,6 +1567,45 @@ static bool check_blob_header(const fpc_ctx* c, const uint32_t* h, std::string* 
       return false;
     }
   return true;
+}
+
+// ---- Winograd-domain filters U = G g G^T (x the folded BN scale), in double ------------------------------------
+// F(2x2,3x3): 16 positions (generations 1, 2); F(4x4,3x3) on the points 0, +-1, +-2, inf: 36 positions (generation 3).
+// U[(n * ci + cc) * P + i * R + j] for output channels n0 .. n0 + nn - 1 of w1 [co][ci][3][3].
+static std::vector<double> winograd_filters(const float* w1, int n0, int nn, int ci, const std::vector<double>& scale, int P) {
+  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  static const double G4[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const int R = P == 36 ? 6 : 4;
+  const double(*G)[3] = P == 36 ? G4 : G2;
+  std::vector<double> U((size_t)nn * ci * P);
+  for (int n = 0; n < nn; ++n)
+    for (int cc = 0; cc < ci; ++cc) {
+      const float* g = w1 + ((size_t)(n0 + n) * ci + cc) * 9;
+      double t[6][3];
+      for (int i = 0; i < R; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+      for (int i = 0; i < R; ++i)
+        for (int j = 0; j < R; ++j)
+          U[((size_t)n * ci + cc) * P + i * R + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * scale[n0 + n];
+    }
+  return U;
+}
+
+// ---- generation-3 Winograd fragments (wblock36_mfma.h): as generation 2's with 36 positions per chunk --------------
+static void pack_w36_winograd(const std::vector<double>& U, int nn, int ci, const WKindInfo& k, int nchunk, float* dst) {
+  const size_t gstride = w1_floats(k, nchunk) / k.NCG;
+  for (int cg = 0; cg < k.NCG; ++cg)
+    for (int ch = 0; ch < nchunk; ++ch)
+      for (int xi = 0; xi < 36; ++xi)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = 16 * cg + (lane & 15), kq = lane >> 4;
+          float* d4 = dst + cg * gstride + (((size_t)ch * 36 + xi) * 64 + lane) * 4;
+          for (int j = 0; j < 4; ++j) {
+            const int cc = 16 * ch + 4 * kq + j;
+            d4[j] = (n < nn && cc < ci) ? (float)U[((size_t)n * ci + cc) * 36 + xi] : 0.f;
+          }
+        }
 }
 
 // ---- generation-2 Winograd fragments (wblock16_mfma.h) ---------------------------------------------
@@ -1665,21 +1773,11 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
         } else if (!fold_bn(m, p + ".bn1", co, &f1, missing)) {
           return FPC_E_MISSING_KEY;
         }
-        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         float* dst = blob.data() + cw.w_off[0];
         const int nn = std::min(k.CMID, co - op.n0);
-        std::vector<double> U((size_t)nn * ci * 16);
-        for (int n = 0; n < nn; ++n)
-          for (int cc = 0; cc < ci; ++cc) {
-            const float* g = w1 + ((size_t)(op.n0 + n) * ci + cc) * 9;
-            double t[4][3];
-            for (int i = 0; i < 4; ++i)
-              for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
-            for (int i = 0; i < 4; ++i)
-              for (int j = 0; j < 4; ++j)
-                U[((size_t)n * ci + cc) * 16 + i * 4 + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * f1.s[op.n0 + n];
-          }
-        if (k.gen == 2) pack_w16_winograd(U, nn, ci, k.NCG, a.nchunk, dst);
+        const std::vector<double> U = winograd_filters(w1, op.n0, nn, ci, f1.s, k.gen == 3 ? 36 : 16);
+        if (k.gen == 3) pack_w36_winograd(U, nn, ci, k, a.nchunk, dst);
+        else if (k.gen == 2) pack_w16_winograd(U, nn, ci, k.NCG, a.nchunk, dst);
         else
         for (int ch = 0; ch < a.nchunk; ++ch)
           for (int xi = 0; xi < 16; ++xi)
@@ -1701,21 +1799,11 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
       Fold f1, f2, fp;
       if (!w1 || !w2 || !fold_bn(m, p + ".bn1", co, &f1, missing) || !fold_bn(m, p + ".bn2", co, &f2, missing))
         return FPC_E_MISSING_KEY;
-      // U = G (g * s) G^T in double, rounded once; [chunk][xi][k8][nb][lane] float4
-      static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-      std::vector<double> U((size_t)co * ci * 16);
-      for (int n = 0; n < co; ++n)
-        for (int cc = 0; cc < ci; ++cc) {
-          const float* g = w1 + ((size_t)n * ci + cc) * 9;
-          double t[4][3];
-          for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
-          for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j)
-              U[((size_t)n * ci + cc) * 16 + i * 4 + j] = (t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]) * f1.s[n];
-        }
+      // U = G (g * s) G^T in double, rounded once; generation 1: [chunk][xi][k8][nb][lane] float4
+      const std::vector<double> U = winograd_filters(w1, 0, co, ci, f1.s, k.gen == 3 ? 36 : 16);
       float* dst = blob.data() + cw.w_off[0];
-      if (k.gen == 2) pack_w16_winograd(U, co, ci, k.NCG, a.nchunk, dst);
+      if (k.gen == 3) pack_w36_winograd(U, co, ci, k, a.nchunk, dst);
+      else if (k.gen == 2) pack_w16_winograd(U, co, ci, k.NCG, a.nchunk, dst);
       else
       for (int ch = 0; ch < a.nchunk; ++ch)
         for (int xi = 0; xi < 16; ++xi)
@@ -1740,7 +1828,7 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
         srcs.push_back({ci, a.k8_x * 8, 1, [&](int n, int c_, int) { return (double)wp[(size_t)n * ci + c_]; }, &fp.s});
         for (int n = 0; n < co; ++n) bias[n] += fp.t[n];
       }
-      if (k.gen == 2) {
+      if (k.gen >= 2) {
         pack_w16_1x1(srcs, co, k.NCG, blob.data() + cw.w_off[1]);
       } else {
         std::vector<float> frag = pack_conv(srcs, co, nbt, 8);
@@ -2082,7 +2170,16 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         }
         // persistent (one workgroup per CU walking the tiles) when a workgroup gets enough tiles to
         // amortise; otherwise one workgroup per tile
-        const int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
+        int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
+        if (g_wkinds[op.wkind].gen == 3) {
+          // One workgroup per CU (137 KB of LDS), so a launch lasts ceil(tiles / CUs) tile times whatever the grid: take
+          // the SMALLEST grid that still finishes in that many rounds (a multiple of 8: the tile walk is per XCD) and
+          // leave the other CUs to the launches of the other sub-batch's stream -- 640 tiles: 216 workgroups x 3 rounds
+          // instead of 256 of which 128 idle through the third; 320 tiles: 160 x 2.
+          const int cus8 = std::max(1, c->num_cus / 8), per_xcd = (a.total + 7) / 8;
+          const int rounds = (per_xcd + cus8 - 1) / cus8;
+          grid = 8 * std::min(cus8, (per_xcd + rounds - 1) / rounds);
+        }
         g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid), op.grid_y), sb.st);
         break;
       }
@@ -2450,8 +2547,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->split_heads = (pf & FPC_PLAN_SPLIT_HEADS) != 0;
     if (pf & FPC_PLAN_NO_PERSISTENT_GRID) c->persist_min_tiles = 0;
     c->layer1_t816 = (pf & FPC_PLAN_LAYER1_TILE_8x16) != 0;
-    c->winograd_gen = (pf & FPC_PLAN_WINOGRAD_GEN1) ? 1 : 2;
-    if (const char* e = getenv("FPC_WINOGRAD_GEN")) c->winograd_gen = atoi(e) == 1 ? 1 : 2;
+    c->winograd_gen = (pf & FPC_PLAN_WINOGRAD_GEN1) ? 1 : (pf & FPC_PLAN_WINOGRAD_GEN2) ? 2 : 3;
+    if (const char* e = getenv("FPC_WINOGRAD_GEN")) c->winograd_gen = std::min(3, std::max(1, atoi(e)));
     c->latency_tiles = !(pf & FPC_PLAN_NO_LATENCY_TILES);
     if (const char* e = getenv("FPC_LATENCY_TILES")) c->latency_tiles = atoi(e) != 0;
     c->fuse_softmax = !(pf & FPC_PLAN_NO_FUSED_SOFTMAX);

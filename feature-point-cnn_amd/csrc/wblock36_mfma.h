@@ -116,6 +116,12 @@ __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4&
 #undef FPC_MFMA8_IN
 }
 
+// Byte offsets of this kernel's buffer accesses are SIGNED 32-bit sums `per-lane part + uniform part`, added with
+// saturation; a lane that must not touch memory carries this marker as its per-lane part: marker + anything >= 0 stays
+// >= marker, which is the (or above the) range of every descriptor here.  Tensors must be smaller than this (the host
+// checks: fpc_api.hip, w36_fits).
+#define W36_MARKER 0x7fffff00
+
 template <int NB, int TYT, int TXT>
 __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   using C = W36Cfg<NB, TYT, TXT>;
@@ -124,7 +130,6 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   f32x4* const lds4 = reinterpret_cast<f32x4*>(lds);
   constexpr int TL4 = C::OFF_H0 / 4;        // h, x staging, output tile of one half (float4 units)
-  float* const TL = lds + C::OFF_H0;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       const int hx = pix - hy * HW;
       const bool ok = ((unsigned)(iy0 + hy) < (unsigned)hlim) & ((unsigned)(ix0 + hx) < (unsigned)a.W) & (hy < HH) & (c4 < 4);
       const int off = (((hy - 1) * a.W + (hx - 1)) * a.csx + c4 * 4) * 4;
-      okoff[i] = ok ? off : 0x7fffff00;
+      okoff[i] = ok ? off : W36_MARKER;
     }
   };
   auto load_halo = [&](int base, int hoff) {             // base: halo_base of the tile + 64 bytes per chunk; hoff: the halo buffer (floats)
@@ -245,9 +250,6 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   struct BF { f32x4 v[2]; };
   auto ldb = [&](int s) {      // ring step s (counted from the tile's first chunk)
     BF r;
-#ifdef W36_EXPERIMENT_SAME_FRAGMENTS
-    s &= 7;     // (harness only: every step re-reads the same 16 KB per wave -- how much of a step is L2 -> CU traffic?)
-#endif
     if (NB == 2) {
       r.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024, 0));
       r.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024 + gs_s, 0));
@@ -274,7 +276,10 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   // the tail's per-thread constants: output float4 e = tid + 256 i of a half lies at pixel m0 + PPI i, channel quad c4
   constexpr int C4 = N / 4, EIT = HPX * C4 / NT, PPI = NT / C4;       // float4 per pixel; float4 per thread (16 / 8); pixels per i (8 / 16)
   constexpr int CPR = TW / PPI;                                      // column steps per pixel row (1, 2 or 4)
-  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + blockIdx.y * N, 0, 0x7ffffff0, 0x00020000);
+  // (range = the marker below: `marker + uniform offset`, saturated, must be out of range for EVERY uniform offset >= 0.
+  // With a range above the marker, the masked columns of the first tile of the first frame -- uniform offset 0 -- were
+  // in range and wrote 2 GB behind the tensor.)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + blockIdx.y * N, 0, W36_MARKER, 0x00020000);
 
   const int wg_stamp = wg_first + 2 * wg_step < wg_end ? wg_first + 2 * wg_step : wg_first;
   for (int wg = wg_first; wg < wg_end; wg += wg_step) {
@@ -317,11 +322,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
 #endif
       fpc_static_for<STEPS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
-#ifdef W36_TQ0      // (harness: stamps at steps W36_TQ0, W36_TQ0 + 1, ... instead of every fourth)
-        if constexpr (s >= W36_TQ0 && s < W36_TQ0 + 9) { FPC_TQ(s - W36_TQ0) }
-#else
         if constexpr (s % (STEPS / 9) == 0) { FPC_TQ(s / (STEPS / 9)) }
-#endif
         // ---- the step's gap: everything that is not an MFMA, in front of the eight MFMAs
         bq[(s + RING - 1) % RING] = ldb(c * STEPS + s + RING - 1);
         if (s + 1 < STEPS) {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
     const int xpart = (m0 * a.csx + c4t * 4) * 4, opart = (m0 * a.cso + c4t * 4) * 4;
     int ocol[CPR];                              // opart + column step k, or a huge positive number where that column is outside the frame
 #pragma unroll
-    for (int k = 0; k < CPR; ++k) ocol[k] = (tx * TW + m0 + k * PPI < a.W) ? opart + k * PPI * a.cso * 4 : 0x7fffff00;
+    for (int k = 0; k < CPR; ++k) ocol[k] = (tx * TW + m0 + k * PPI < a.W) ? opart + k * PPI * a.cso * 4 : W36_MARKER;
 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -525,25 +526,6 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       // one 16-channel step of the GEMM: blocks of eight MFMAs (one pixel block x 2 channel blocks, or two pixel blocks x 1),
       // the next block's A fragment(s) read in the gap in front of this block's MFMAs
       constexpr int NBLK = NB == 2 ? 8 : 4, APB = NB == 2 ? 1 : 2;      // blocks per step, A fragments per block
-      auto gemm_step = [&](int arow4, const f32x4* bv, f32x4 (&af)[2][APB], bool prefetch_next_step, int arow4_next) {
-        // arow4: float4 index of (pixel n16 of block 0, channels 16 g + 4 kq) ; pixel block mb lies 16 rows further
-        fpc_static_for<NBLK>([&](auto B_) __attribute__((always_inline)) {
-          constexpr int blk = decltype(B_)::value;
-          if (blk + 1 < NBLK) {
-#pragma unroll
-            for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[arow4 + ((blk + 1) * APB + q) * 16 * (RX / 4)];
-          } else if (prefetch_next_step) {
-#pragma unroll
-            for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[arow4_next + q * 16 * (RX / 4)];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (NB == 2) fpc_mfma_step<true, true>(acc2[blk][0], acc2[blk][1], af[blk & 1][0], af[blk & 1][0], bv[0], bv[1]);
-          else fpc_mfma_step<true, true>(acc2[2 * blk][0], acc2[2 * blk + 1][0], af[blk & 1][0], af[blk & 1][APB - 1], bv[0], bv[0]);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      };
-      static_assert(RH == RX || NB == 1, "the h tile and the x tile share the row pitch (N = 128)");
-      // (rows of RH floats for h, RX for x: gemm_step is written for RX; for N = 64 the h rows are 72 floats and h uses its own pitch below)
       auto gemm_over = [&](int row_pitch4, int ksteps, int s_first) {
         int ar = TL4 + n16 * row_pitch4 + kq;
         asm volatile("" : "+v"(ar));
@@ -578,7 +560,6 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           }
         }
       };
-      (void)gemm_step;
       gemm_over(RH / 4, KH, 0);
       if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
       if (proj) {

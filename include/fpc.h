@@ -100,7 +100,8 @@ enum {
   FPC_PLAN_WINOGRAD_GEN1 = 1 << 10,        /* round-1 Winograd kernel for the 64- / 128-channel layers  (FPC_WINOGRAD_GEN=1) */
   FPC_PLAN_NO_LATENCY_TILES = 1 << 11,     /* calls of a few frames keep the 8x16 tiles of the batch plan (FPC_LATENCY_TILES=0) */
   FPC_PLAN_NMS_ONE_WORKGROUP = 1 << 12,    /* survivors of a frame sorted by one workgroup, not in slices (FPC_NMS_CHUNKED=0)   */
-  FPC_PLAN_NO_FUSED_SOFTMAX = 1 << 13      /* FPC_BF16: exp-softmax as its own launch in fpc_detect too  (FPC_FUSE_SOFTMAX=0)   */
+  FPC_PLAN_NO_FUSED_SOFTMAX = 1 << 13,     /* FPC_BF16: exp-softmax as its own launch in fpc_detect too  (FPC_FUSE_SOFTMAX=0)   */
+  FPC_PLAN_WINOGRAD_GEN2 = 1 << 14         /* round-2 Winograd kernel, F(2x2,3x3), instead of F(4x4,3x3) (FPC_WINOGRAD_GEN=2)   */
 };
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']

@@ -84,7 +84,11 @@ def test_f1_per_layer_taps_on_the_device(torch_gpu, golden_dir, dtype):
     sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
     frame = synth.make_batch(int(g["seed_frame"]), 1, h, w)
     from fpc_amd.engine import Engine
-    for kw in (dict(), dict(plan_flags=["no_winograd"]), dict(plan_flags=["no_fused_blocks"])):
+    # default plan (a one-frame call runs the latency variants: generation-2 Winograd on fine tiles); the batch plan's
+    # kernels on the same frame (no_latency_tiles: the F(4x4,3x3) kernel, wblock36_mfma.h, on every 64- / 128-channel layer);
+    # generation 2 forced; direct convolutions; unfused
+    for kw in (dict(), dict(plan_flags=["no_latency_tiles"]), dict(plan_flags=["no_latency_tiles", "winograd_gen2"]),
+               dict(plan_flags=["no_winograd"]), dict(plan_flags=["no_fused_blocks"])):
         if kw and dtype != "f32":
             continue
         e = engine(h, w, dtype=dtype, **kw)
@@ -98,17 +102,20 @@ def test_f1_per_layer_taps_on_the_device(torch_gpu, golden_dir, dtype):
         e.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32_split", "f32_split_f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32_batch_plan", "f32_split", "f32_split_f16"])
 @pytest.mark.parametrize("tag", ["qvga", "vga", "magicpoint_qvga"])
 def test_f5_end_to_end(torch_gpu, golden_dir, tag, dtype):
     """The reference's own outputs (tests/golden/make_golden.py) at the north_star bar -- dense maps within
-    1e-4, keypoint set identical -- for the fp32 MFMA path and for the split-operand path (block_x3.h)."""
+    1e-4, keypoint set identical -- for the fp32 MFMA path and for the split-operand path (block_x3.h).
+    "f32_batch_plan": the kernels a 32-frame batch runs (Winograd F(4x4,3x3) blocks), on the fixture's one frame."""
+    plan = dict(plan_flags=["no_latency_tiles"]) if dtype == "f32_batch_plan" else {}
+    dtype = "f32" if dtype == "f32_batch_plan" else dtype
     g = np.load(os.path.join(golden_dir, "f5_e2e_%s.npz" % tag))
     h, w = int(g["h"]), int(g["w"])
     de = bool(int(g["descriptor_enabled"]))
     sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
     frame = synth.make_batch(int(g["seed_frame"]), 1, h, w)
-    e = engine(h, w, descriptor_enabled=de, dtype=dtype)
+    e = engine(h, w, descriptor_enabled=de, dtype=dtype, **plan)
     e.load_state_dict(sd)
     prob, desc, logits = e.forward(frame)
     prob, desc, logits = prob.cpu().numpy(), desc.cpu().numpy(), logits.cpu().numpy()
@@ -273,9 +280,10 @@ def test_full_size_batch_properties(torch_gpu):
     oracle = oracle_mod()
     for i in (0, 13, 31):
         _check_frame_against_oracle_postproc(oracle, prob[i].cpu().numpy(), desc[i].cpu().numpy(), res[i], h, w)
-    o_prob, o_desc, o_logits = oracle.forward(frames[7:8], sd, SPEC)
-    assert np.max(np.abs(prob[7].cpu().numpy() - o_prob[0])) < ATOL
-    assert np.max(np.abs(desc[7].cpu().numpy() - o_desc[0])) < ATOL
+    for i in (7, 29):          # one frame of each sub-batch against the oracle's own forward
+        o_prob, o_desc, o_logits = oracle.forward(frames[i:i + 1], sd, SPEC)
+        assert np.max(np.abs(prob[i].cpu().numpy() - o_prob[0])) < ATOL
+        assert np.max(np.abs(desc[i].cpu().numpy() - o_desc[0])) < ATOL
     for xy, conf, d, ncand in res:
         assert len(conf) > 100 and ncand >= len(conf)
         assert np.all(np.diff(conf) <= 0)
@@ -484,6 +492,11 @@ def test_packed_weight_blob_round_trip(torch_gpu):
     {"FPC_XCD_ORDER": "0", "FPC_MIN_SUB": "4"},              # plain tile order in the Winograd kernel; sub-batches of 4
     {"FPC_PERSIST_MIN": "0"},                                # Winograd kernel with one workgroup per tile
     {"FPC_WINOGRAD_IN1": "0"},                               # layer_in.1 as one fused direct block (no conv-only Winograd)
+    {"FPC_LATENCY_TILES": "0"},                              # the batch plan's kernels (Winograd F(4x4,3x3)) on a 13-frame call
+    {"FPC_LATENCY_TILES": "0", "FPC_XCD_ORDER": "0"},        # ... with the plain tile order
+    {"FPC_LATENCY_TILES": "0", "FPC_PERSIST_MIN": "0"},      # ... and with the non-persistent grid size
+    {"FPC_LATENCY_TILES": "0", "FPC_WINOGRAD_GEN": "2"},     # round 2's F(2x2,3x3) kernel
+    {"FPC_LATENCY_TILES": "0", "FPC_WINOGRAD_GEN": "1"},     # round 1's
 ])
 def test_alternative_plans_agree(torch_gpu, golden_dir, env):
     """Every launch plan the library can be switched to (environment knobs read at fpc_create) must
@@ -1010,16 +1023,18 @@ def test_random_geometries_and_settings(torch_gpu):
     oracle = oracle_mod()
     rng = np.random.Generator(np.random.PCG64(2718))
     sizes = [(32, 48), (48, 80), (80, 48), (112, 176), (96, 320), (176, 64), (144, 208), (64, 336)]
-    for case in range(16):
+    for case in range(24):
         h, w = sizes[case % len(sizes)]
         n = int(rng.integers(1, 6))
-        dtype = ["f32", "f32_split", "f32_split_f16"][case % 3]
+        dtype = ["f32", "f32_split", "f32_split_f16", "f32"][case % 4]
         de = bool(case % 4 != 3)
         nms, border = int(rng.integers(0, 7)), int(rng.integers(0, 7))
         thr = float(rng.choice([0.005, 0.015, 0.05]))
         sd = synth.make_state_dict(100 + case, dustbin_bias=float(rng.choice([2.0, 4.0])))
         frames = synth.make_batch(1000 + 10 * case, n, h, w)
-        e = engine(h, w, n, dtype=dtype, descriptor_enabled=de, nms_dist=nms, border_remove=border, conf_thresh=thr)
+        # every second fp32 case on the batch plan's kernels (F(4x4,3x3) tiles of 16 x 16 / 8 x 32 pixels on these odd sizes)
+        plan = dict(plan_flags=["no_latency_tiles"]) if dtype == "f32" and case % 2 == 0 else {}
+        e = engine(h, w, n, dtype=dtype, descriptor_enabled=de, nms_dist=nms, border_remove=border, conf_thresh=thr, **plan)
         e.load_state_dict(sd if de else {k: v for k, v in sd.items() if not k.startswith("descriptor.")})
         prob, desc, logits = e.forward(frames)
         res = e.detect(frames)
