@@ -98,13 +98,18 @@ struct W36Cfg {
 //    ds_read per MFMA 38.5 cycles instead of 32, three 39.6): the non-MFMA instructions of a step belong in ONE gap, in
 //    front of its eight MFMAs.  As separate asm statements the compiler put its own s_nop / s_waitcnt / address
 //    arithmetic between them: a step took 295 cycles instead of 256 + one gap.
+//  * The compiler does not know what is inside the asm, so it cannot place the wait states an MFMA result needs before
+//    a VALU instruction reads it (11 after this 8-pass MFMA) -- and it DOES read accumulators behind the asm: copies
+//    between the register files where its allocator splits a live range (seen right behind a block: v_accvgpr_read of
+//    the two accumulators just written -- stale values, wrong results).  The block therefore ends with its own 11 wait
+//    states; the seventh MFMA finished long before.
 template <bool AG0, bool AG1>
 __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
 #define FPC_MFMA8                                                                                                      \
   "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %14, %1\n\t"                                \
   "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"                                \
   "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"                                \
-  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %17, %1"
+  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %17, %1\n\ts_nop 10"
 #define FPC_MFMA8_IN                                                                                                   \
   "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b0[0]), "v"(b0[1]), \
       "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3])
@@ -281,6 +286,10 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   // in range and wrote 2 GB behind the tensor.)
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + blockIdx.y * N, 0, W36_MARKER, 0x00020000);
 
+  const int g2s = __builtin_amdgcn_readfirstlane(((a.k8_h + a.k8_x) / 2 + C::WPAD2) * 64);     // float4 per channel group of the 1x1 streams
+  const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.w2), 0, a.conv_only ? 0 : 4 * NB * g2s * 16, 0x00020000);
+  const unsigned w2lane = (unsigned)(wave * NB * g2s) * 16u + lane16;
+
   const int wg_stamp = wg_first + 2 * wg_step < wg_end ? wg_first + 2 * wg_step : wg_first;
   for (int wg = wg_first; wg < wg_end; wg += wg_step) {
     const int b = pos_cur.b, ty = pos_cur.ty, tx = pos_cur.tx;
@@ -289,10 +298,16 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
     if (wg == wg_stamp) { FPC_STAMP(0) }
 
     f32x4 acc[36][NB];
+    {
+      // (a zero the optimiser cannot see through: as the constant 0.f, every accumulator's initial tuple was a loop
+      // invariant of the persistent tile loop -- hoisted in front of it, 48 + 64 registers, and spilled)
+      float zf = 0.f;
+      asm volatile("" : "+v"(zf));
 #pragma unroll
-    for (int p = 0; p < 36; ++p)
+      for (int p = 0; p < 36; ++p)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[p][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NB; ++nb) acc[p][nb] = f32x4{zf, zf, zf, zf};
+    }
 
     BF bq[RING];
 #pragma unroll
@@ -372,9 +387,14 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
 #endif
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): once per tile (see wblock16_kernel)
-    for (int c = 0; c < nchunk; c += 2) {
-      chunk_body(std::integral_constant<int, 0>{}, c);
-      chunk_body(std::integral_constant<int, 1>{}, c + 1);
+    {   // (do-while: nchunk >= 4.  With a loop that may run zero times the ring's first fragments were also live on the
+        // path around it -- the compiler spilled all of them behind a vmcnt(0) and reloaded them after the loop.)
+      int c = 0;
+      do {
+        chunk_body(std::integral_constant<int, 0>{}, c);
+        chunk_body(std::integral_constant<int, 1>{}, c + 1);
+        c += 2;
+      } while (c < nchunk);
     }
     if (wg == wg_stamp) { FPC_STAMP(1) }
     // (the last MFMAs' results are read by VALU instructions below: a wait the compiler manages for its own MFMAs and
@@ -458,38 +478,14 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       }
       FPC_LDS_BARRIER();
       if (wg == wg_stamp && half == 0) { FPC_STAMP(2) }
-      // ------------------------------------------------ shortcut operands requested now, used after the GEMM over h
-      constexpr int XIT = HPX * 32 / NT;                            // x staging float4 per thread and pass: 16
-      f32x4 xst[XIT];
-      auto load_x = [&](int pass) {    // projection: up to 128 channels of the half's pixels, [px][32 float4]; pixel m = (tid >> 5) + 8 i
-        const int kx4 = min(32, a.k8_x * 2 - pass * 32);
-        const int xp = ((tid_t >> 5) * a.csx + ((tid_t & 31) < kx4 ? pass * 128 + (tid_t & 31) * 4 : 0)) * 4;
-#pragma unroll
-        for (int i = 0; i < XIT; ++i) {
-          constexpr int XCPR = TW / 8;
-          const int so = xbase + ((i / XCPR) * a.W + (i % XCPR) * 8) * a.csx * 4;      // (uniform)
-          xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xp + so, 0, 0));
-        }
-      };
-      if (!a.conv_only) {
-        if (proj) load_x(0);
-        else {                          // identity: x in the layout of the output stores, added in the epilogue
-#pragma unroll
-          for (int i = 0; i < EIT; ++i) {
-            const int so = xbase + ((i / CPR) * a.W + (i % CPR) * PPI) * a.csx * 4;     // (uniform)
-            xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xpart + so, 0, 0));
-          }
-        }
-      }
       // output float4 i of this thread: LDS [m0 + PPI i][c4t], global row i / CPR, column step i % CPR
       int erd = TL4 + m0 * (RH / 4) + c4t;
       asm volatile("" : "+v"(erd));
-      auto store_out = [&](bool add_x) {
+      auto store_out = [&]() {
 #pragma unroll
         for (int i = 0; i < EIT; ++i) {
           if (i / CPR < rows_valid) {                                     // (uniform)
             f32x4 v = lds4[erd + i * PPI * (RH / 4)];
-            if (add_x) v += xst[i];
             if (!a.conv_only) {
               v.x = v.x > 0.f ? v.x : 0.f;
               v.y = v.y > 0.f ? v.y : 0.f;
@@ -505,22 +501,17 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       };
 
       if (a.conv_only) {  // h is the result: [128 px][N] in LDS -> 16-byte stores (ReLU already applied)
-        store_out(false);
+        store_out();
         FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
         continue;
       }
 
       // ------------------------------------------------ phase 2: 1x1 over h (+ projection over x), 8 pixel blocks x NB channel blocks per wave
       f32x4 acc2[8][NB];
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const size_t g2stride = ((size_t)(a.k8_h + a.k8_x) / 2 + C::WPAD2) * 64;     // float4 per channel group
-      const float4* const w2s = a.w2 + (size_t)(wave * NB) * g2stride;
+      // the 1x1 fragments through a buffer descriptor, as the 3x3's: step and channel block in the SCALAR offset (a
+      // 64-bit address per load is two VALU instructions in an MFMA gap)
       auto ldb2 = [&](int s, int nb) {
-        const float4 v = fpc_ldg_su(w2s + (size_t)nb * g2stride + (size_t)s * 64, lane16);
-        return f32x4{v.x, v.y, v.z, v.w};
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, (int)w2lane, (nb * g2s + s * 64) * 16, 0));
       };
       constexpr int KH = N / 16;
       // one 16-channel step of the GEMM: blocks of eight MFMAs (one pixel block x 2 channel blocks, or two pixel blocks x 1),
@@ -560,9 +551,34 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           }
         }
       };
-      gemm_over(RH / 4, KH, 0);
-      if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
+      // Shortcut.  Every register of it is DEFINED AND USED inside one branch: declared in front of the branches and
+      // used behind them, the staging registers were undefined values live around the whole tile loop -- and spilled.
       if (proj) {
+        // projection: more K for the same accumulators -- up to 128 channels of the half's pixels per pass, [px][32 float4];
+        // pixel m = (tid >> 5) + 8 i
+        constexpr int XIT = HPX * 32 / NT;                            // staging float4 per thread and pass: 16
+        f32x4 xst[XIT];
+        auto load_x = [&](int pass) {
+          const int kx4 = min(32, a.k8_x * 2 - pass * 32);
+          const int xp = ((tid_t >> 5) * a.csx + ((tid_t & 31) < kx4 ? pass * 128 + (tid_t & 31) * 4 : 0)) * 4;
+#pragma unroll
+          for (int i = 0; i < XIT; ++i) {
+            constexpr int XCPR = TW / 8;
+            const int so = xbase + ((i / XCPR) * a.W + (i % XCPR) * 8) * a.csx * 4;      // (uniform)
+            xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xp + so, 0, 0));
+          }
+        };
+        load_x(0);
+        {
+          float zf = 0.f;
+          asm volatile("" : "+v"(zf));
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{zf, zf, zf, zf};
+        }
+        gemm_over(RH / 4, KH, 0);
+        if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
         const int npass = (a.k8_x + 15) >> 4;
         for (int pass = 0; pass < npass; ++pass) {
           FPC_LDS_BARRIER();   // h (or the previous pass's x) has been read by every wave
@@ -577,6 +593,23 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           const int steps = min(8, a.k8_x / 2 - pass * 8);   // 16-channel steps of this pass: 4 or 8
           gemm_over(RX / 4, steps, KH + pass * 8);
         }
+      } else {
+        // identity: x is the INITIAL VALUE of the accumulators, read in their layout (row 4 kq + r of pixel block mb, this
+        // lane's channel): 64 four-byte loads per lane and half, no staging registers, no additions in the epilogue
+        int xl = (4 * kq * a.csx + 16 * (wave * NB) + n16) * 4;
+        asm volatile("" : "+v"(xl));
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            constexpr int BPR = TW / 16;                                // pixel blocks per pixel row (1 or 2)
+            const int so = xbase + ((mb / BPR) * a.W + (mb % BPR) * 16 + r) * a.csx * 4;      // (uniform)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc2[mb][nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xl + so + 64 * nb, 0, 0));
+          }
+        gemm_over(RH / 4, KH, 0);
+        if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
       }
 
       // ------------------------------------------------ epilogue: output tile through LDS -> 16-byte stores
@@ -596,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
         }
       }
       FPC_LDS_BARRIER();
-      store_out(!proj);
+      store_out();
       if (wg == wg_stamp && half == 0) { FPC_STAMP(5) }
       FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
     }  // halves
