@@ -76,16 +76,16 @@ struct W36Cfg {
   static constexpr int LDS_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-  // one ring step = 8 MFMAs: one position x 2 channel blocks (NB = 2) or two positions x 1 block (NB = 1: two
-  // accumulators alternate, a single dependent chain would run at 40 instead of 32 cycles per MFMA)
-  static constexpr int STEPS = NB == 2 ? 36 : 18;
-  // Ring depth in steps (8 registers each; must divide STEPS so that slot indices are compile-time constants across
+  // one ring step = TWO positions: 16 MFMAs (NB = 2: two positions x two channel blocks, four accumulators in turn) or 8
+  // (NB = 1: two accumulators in turn -- a single dependent chain would run at 40 instead of 32 cycles per MFMA)
+  static constexpr int STEPS = 18;
+  // Ring depth in steps (8 NB registers each; must divide STEPS so that slot indices are compile-time constants across
   // chunks).  vmcnt retires in order: a fragment requested after the chunk's halo request waits for it, so the ring has
-  // to hold the fragments of that whole latency (RING - 1 steps of 256 cycles).
-  static constexpr int RING = NB == 2 ? 9 : 18;
+  // to hold the fragments of that whole latency (RING - 1 steps of 256 NB cycles).
+  static constexpr int RING = NB == 2 ? 6 : 18;
   static_assert(STEPS % RING == 0, "ring slots must line up across chunks");
   static constexpr int PAG = NB == 2 ? 30 : 36;                     // positions whose accumulators live in AGPRs (240 of 256; the other 48 registers in VGPRs)
-  static constexpr int WPAD = 2 * RING;                             // zero POSITIONS behind every channel group's stream
+  static constexpr int WPAD = 36;                                   // zero POSITIONS behind every channel group's stream (>= 2 RING)
   static constexpr int WPAD2 = 16;                                  // ... and steps behind the 1x1 streams (as generation 2)
 };
 
@@ -126,6 +126,31 @@ __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4&
 // >= marker, which is the (or above the) range of every descriptor here.  Tensors must be smaller than this (the host
 // checks: fpc_api.hip, w36_fits).
 #define W36_MARKER 0x7fffff00
+
+// Sixteen MFMAs as one statement -- two positions x two channel blocks, four accumulators in turn -- for the 128-channel
+// instance: half as many gaps and half as many trailing wait states per MFMA as blocks of eight.
+template <bool AG>
+__device__ __forceinline__ void fpc_mfma_step16(f32x4& c00, f32x4& c01, f32x4& c10, f32x4& c11, const f32x4& a0, const f32x4& a1,
+                                                const f32x4& b00, const f32x4& b01, const f32x4& b10, const f32x4& b11) {
+  // operands: 0-3 accumulators; 4-7 a0; 8-11 a1; 12-15 b00; 16-19 b01; 20-23 b10; 24-27 b11
+#define FPC_MFMA16                                                                                                      \
+  "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\tv_mfma_f32_16x16x4_f32 %1, %4, %16, %1\n\t"                               \
+  "v_mfma_f32_16x16x4_f32 %2, %8, %20, %2\n\tv_mfma_f32_16x16x4_f32 %3, %8, %24, %3\n\t"                               \
+  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\tv_mfma_f32_16x16x4_f32 %1, %5, %17, %1\n\t"                               \
+  "v_mfma_f32_16x16x4_f32 %2, %9, %21, %2\n\tv_mfma_f32_16x16x4_f32 %3, %9, %25, %3\n\t"                               \
+  "v_mfma_f32_16x16x4_f32 %0, %6, %14, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %18, %1\n\t"                               \
+  "v_mfma_f32_16x16x4_f32 %2, %10, %22, %2\n\tv_mfma_f32_16x16x4_f32 %3, %10, %26, %3\n\t"                             \
+  "v_mfma_f32_16x16x4_f32 %0, %7, %15, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %19, %1\n\t"                               \
+  "v_mfma_f32_16x16x4_f32 %2, %11, %23, %2\n\tv_mfma_f32_16x16x4_f32 %3, %11, %27, %3\n\ts_nop 10"
+#define FPC_MFMA16_IN                                                                                                   \
+  "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b00[0]), "v"(b00[1]), \
+      "v"(b00[2]), "v"(b00[3]), "v"(b01[0]), "v"(b01[1]), "v"(b01[2]), "v"(b01[3]), "v"(b10[0]), "v"(b10[1]), "v"(b10[2]),  \
+      "v"(b10[3]), "v"(b11[0]), "v"(b11[1]), "v"(b11[2]), "v"(b11[3])
+  if constexpr (AG) asm volatile(FPC_MFMA16 : "+a"(c00), "+a"(c01), "+a"(c10), "+a"(c11) : FPC_MFMA16_IN);
+  else asm volatile(FPC_MFMA16 : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11) : FPC_MFMA16_IN);
+#undef FPC_MFMA16
+#undef FPC_MFMA16_IN
+}
 
 template <int NB, int TYT, int TXT>
 __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
@@ -252,16 +277,14 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(w1h), 0, (int)(4u * (unsigned)NB * gstride), 0x00020000);
   const unsigned wlane = (unsigned)(wave * NB) * gstride + lane16;
   const int gs_s = __builtin_amdgcn_readfirstlane((int)gstride);
-  struct BF { f32x4 v[2]; };
-  auto ldb = [&](int s) {      // ring step s (counted from the tile's first chunk)
+  struct BF { f32x4 v[2][NB]; };      // [position of the step][channel block]
+  auto ldb = [&](int s) {      // ring step s (counted from the tile's first chunk): positions 2 s, 2 s + 1
     BF r;
-    if (NB == 2) {
-      r.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024, 0));
-      r.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 1024 + gs_s, 0));
-    } else {
-      r.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 2048, 0));
-      r.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, s * 2048 + 1024, 0));
-    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        r.v[q][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane, (2 * s + q) * 1024 + nb * gs_s, 0));
     return r;
   };
 
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       int ao = aoff4 + VB_OFF / 4, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
       asm volatile("" : "+v"(ao), "+v"(trd_c), "+v"(twr_c));
       // A operand: two register sets, the next step's read while this step's MFMAs run
-      constexpr int AQ = NB == 2 ? 1 : 2;       // positions per step
+      constexpr int AQ = 2;                     // positions per step
       f32x4 ac[2][AQ];
 #pragma unroll
       for (int q = 0; q < AQ; ++q) ac[0][q] = lds4[ao + q * 64];
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
 #endif
       fpc_static_for<STEPS>([&](auto S) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
-        if constexpr (s % (STEPS / 9) == 0) { FPC_TQ(s / (STEPS / 9)) }
+        if constexpr (s % 2 == 0) { FPC_TQ(s / 2) }
         // ---- the step's gap: everything that is not an MFMA, in front of the eight MFMAs
         bq[(s + RING - 1) % RING] = ldb(c * STEPS + s + RING - 1);
         if (s + 1 < STEPS) {
@@ -364,18 +387,22 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- eight MFMAs
+        // ---- the step's MFMAs
         {
           const BF& bv = bq[s % RING];
-          constexpr int p0 = NB == 2 ? s : 2 * s, p1 = NB == 2 ? s : 2 * s + 1, n1 = NB == 2 ? 1 : 0;
-          fpc_mfma_step<(p0 < C::PAG), (p1 < C::PAG)>(acc[p0][0], acc[p1][n1], ac[s & 1][0], ac[s & 1][AQ - 1], bv.v[0], bv.v[1]);
+          constexpr int p0 = 2 * s, p1 = 2 * s + 1;
+          if constexpr (NB == 2)
+            fpc_mfma_step16<(p0 < C::PAG)>(acc[p0][0], acc[p0][1], acc[p1][0], acc[p1][1], ac[s & 1][0], ac[s & 1][1], bv.v[0][0], bv.v[0][1],
+                                           bv.v[1][0], bv.v[1][NB - 1]);
+          else
+            fpc_mfma_step<true, true>(acc[p0][0], acc[p1][0], ac[s & 1][0], ac[s & 1][1], bv.v[0][0], bv.v[1][0]);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
       FPC_TQ(9)
       // this wave's halo requests of the chunk have landed in LDS: everything but the ring's newest fragments is complete
       // (vmcnt counts in order; the ring waits above already imply it -- stated for the hardware, free)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING - 1)) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB * (RING - 1)) : "memory");
       FPC_LDS_BARRIER();
       FPC_TQ(10)
 #ifdef FPC_DIAG
@@ -455,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
 
     // per-thread parts of the tail's global addresses (bytes), for this tile
     const int m0 = tid_t / C4, c4t = tid_t - m0 * C4;
-    const int xpart = (m0 * a.csx + c4t * 4) * 4, opart = (m0 * a.cso + c4t * 4) * 4;
+    const int opart = (m0 * a.cso + c4t * 4) * 4;
     int ocol[CPR];                              // opart + column step k, or a huge positive number where that column is outside the frame
 #pragma unroll
     for (int k = 0; k < CPR; ++k) ocol[k] = (tx * TW + m0 + k * PPI < a.W) ? opart + k * PPI * a.cso * 4 : W36_MARKER;
