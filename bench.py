@@ -440,8 +440,11 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("FPC_BENCH_CONTEXTS", "1")),
-                    help="fpc contexts used round-robin (double buffering: batch k+1 starts while batch k drains)")
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("FPC_BENCH_CONTEXTS", "0")),
+                    help="fpc contexts used round-robin (double buffering: batch k+1 starts while batch k drains).  Default "
+                         "(0): 2 for the fp32 VGA workload, each running its batch as ONE sub-batch -- a 32-frame launch of "
+                         "the F(4x4,3x3) blocks is 640 tiles = 2.5 rounds of the 256 CUs, which only a second independent "
+                         "batch can fill -- and 1 elsewhere.  `single_context` in the line is the same loop on one context.")
     ap.add_argument("--gray", action="store_true",
                     help="feed gray frames [n,1,H,W] (in_channels=1: stem filters summed over the input channels); "
                          "default is the reference network's 3-channel input")
@@ -480,6 +483,9 @@ def main():
         H, W, BATCH, dtype = 960, 1280, 64, "bf16"
         args.no_host_fed = True
     mode = Mode(dtype, args.workload)
+    auto_ctx = args.contexts <= 0
+    if auto_ctx:
+        args.contexts = 2 if (args.workload == "vga32" and dtype == "f32" and args.arch == "resnet") else 1
 
     rank, world, local = fdist.init_from_env()
     if world != args.gpus:
@@ -509,6 +515,9 @@ def main():
     sd = (synth.make_vgg_state_dict(0, dustbin_bias=5.5) if vgg else synth.make_state_dict(0, dustbin_bias=7.0)) if rank == 0 else None
     cin = 1 if args.gray else 3
     kw = dict(device=local, in_channels=cin, dtype=dtype, arch=args.arch, descriptor_enabled=not magic)
+    kw1 = dict(kw)                       # a context on its own: the library's default plan (two sub-batches on two streams)
+    if args.contexts > 1 and "FPC_STREAMS" not in os.environ:
+        kw["num_streams"] = 1            # contexts in turn: each runs its whole batch as one sub-batch
     eng = Engine(H, W, max_batch=BATCH, **kw)
     fdist.barrier()
     tb0 = time.perf_counter()
@@ -578,10 +587,31 @@ def main():
                   "ms_per_step": round(d1 / ks * 1e3, 4)}
 
     single = rank == 0 and world == 1
+    single_ctx = None
+    if args.contexts > 1 and not args.only_timed:
+        # the same loop on ONE context with the library's default plan (every rank; not part of `value`)
+        e0 = Engine(H, W, max_batch=BATCH, **kw1)
+        e0.import_packed(eng.export_packed())
+        for _ in range(min(10, args.warmup)):
+            e0.detect_async(frames, BATCH)
+        e0.sync()
+        ks = max(args.steps, 50)
+        fdist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            e0.detect_async(frames, BATCH)
+        e0.sync()
+        torch.cuda.synchronize(dev)
+        fdist.barrier()
+        d1 = fdist.max_over_ranks(time.perf_counter() - t1)
+        single_ctx = {"value": round(BATCH * ks * world / d1, 2), "unit": "frames/s", "steps": ks, "ms_per_step": round(d1 / ks * 1e3, 4),
+                      "plan": "one context, the library's default plan (two sub-batches of 16 frames on two streams)"}
+        e0.close()
     serial = None
     if use_events and single and not args.no_serial_pass:
         # same kernels, one stream: clean per-kernel durations (not part of `value`)
-        e1 = Engine(H, W, max_batch=BATCH, num_streams=1, plan_flags=["nms_in_line"], **kw)
+        e1 = Engine(H, W, max_batch=BATCH, num_streams=1, plan_flags=["nms_in_line"], **kw1)
         e1.import_packed(eng.export_packed())
         for _ in range(2):
             e1.detect_async(frames, BATCH)
@@ -597,7 +627,7 @@ def main():
         e1.close()
     latency = None
     if single and not args.no_latency:
-        el = Engine(H, W, max_batch=1, **kw)
+        el = Engine(H, W, max_batch=1, **kw1)
         el.import_packed(eng.export_packed())
         one = frames[:1].contiguous()
         for _ in range(20):
@@ -685,6 +715,11 @@ def main():
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
             "weights_broadcast_ms": round(bcast_ms, 2),
         }
+        out["config"]["contexts"] = args.contexts
+        out["config"]["batches_in_flight"] = ("%d contexts in turn, each a whole 32-frame batch per call on one stream: batch k+1 starts while "
+                                              "batch k drains" % args.contexts) if args.contexts > 1 else "1 context"
+        if single_ctx is not None:
+            out["single_context"] = single_ctx
         if per_rank is not None:
             out["per_rank"] = {"frames_per_s": [r[0] for r in per_rank], "weights_start_up_ms": [r[1] for r in per_rank]}
         if steady is not None:

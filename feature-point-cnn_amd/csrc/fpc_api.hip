@@ -1440,8 +1440,21 @@ static int build_plan(fpc_ctx* c) {
         const fpc_ctx::ConvW cwa = c->convw[ia];
         c->ops.insert(c->ops.begin() + ia + 1, oh);
         c->convw.insert(c->convw.begin() + ia + 1, cwa);
+      } else if (g_wkinds[c->ops[c->ops.size() - 3].wkind].gen == 3 && c->latency_tiles) {
+        // generation 3's fragments have 36 positions: the small-call variant (generation 2 on 4 x 16 tiles, then the same
+        // 1x1) gets fragments of its own
+        for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
+        const size_t ib = c->ops.size();
+        for (int n0 = 0; n0 < 256; n0 += 128)
+          add_wconv(c, p, true, WK_W16_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+        add_conv(c, t, &bo);
+        retile_last(c, K_T320_1x1_K64_N128);
+        Op& oh = c->ops[ib];
+        oh.wkind = WK_W16_C128H;
+        oh.wargs.tiles_y = (H16 + 3) / 4;
+        oh.mfma_flops_per_frame = 2 * 2.0 * oh.wargs.tiles_x * oh.wargs.tiles_y * 128.0 * (16.0 * 16 * 256);
+        for (size_t k = ib; k < c->ops.size(); ++k) c->ops[k].when = 1;
       } else if (c->latency_tiles || c->winograd_gen == 1) {
-      // (generation 3 comes here too: its fragments have 36 positions, so a 4 x 16 instance of generation 2 could not share them)
       for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
       // a call of a few frames has 12 tiles per frame here: three dependent launches cost more latency than they save
       // work, so small calls take the fused direct block instead (its weights sit in the blob next to the others)
