@@ -7,8 +7,8 @@
 #include "../../feature-point-cnn_amd/csrc/block_bf16.h"
 #include "../../feature-point-cnn_amd/csrc/block_x3.h"
 using namespace fpc;
-#ifndef ABL
-#define ABL 0   // -DABL=8 (STEMB_ABL_POOL) etc.: one phase removed, see block_x3.h
+#ifndef STEM_ABL
+#define STEM_ABL 0   // -DSTEM_ABL=8 (STEMB_ABL_POOL) etc.: one phase removed, see block_x3.h
 #endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
@@ -24,12 +24,12 @@ int main(int argc, char** argv) {
   CK(hipMemset(bias, 0, 256));
   StemX3Args a{}; a.in = in; a.wfrag = wf; a.bias = bias; a.out = (float*)out; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Hp = H / 4; a.Wp = W / 4;
   a.tiles_x = (a.Wp + 7) / 8; a.tiles_y = (a.Hp + 7) / 8; a.frames = B;
-  CK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<3, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<3>::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<3, STEM_ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<3>::LDS_BYTES));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
   for (int rep = 0; rep < 6; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(stem_pool_bf16_kernel<3, ABL>, dim3(G), dim3(STEMB_THREADS), StemBCfg<3>::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL((stem_pool_bf16_kernel<3, STEM_ABL>), dim3(G), dim3(STEMB_THREADS), StemBCfg<3>::LDS_BYTES, 0, a);
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
