@@ -101,15 +101,19 @@ struct W36Cfg {
 //  * The compiler does not know what is inside the asm, so it cannot place the wait states an MFMA result needs before
 //    a VALU instruction reads it (11 after this 8-pass MFMA) -- and it DOES read accumulators behind the asm: copies
 //    between the register files where its allocator splits a live range (seen right behind a block: v_accvgpr_read of
-//    the two accumulators just written -- stale values, wrong results).  The block therefore ends with its own 11 wait
-//    states; the seventh MFMA finished long before.
+//    the two accumulators just written -- stale values, wrong results).  Eleven s_nop wait states at the end of every
+//    block fix that at 5 % of the kernel's time.  Instead the block's LAST MFMA is the compiler's own builtin: it then
+//    knows the hazard of the one result that can still be in flight when the block ends and pays for it only where it
+//    really puts a reader there (every other MFMA of the block was issued at least 32 cycles -- one MFMA -- earlier and
+//    has all but written its result when the last one issues: 40 cycles from issue to result, 32 to the next issue
+//    plus the builtin's own issue slots -- and two s_nop cycles at the end of the asm for margin).
 template <bool AG0, bool AG1>
 __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
 #define FPC_MFMA8                                                                                                      \
   "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %14, %1\n\t"                                \
   "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"                                \
   "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"                                \
-  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %17, %1\n\ts_nop 10"
+  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\ts_nop 1"
 #define FPC_MFMA8_IN                                                                                                   \
   "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b0[0]), "v"(b0[1]), \
       "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3])
@@ -117,6 +121,8 @@ __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4&
   else if constexpr (AG0) asm volatile(FPC_MFMA8 : "+a"(c0), "+v"(c1) : FPC_MFMA8_IN);
   else if constexpr (AG1) asm volatile(FPC_MFMA8 : "+v"(c0), "+a"(c1) : FPC_MFMA8_IN);
   else asm volatile(FPC_MFMA8 : "+v"(c0), "+v"(c1) : FPC_MFMA8_IN);
+  // the LAST MFMA of the block is the compiler's own (see the header comment: it then knows the wait states)
+  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], c1, 0, 0, 0);
 #undef FPC_MFMA8
 #undef FPC_MFMA8_IN
 }
@@ -141,13 +147,14 @@ __device__ __forceinline__ void fpc_mfma_step16(f32x4& c00, f32x4& c01, f32x4& c
   "v_mfma_f32_16x16x4_f32 %0, %6, %14, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %18, %1\n\t"                               \
   "v_mfma_f32_16x16x4_f32 %2, %10, %22, %2\n\tv_mfma_f32_16x16x4_f32 %3, %10, %26, %3\n\t"                             \
   "v_mfma_f32_16x16x4_f32 %0, %7, %15, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %19, %1\n\t"                               \
-  "v_mfma_f32_16x16x4_f32 %2, %11, %23, %2\n\tv_mfma_f32_16x16x4_f32 %3, %11, %27, %3\n\ts_nop 10"
+  "v_mfma_f32_16x16x4_f32 %2, %11, %23, %2\n\ts_nop 1"
 #define FPC_MFMA16_IN                                                                                                   \
   "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b00[0]), "v"(b00[1]), \
       "v"(b00[2]), "v"(b00[3]), "v"(b01[0]), "v"(b01[1]), "v"(b01[2]), "v"(b01[3]), "v"(b10[0]), "v"(b10[1]), "v"(b10[2]),  \
       "v"(b10[3]), "v"(b11[0]), "v"(b11[1]), "v"(b11[2]), "v"(b11[3])
   if constexpr (AG) asm volatile(FPC_MFMA16 : "+a"(c00), "+a"(c01), "+a"(c10), "+a"(c11) : FPC_MFMA16_IN);
   else asm volatile(FPC_MFMA16 : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11) : FPC_MFMA16_IN);
+  c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b11[3], c11, 0, 0, 0);     // (the block's last MFMA: the compiler's own)
 #undef FPC_MFMA16
 #undef FPC_MFMA16_IN
 }
