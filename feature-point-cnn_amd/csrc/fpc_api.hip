@@ -1754,9 +1754,10 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
       for (int nb = 0; nb < 2; ++nb)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 4; ++j) {
-            const int k = g * 8 + 2 * j + (lane >> 5), n = nb * 32 + (lane & 31);
+            const StemPair sp = stem_pair(c->cin, g * 4 + j);      // the kernels' K order (kernels_misc.h)
+            const int k = (lane >> 5) ? sp.wb : sp.wa, n = nb * 32 + (lane & 31);
             double v = 0.0;
-            if (k < kreal) {
+            if (k >= 0 && k < kreal) {
               if (c->cin == 3) v = (double)w[n * 147 + k];
               else  // gray frame == the same plane in all three channels: sum the three filters
                 v = (double)w[n * 147 + k] + (double)w[n * 147 + 49 + k] + (double)w[n * 147 + 98 + k];

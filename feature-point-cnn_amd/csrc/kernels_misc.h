@@ -37,6 +37,28 @@ __device__ __forceinline__ constexpr int stem_koff(int k) {
   return (k / 49) * (STEM_HALO * STEM_LW) + ((k % 49) / 7) * STEM_LW + (k % 7);
 }
 
+// K order of the stem's GEMM (round 3).  One v_mfma_f32_32x32x2_f32 takes K = 2: lanes 0-31 supply one filter tap, lanes
+// 32-63 another.  With the taps in flat (c, ky, kx) order the two LDS addresses of a step differ by an amount that
+// changes from step to step (1 inside a filter row, 34 across its end, ...), i.e. a per-lane select + add in front of
+// every read -- two VALU instructions between MFMAs, and on gfx950 a VALU instruction between two fp32 MFMAs costs 15
+// cycles (generation 3).  Pairing taps so that the second lies either ONE COLUMN to the right of
+// the first or ONE ROW below it leaves two per-lane bases (a + half, a + half * STEM_LW) and a compile-time offset per
+// step: no VALU instruction in the K loop.  Per channel: 21 column pairs (kx = 0|1, 2|3, 4|5 of the 7 rows), 3 row pairs
+// (kx = 6 of rows 0|1, 2|3, 4|5) and the last tap (6, 6) as the SECOND of a column pair whose first, (6, 5) again, has
+// weight zero: 25 steps per channel (the flat order: 24.5).  The host packs the fragments from the same function.
+struct StemPair {
+  int addr_k;   // tap whose LDS address lanes 0-31 read (flat index c * 49 + ky * 7 + kx)
+  int wa, wb;   // taps whose WEIGHTS lanes 0-31 / 32-63 multiply (-1: zero)
+  int row;      // 1: lanes 32-63 read one LDS row below lanes 0-31; 0: one column to the right
+};
+__host__ __device__ constexpr StemPair stem_pair(int cin, int t) {
+  const int c = t / 25, i = t % 25;
+  if (c >= cin) return StemPair{0, -1, -1, 0};                                        // padding steps of the last group
+  if (i < 21) return StemPair{c * 49 + (i / 3) * 7 + 2 * (i % 3), c * 49 + (i / 3) * 7 + 2 * (i % 3), c * 49 + (i / 3) * 7 + 2 * (i % 3) + 1, 0};
+  if (i < 24) return StemPair{c * 49 + 2 * (i - 21) * 7 + 6, c * 49 + 2 * (i - 21) * 7 + 6, c * 49 + (2 * (i - 21) + 1) * 7 + 6, 1};
+  return StemPair{c * 49 + 6 * 7 + 5, -1, c * 49 + 6 * 7 + 6, 0};
+}
+
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   __shared__ float lds[STEM_LDS_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,11 +80,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   }
   __syncthreads();
 
-  int abase[2];
+  int acol[2], arow[2];   // A operand bases: lanes 32-63 one column to the right / one row below (stem_pair)
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const int m = (wave * 2 + mb) * 32 + l31;
-    abase[mb] = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T);
+    const int ab = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T);
+    acol[mb] = ab + half;
+    arow[mb] = ab + half * STEM_LW;
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -78,13 +102,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     const float4 bq0 = wp[(g * 2 + 0) * 64], bq1 = wp[(g * 2 + 1) * 64];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k0 = g * 8 + 2 * j;  // lanes 0-31 take k0, lanes 32-63 take k0+1
-      const int off = half ? stem_koff(k0 + 1) : stem_koff(k0);
+      constexpr int CIN3 = 3;
+      const StemPair P = stem_pair(CIN3, g * 4 + j);
+      const int off = stem_koff(P.addr_k);
       const float bf0 = j == 0 ? bq0.x : j == 1 ? bq0.y : j == 2 ? bq0.z : bq0.w;
       const float bf1 = j == 0 ? bq1.x : j == 1 ? bq1.y : j == 2 ? bq1.z : bq1.w;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const float af = lds[abase[mb] + off];
+        const float af = lds[(P.row ? arow[mb] : acol[mb]) + off];
         acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf0, acc[mb][0], 0, 0, 0);
         acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf1, acc[mb][1], 0, 0, 0);
       }
@@ -150,9 +175,12 @@ __device__ __forceinline__ void stem_pool_emit(const float* lds, float* out, int
     if (pass == 1 && j != 0) break;
     const int gpy = ty * 8 + py;
     if (gpy >= Hp) continue;
+    // (values may be negative: the fp32 stem hands over conv + bias and the ReLU comes after the max; the sentinel for
+    // "no pixel of this window in this tile" is far below anything a convolution produces)
+    constexpr float NONE = -3.0e38f;
     float cm[STEM_T];
 #pragma unroll
-    for (int cc = 0; cc < STEM_T; ++cc) cm[cc] = -1.f;
+    for (int cc = 0; cc < STEM_T; ++cc) cm[cc] = NONE;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int rr = 2 * py - 1 + dy;
@@ -162,15 +190,16 @@ __device__ __forceinline__ void stem_pool_emit(const float* lds, float* out, int
     }
 #pragma unroll
     for (int cc = 0; cc < STEM_T; ++cc)
-      if (gx0 + cc >= Wo) cm[cc] = -1.f;  // conv columns beyond the image
+      if (gx0 + cc >= Wo) cm[cc] = NONE;  // conv columns beyond the image
     float* row = out + ((size_t)(b * Hp + gpy) * Wp + tx * 8) * 64 + nb * 32 + c;
 #pragma unroll
     for (int px = 0; px < 9; ++px) {
       if (tx * 8 + px >= Wp) continue;
-      float mx = px < 8 ? cm[2 * px] : -1.f;
+      float mx = px < 8 ? cm[2 * px] : NONE;
       if (px > 0) mx = fmaxf(mx, cm[2 * px - 1]);
       if (px < 8) mx = fmaxf(mx, cm[2 * px + 1]);
-      if (mx < 0.f) continue;  // no pixel of this window lies in this tile
+      if (mx < -1.0e38f) continue;  // no pixel of this window lies in this tile
+      mx = fmaxf(mx, 0.f);         // ReLU (>= +0 from here on: the atomicMax on the float bits below relies on it)
       if (range_flag && mx > 65504.f) atomicOr(range_flag, 1);
       if (py >= 1 && py <= 7 && px >= 1 && px <= 7)
         row[px * 64] = mx;  // whole window inside this tile
@@ -223,19 +252,25 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   }
   __syncthreads();
 
-  int abase[2];
+  int acol[2], arow[2];   // A operand bases: lanes 32-63 one column to the right / one row below (stem_pair)
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const int m = (wave * 2 + mb) * 32 + l31;
-    abase[mb] = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T) + 1;  // + 1: LDS column 0 is image column ix0 - 1
+    const int ab = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T) + 1;  // + 1: LDS column 0 is image column ix0 - 1
+    acol[mb] = ab + half;
+    arow[mb] = ab + half * STEM_LW;
   }
+  // the accumulators START at the folded-BN bias (every register of a lane belongs to channel nb * 32 + l31): no
+  // addition in the epilogue; the ReLU moves behind the max-pool (max and ReLU commute: one per pooled value, not per pixel)
   f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j) {
+    const float bias = a.bias[j * 32 + l31];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bias;
+  }
 
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
@@ -245,13 +280,13 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k0 = g * 8 + 2 * j;  // lanes 0-31 take k0, lanes 32-63 take k0+1
-      const int off = half ? stem_koff_c<KREAL>(k0 + 1) : stem_koff_c<KREAL>(k0);
+      const StemPair P = stem_pair(CIN, g * 4 + j);
+      const int off = stem_koff_c<KREAL>(P.addr_k);
       const float bf0 = j == 0 ? q0[0].x : j == 1 ? q0[0].y : j == 2 ? q0[0].z : q0[0].w;
       const float bf1 = j == 0 ? q0[1].x : j == 1 ? q0[1].y : j == 2 ? q0[1].z : q0[1].w;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const float af = lds[abase[mb] + off];
+        const float af = lds[(P.row ? arow[mb] : acol[mb]) + off];
         acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf0, acc[mb][0], 0, 0, 0);
         acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf1, acc[mb][1], 0, 0, 0);
       }
@@ -266,14 +301,12 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     __syncthreads();  // nb == 0: halo reads done; nb == 1: previous half's pooling reads done
-    const float bias = a.bias[nb * 32 + l31];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (wave * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float v = acc[mb][nb][r] + bias;
-        lds[m * STEM_TROW + l31] = v > 0.f ? v : 0.f;
+        lds[m * STEM_TROW + l31] = acc[mb][nb][r];      // conv + bias, before the ReLU (stem_pool_emit applies it to the pooled value)
       }
     __syncthreads();
     stem_pool_emit(lds, a.out, b, ty, tx, nb, a.Ho, a.Wo, a.Hp, a.Wp, tid, nullptr);
