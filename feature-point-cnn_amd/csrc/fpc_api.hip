@@ -21,6 +21,7 @@
 #include "block_mfma.h"
 #include "block_bf16.h"
 #include "block_x3.h"
+#include "stem_bf16.h"
 #include "wblock_mfma.h"
 #include "wblock16_mfma.h"
 #include "wblock36_mfma.h"
@@ -1303,6 +1304,8 @@ static int build_plan(fpc_ctx* c) {
     op.bytes_per_frame = 4.0 * (double)c->cin * H * W + (c->bf16 ? 2.0 : 4.0) * 64.0 * H4 * W4;   // frame in, pooled map out
     if (c->split || c->bf16)  // stem_pool_x3_kernel: (rows + 1) / 2 K16 steps of six bf16 MFMAs
       op.mfma_flops_per_frame = (c->bf16 ? 1 : c->split_f16 ? 3 : 6) * 2.0 * ((H2 + 15) / 16) * ((W2 + 15) / 16) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
+    if (c->bf16)              // stem_bf16_kernel: 8 x 7 pooled pixels per tile, 8 blocks of 32 pixels x 64 channels x K16 steps
+      op.mfma_flops_per_frame = 2.0 * ((H4 + SB2_PH - 1) / SB2_PH) * ((W4 + SB2_PW - 1) / SB2_PW) * 256.0 * 64 * 16.0 * ((c->cin * 7 + 1) / 2);
     c->ops.push_back(op);
     c->convw.push_back({});
     c->stem_w_off = bo;
@@ -2131,10 +2134,12 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 2>), grid, dim3(256), 0, sb.st, x);
             } else if (c->bf16) {  // bf16 mode: bf16 operands like every other layer of the mode, bf16 out, no atomics
               x.frames = n;
-              const int T = a.tiles_x * a.tiles_y * n;
+              x.tiles_x = (x.Wp + SB2_PW - 1) / SB2_PW;   // stem_bf16.h: 8 x 7 pooled pixels per tile
+              x.tiles_y = (x.Hp + SB2_PH - 1) / SB2_PH;
+              const int T = x.tiles_x * x.tiles_y * n;
               const dim3 pg(std::min((T + 7) / 8 * 8, std::max(8, 2 * c->num_cus / 8 * 8)));  // two workgroups per CU, a multiple of 8
-              if (c->cin == 1) hipLaunchKernelGGL(stem_pool_bf16_kernel<1>, pg, dim3(STEMB_THREADS), StemBCfg<1>::LDS_BYTES, sb.st, x);
-              else hipLaunchKernelGGL(stem_pool_bf16_kernel<3>, pg, dim3(STEMB_THREADS), StemBCfg<3>::LDS_BYTES, sb.st, x);
+              if (c->cin == 1) hipLaunchKernelGGL(stem_bf16_kernel<1>, pg, dim3(SB2_THREADS), StemB2Cfg<1>::LDS_BYTES, sb.st, x);
+              else hipLaunchKernelGGL(stem_bf16_kernel<3>, pg, dim3(SB2_THREADS), StemB2Cfg<3>::LDS_BYTES, sb.st, x);
             } else {
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 3>), grid, dim3(256), 0, sb.st, x);
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 3>), grid, dim3(256), 0, sb.st, x);
@@ -2635,8 +2640,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   }
   HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                12 * cfg->width * (int)sizeof(float)));
-  HIPCHECK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<1>::LDS_BYTES));
-  HIPCHECK(hipFuncSetAttribute((const void*)stem_pool_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, StemBCfg<3>::LDS_BYTES));
+  HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<1>::LDS_BYTES));
+  HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<3>::LDS_BYTES));
   HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
 #ifdef FPC_DIAG
@@ -3220,7 +3225,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
     if (kernels) {
       const char* k = "?";
       if (op) switch (op->type) {
-          case OP_STEM: k = c->bf16 ? "stem_pool_bf16_kernel" : c->split ? "stem_pool_x3_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
+          case OP_STEM: k = c->bf16 ? "stem_bf16_kernel" : c->split ? "stem_pool_x3_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;
