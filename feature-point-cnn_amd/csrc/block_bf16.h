@@ -62,14 +62,43 @@ struct BlockBfArgs {
 #endif
 };
 
+// Pixel order inside a tile, and the halo's row pitch (round 3).  Phase 1 reads a pixel's 16 bytes of a K16 step with
+// ds_read_b128: the LDS serves that in groups of sixteen lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (banks =
+// 16-byte unit mod 16), and a halo pixel is ROW16 = KC / 8 + 1 units (odd), so a group is conflict-free iff its sixteen
+// halo pixel indices differ mod 16.  Row-major pixels (lane = pixel, 20 or 16 to a tile row, halo rows 22 or 18 wide)
+// put lanes 20-27 on the next tile row and two of them on the units of lanes 12-15: PMC showed 43-50 % of these
+// kernels' LDS cycles as bank conflicts at 0.5-0.6 LDS busy.  With 32-pixel blocks of FOUR tile rows x EIGHT pixels
+// (lane = 8 row + column) and a halo pitch = 8 mod 16 pixels, a group's lanes are columns 0-3 of rows 0 and 3 and 4-7 of
+// rows 1 and 2 (or the complement): indices {0-3}, {8 + 4..7}, {16 + 4..7}, {24 + 0..3} mod 16 -- all sixteen.
+// Stride-1 tiles whose sides are multiples of 4 x 8 use it; the others stay row-major.
+__host__ __device__ constexpr bool bf_blocked(int TH, int TW, int S) { return S == 1 && TH % 4 == 0 && TW % 8 == 0; }
+__host__ __device__ constexpr int bf_halo_pitch(int TH, int TW, int S, int EXT) {
+  const int hw = (TW - 1) * S + EXT;
+  return bf_blocked(TH, TW, S) ? (hw <= 8 ? 8 : (hw - 8 + 15) / 16 * 16 + 8) : hw;
+}
+// pixel m of a tile (block m >> 5, lane m & 31) -> tile row / column
+template <int TH, int TW, int S>
+__device__ __forceinline__ void bf_pixel(int m, int& py, int& px) {
+  if constexpr (bf_blocked(TH, TW, S)) {
+    constexpr int BX = TW / 8;
+    const int blk = m >> 5, l = m & 31;
+    py = (blk / BX) * 4 + (l >> 3);
+    px = (blk % BX) * 8 + (l & 7);
+  } else {
+    py = m / TW;
+    px = m - py * TW;
+  }
+}
+
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
 struct BlockBfCfg {
   static constexpr int NT = WM * WN * 64;
   static constexpr int HW = (TW - 1) * S + EXT, HH = (TH - 1) * S + EXT;
+  static constexpr int HP = bf_halo_pitch(TH, TW, S, EXT);   // halo row pitch in LDS, pixels
   static constexpr int ROW16 = KC / 8 + 1;            // 16-byte units per halo pixel (+1 skew)
   static constexpr int ROWH16 = CMIDP / 8 + 1;        // per h row
   static constexpr int M = WM * MB * 32, N = WN * NB * 32;
-  static constexpr int HALO_BYTES = HH * HW * ROW16 * 16;
+  static constexpr int HALO_BYTES = HH * HP * ROW16 * 16;
   static constexpr int H_BYTES = M * ROWH16 * 16;
   static constexpr int TILE_BYTES = HALO_BYTES > H_BYTES ? HALO_BYTES : H_BYTES;   // the halo chunk, then h
   static constexpr int LDS_BYTES = TILE_BYTES + 2 * N * 4;                         // + b1, b2
@@ -79,7 +108,7 @@ struct BlockBfCfg {
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
 __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockBfArgs a) {
   using C = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
-  constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
+  constexpr int NT = C::NT, HW = C::HW, HH = C::HH, HP = C::HP, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
   constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, ROWH16 = C::ROWH16, NBT = WN * NB;
   extern __shared__ uint4 lds16[];
 
@@ -113,8 +142,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   for (int mb = 0; mb < MB; ++mb) {
     int m = (wm * MB + mb) * 32 + l31;
     m = m < TH * TW ? m : TH * TW - 1;
-    const int py = m / TW, px = m - py * TW;
-    abase[mb] = ((py * S) * HW + px * S) * ROW16 + half;
+    int py, px;
+    bf_pixel<TH, TW, S>(m, py, px);
+    abase[mb] = ((py * S) * HP + px * S) * ROW16 + half;
   }
   constexpr int stepstride = NBT * 64;
   // The MFMAs below take the weight fragment as the A operand and the pixels as B: the accumulators then hold the tile
@@ -166,6 +196,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         pix = in ? pix : HH * HW - 1;
         c8 = in ? c8 : KC8;
       }
+      if constexpr (HP != HW) pix += (pix / HW) * (HP - HW);   // halo row pitch in LDS
       *reinterpret_cast<u32x4*>(&lds16[pix * ROW16 + c8]) = stage[i];
     }
   };
@@ -192,6 +223,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       wstep += stepstride * 16;
     }
   }
+#ifdef FPC_DIAG
+  // second record of a workgroup (+ 32768): shader clock / 100 MHz clock at its start and at the end of every tile, tile count
+  if (a.stamps && threadIdx.x == 0) {
+    unsigned long long t0_, r0_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_), "=s"(r0_)::"memory");
+    a.stamps[((size_t)blockIdx.x + 32768) * 8 + 0] = t0_;
+    a.stamps[((size_t)blockIdx.x + 32768) * 8 + 1] = r0_;
+    a.stamps[((size_t)blockIdx.x + 32768) * 8 + 4] = 0;
+  }
+#endif
   for (int tcur = t_first + (int)(blockIdx.x >> 3); tcur < t_end; tcur += per) {
   const int b = cur.b, ty = cur.ty, tx = cur.tx;
   const uint4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;   // (the ConvTranspose phases' path below)
@@ -206,6 +247,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 
   // ---------------------------------------------------------------- phase 1: KxK conv (+ the shortcut)
   FPC_STAMP(0)
+  FPC_RSTAMP(6)
   uint4 b0[NB], b1[NB];
   // A chunk of a ResNetBlock is 9 x K16 steps of conv1 and K16 steps of the SHORTCUT on the same chunk of x: the 1x1
   // projection (or the identity, as a unit matrix: exact in bf16 x fp32) reads exactly the pixels the 3x3's centre tap
@@ -224,7 +266,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       store_chunk();
       FPC_LDS_BARRIER();
       if (chunk == 0) { FPC_STAMP(1) }
-      if (chunk == 1) { FPC_STAMP(6) }
       load_chunk(cur, chunk + 1);
       u32x4 av[MB], an[MB];
 #pragma unroll
@@ -412,7 +453,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
         if (tid == 0) s_cnt = 0;
         FPC_LDS_BARRIER();   // phase 2 has read h; the counter is visible
         const int m = ml;
-        const int py = m / TW, px = m - py * TW;
+        int py, px;
+        bf_pixel<TH, TW, S>(m, py, px);
         const int y = oyb + py, x = oxb + px;
         const bool live = (m < TH * TW) & (y < a.Ho) & (x < a.Wo);
         const int W8 = a.Wo * 8;
@@ -468,7 +510,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
           uint32_t* dst = a.cand + (size_t)(b - a.frame0) * a.Ho * 8 * W8 + s_base;
           for (int i = tid; i < ncl; i += NT) {
             const int id = s_list[i], mm = id >> 6, cc = id & 63;
-            const int yy = oyb + mm / TW, xx = oxb + mm % TW;
+            int my, mx;
+            bf_pixel<TH, TW, S>(mm, my, mx);
+            const int yy = oyb + my, xx = oxb + mx;
             dst[i] = (uint32_t)((8 * yy + (cc >> 3)) * W8 + 8 * xx + (cc & 7));
           }
         }
@@ -480,7 +524,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int m = ml + mb * 32;
-        const int py = m / TW, px = m - py * TW;
+        int py, px;
+        bf_pixel<TH, TW, S>(m, py, px);
         const int y = oyb + py, x = oxb + px;
         const bool live = (m < TH * TW) & (y < a.Ho) & (x < a.Wo);
         const unsigned obase = (unsigned)((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * (unsigned)(a.cso * 4);
@@ -526,7 +571,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       for (int i = 0; i < EIT; ++i) {
         const int e = tl + i * NT;
         const int m = e / C8, c8 = e - m * C8;
-        const int py = m / TW, px = m - py * TW;
+        int py, px;
+        bf_pixel<TH, TW, S>(m, py, px);
         const int y = oyb + py, x = oxb + px;
         const bool on = (NE % NT == 0 || e < NE) & (y < a.Ho) & (x < a.Wo);
         const unsigned off = (unsigned)((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * (unsigned)(a.cso * 2) + (unsigned)(c8 * 16);
@@ -536,6 +582,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     }
   }
   FPC_STAMP(5)
+  FPC_RSTAMP(7)
+#ifdef FPC_DIAG
+  if (a.stamps && threadIdx.x == 0) {
+    unsigned long long t0_, r0_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_), "=s"(r0_)::"memory");
+    a.stamps[((size_t)blockIdx.x + 32768) * 8 + 2] = t0_;
+    a.stamps[((size_t)blockIdx.x + 32768) * 8 + 3] = r0_;
+    a.stamps[((size_t)blockIdx.x + 32768) * 8 + 4] += 1;
+  }
+#endif
   cur = nxt;
   }
 }

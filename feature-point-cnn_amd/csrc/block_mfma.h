@@ -27,8 +27,16 @@ namespace fpc {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
     a.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                         \
   }
+// the constant 100 MHz clock beside it (slot i): in-kernel shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+#define FPC_RSTAMP(i)                                                                    \
+  if (a.stamps && threadIdx.x == 0) {                                                    \
+    unsigned long long t_;                                                               \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    a.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                         \
+  }
 #else
 #define FPC_STAMP(i)
+#define FPC_RSTAMP(i)
 #endif
 
 struct BlockArgs {

@@ -255,13 +255,13 @@ static WKind w36_kind(int cout, int H, int W) {
 #define FPC_BF16_KINDS(X)                                                                   \
   X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
   X(F620_s2_K16_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)   \
-  X(F620_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)   \
-  X(F620_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 4, 1, 1, 3, 80)     \
-  X(F620_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 80, 4, 1, 1, 3, 80)     \
-  X(F620_s1_K64_C80w, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 3, 64, 2, 2, 2, 2, 80)   \
+  X(F816_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 1, 4, 4, 1, 128)   \
+  X(F816_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 4, 1, 1, 3, 80)     \
+  X(F816_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 80, 4, 1, 1, 3, 80)     \
+  X(F816_s1_K64_C80w, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 1, 4, 4, 1, 80)   \
   X(F320_s2_K32_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)   \
-  X(F320_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 1, 3, 64, 1, 4, 2, 2, 256)   \
-  X(F620_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 1, 2, 64, 2, 2, 2, 2, 128)   \
+  X(F416_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 4, 16, 1, 3, 64, 1, 4, 2, 2, 256)   \
+  X(F816_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 2, 64, 1, 4, 4, 1, 128)   \
   X(S816_s1_K64_C64, block_x3_kernel, BlockX3Cfg, 3, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)       \
   X(S620_s2_K16_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)     \
   X(S620_s1_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)     \
@@ -837,7 +837,8 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   a.W = s.W;
   a.ntaps = 9;
   a.pad = 1;
-  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
+  // (halo row pitch: block_bf16_kernel pads it for its bank-conflict-free pixel order, block_bf16.h)
+  const int HWp = k.planes == 1 ? bf_halo_pitch(k.TH, k.TW, k.S, k.EXT) : (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) a.tapoff16[ky * 3 + kx] = (ky * HWp + kx) * ROW16;
   a.k16_h = k.CMIDP / 16;
@@ -880,7 +881,7 @@ static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, 
   if (kind >= FK_COUNT) { c->plan_error = true; return; }
   const FKindInfo& k = g_fkinds[kind];
   const int nbt = k.WN * k.NB, K16 = k.KC / 16;
-  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
+  const int HWp = k.planes == 1 ? bf_halo_pitch(k.TH, k.TW, k.S, k.EXT) : (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
   for (int ph = 0; ph < 4; ++ph) {
     const int py = ph >> 1, px = ph & 1;
     Op op;
@@ -947,12 +948,12 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
   add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
-  add_fblock(c, {"encoder.layer2.1", FK_F620_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", FK_F816_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
   // detector.layer.0 on the 2 x 2 blocking of the 128-wide layers (N = 128 for 65 channels: a quarter of the MFMAs on
   // zeros, but four MFMAs per four operand fetches instead of three per four: 0.47 -> 0.40 ms per 64 HD frames);
   // layer.1 (K = 80) measured the same on both shapes and keeps the narrower one
-  add_fblock(c, {"detector.layer.0", FK_F620_s1_K64_C80w, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
-  add_fblock(c, {"detector.layer.1", FK_F620_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
+  add_fblock(c, {"detector.layer.0", FK_F816_s1_K64_C80w, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
+  add_fblock(c, {"detector.layer.1", FK_F816_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
   c->ops.back().fused_softmax_capable = c->fuse_softmax;
   {
     Op op;
@@ -963,10 +964,10 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   }
   if (de) {
     add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K32_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_in.1", FK_F320_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
-    add_fconvT(c, FK_F620_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
-    add_fblock(c, {"descriptor.layer_out.0", FK_F620_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_out.1", FK_F620_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
+    add_fconvT(c, FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
+    add_fblock(c, {"descriptor.layer_out.0", FK_F816_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", FK_F816_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
   }
 }
 
@@ -1009,7 +1010,7 @@ static void add_fconv(fpc_ctx* c, FKind kind, const std::string& prefix, const f
   if (kind >= FK_COUNT) { c->plan_error = true; return; }
   const FKindInfo& k = g_fkinds[kind];
   const int nbt = k.WN * k.NB, K16 = k.KC / 16;
-  const int HWp = (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
+  const int HWp = k.planes == 1 ? bf_halo_pitch(k.TH, k.TW, k.S, k.EXT) : (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
   Op op;
   op.type = OP_BF16;
   op.name = prefix + (k.planes == 2 ? " [2xfp16 conv+bias" : " [3xbf16 conv+bias") + (relu ? "+relu]" : "]");
