@@ -96,7 +96,7 @@ __global__ __launch_bounds__(SB3_THREADS, 2) void stem_bf16_ws_kernel(const Stem
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
       const f32x4 f = __builtin_bit_cast(f32x4, v[k]);
-      const unsigned lo = stemb_pk_bf16(f.x, f.y), hi = stemb_pk_bf16(f.z, f.w);
+      const unsigned lo = pk_bf16(f.x, f.y), hi = pk_bf16(f.z, f.w);
       const bool in = sact & (srow + k * C::RPP < C::WROWS);
       unsigned char* pe = in ? win + pe0 + k * (C::RPP * SB2_PITCH * 4) : lds_raw + C3::OFF_SPARE;
       unsigned char* po = in ? win + pe0 + k * (C::RPP * SB2_PITCH * 4) + C::COPY1 : lds_raw + C3::OFF_SPARE + 8;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(SB3_THREADS, 2) void stem_bf16_ws_kernel(const Stem
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<uint2*>(row + 16 * ((nb * 4 + g) ^ tswz[mb])) =
-              make_uint2(stemb_pk_bf16(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1]), stemb_pk_bf16(acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]));
+              make_uint2(pk_bf16(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1]), pk_bf16(acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]));
     }
   };
 

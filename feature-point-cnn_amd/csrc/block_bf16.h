@@ -19,13 +19,18 @@ typedef unsigned short bf16_t;  // storage type
 
 __device__ __forceinline__ bf16_t f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+// two floats -> one dword of two bf16 (round to nearest even, low half = first) as ONE v_cvt_pk_bf16_f32.  Written as
+// f2bf(a) | f2bf(b) << 16 the compiler pairs the conversions ACROSS the two dwords of a store and spends four more
+// instructions per dword on putting the halves where they belong.  (A vector conversion, not inline asm: the compiler
+// must see a VALU instruction that reads MFMA results, or it leaves out the wait states between the two.)
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_));
+}
 __device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
-  uint4 r;
-  r.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
-  r.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
-  r.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
-  r.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
-  return r;
+  return make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
 }
 
 struct BlockBfArgs {
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
             v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
             if (CMIDP == C::N || n0 < CMIDP)
               *reinterpret_cast<uint2*>(hl + m * (ROWH16 * 16) + n0 * 2) =
-                  make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
+                  make_uint2(pk_bf16(v0, v1), pk_bf16(v2, v3));
           }
         }
     }
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
             const float v2 = fmaxf(acc[mb][nb][4 * g + 2] + bias.z, floor_), v3 = fmaxf(acc[mb][nb][4 * g + 3] + bias.w, floor_);
             if (CMIDP == C::N || n0 < CMIDP)
               *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(lds16) + m * (ROWH16 * 16) + n0 * 2) =
-                  make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
+                  make_uint2(pk_bf16(v0, v1), pk_bf16(v2, v3));
           }
       }
       FPC_LDS_BARRIER();
