@@ -283,6 +283,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + toff + ((st + 1) % K16) * 2]);
         }
+        // (the NEXT step's pixels are requested here, in front of this step's MFMAs: without the fence the scheduler
+        // sinks the reads to the end of the step -- shorter live ranges -- and every MFMA of the next step then waits
+        // out the LDS latency of a read issued two instructions earlier: the ISA showed ds_read, ds_read,
+        // s_waitcnt lgkmcnt(1), v_mfma all through the chunk loop)
+        __builtin_amdgcn_sched_barrier(0);
         if (st / K16 < 9) {
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const u32x4*>(&lds16[hbase[mb] + (k + 1) * 2]);
         }
+        __builtin_amdgcn_sched_barrier(0);   // (as in phase 1: the next step's reads in front of this step's MFMAs)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
