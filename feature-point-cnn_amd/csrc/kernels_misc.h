@@ -222,12 +222,22 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
   const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
 
-  const float4* wp = a.wfrag + lane;
-  float4 q0[2], q1[2];  // B fragments run two groups ahead
-  q0[0] = wp[0];
-  q0[1] = wp[64];
-  q1[0] = wp[128];
-  q1[1] = wp[192];
+  // B fragments run two groups ahead, through a buffer descriptor: the lane's offset in a VGPR that never changes, the
+  // group in the instruction's constant offset.  As wp[(g * 2 + nb) * 64] the loads past the 4 KB immediate range cost
+  // two 64-bit pointer additions each -- VALU instructions in the K loop, and on this GPU a VALU instruction between two
+  // fp32 MFMAs holds the matrix core up (generation 3).
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wfrag), 0, (KG + 2) * 2 * 64 * 16, 0x00020000);
+  const int wlane = lane * 16;
+  auto wfrag = [&](int i) {   // fragment i = group * 2 + nb
+    const f32x4w r = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, i * 1024, 0));
+    return make_float4(r.x, r.y, r.z, r.w);
+  };
+  float4 q0[2], q1[2];
+  q0[0] = wfrag(0);
+  q0[1] = wfrag(1);
+  q1[0] = wfrag(2);
+  q1[1] = wfrag(3);
 
   {  // input window -> LDS as aligned float4 row segments: LDS column 0 is image column ix0 - 1 (= 32 tx - 4, a multiple
      // of 4, and W is a multiple of 8, so every float4 lies entirely inside or entirely outside the frame); 40 columns
@@ -275,8 +285,8 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
     float4 q2[2];
-    q2[0] = wp[((g + 2) * 2 + 0) * 64];
-    q2[1] = wp[((g + 2) * 2 + 1) * 64];
+    q2[0] = wfrag((g + 2) * 2 + 0);
+    q2[1] = wfrag((g + 2) * 2 + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
