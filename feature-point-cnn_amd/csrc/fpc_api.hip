@@ -967,7 +967,8 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
     add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
     add_fconvT(c, FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
     add_fblock(c, {"descriptor.layer_out.0", FK_F816_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_out.1", FK_F816_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 1, 128, false, true}, bo);
+    // (the descriptor map is bf16 as well -- round 3: descriptor16_kernel<8, true> reads it, fpc_forward / the tap convert it)
+    add_fblock(c, {"descriptor.layer_out.1", FK_F816_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 0, 128, false, true}, bo);
   }
 }
 
@@ -2356,6 +2357,11 @@ static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
     hipLaunchKernelGGL(descriptor16_kernel<16>, dim3(G), dim3(256), 0, sb.st,
                        dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 256, 256, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
                        c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 256, sb.n, by_xcd);
+  else if (c->bf16 && dmap_nhwc == c->desc_map)   // FPC_BF16's own map is bf16: half the elements' bytes per frame
+    hipLaunchKernelGGL((descriptor16_kernel<8, true>), dim3(G), dim3(256), 0, sb.st,
+                       reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(dmap_nhwc) + (size_t)sb.f0 * c->Hc * c->Wc * 128),
+                       128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
+                       c->xy + (size_t)sb.f0 * c->cap * 2, c->cap, c->desc_out + (size_t)sb.f0 * c->cap * 128, sb.n, by_xcd);
   else
     hipLaunchKernelGGL(descriptor16_kernel<8>, dim3(G), dim3(256), 0, sb.st,
                        dmap_nhwc + (size_t)sb.f0 * c->Hc * c->Wc * 128, 128, c->Hc, c->Wc, c->H, c->W, c->count + sb.f0,
@@ -2904,7 +2910,10 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
   }
   if (desc) {
     const size_t tot = (size_t)n * c->D * HWc;
-    if (de)
+    if (de && c->bf16)
+      hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                         reinterpret_cast<const unsigned short*>(c->desc_map), c->D, c->D, HWc, n, desc);
+    else if (de)
       hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
                          c->desc_map, c->D, c->D, HWc, n, desc);
     else  // superpoint.py:106-109: zeros when the descriptor head is disabled
@@ -2919,7 +2928,7 @@ int fpc_read_activation(fpc_ctx* c, const char* name, int frame0, int n, float* 
   if (!c || !name || frame0 < 0 || n < 0 || frame0 + n > c->B) return FPC_E_INVALID;
   if (c->vgg) return FPC_E_INVALID;   // the C++ network's layers are read through fpc_forward only
   const int H4 = c->H / 4, W4 = c->W / 4, Hc = c->Hc, Wc = c->Wc, H16 = c->H / 16, W16 = c->W / 16;
-  const bool lowp = c->bf16;          // bf16 tensors (all but the logits and the descriptor map)
+  const bool lowp = c->bf16;          // bf16 tensors (all but the logits)
   struct Tap { const char* name; const void* p; int cs, C, H, W; bool bf; int off; };
   const Tap taps[] = {
       {"pool", c->x0, 64, 64, H4, W4, lowp, 0},
@@ -2933,7 +2942,7 @@ int fpc_read_activation(fpc_ctx* c, const char* name, int frame0, int n, float* 
       {"desc_in.1", c->y16b, 256, 256, H16, W16, lowp, 0},
       {"up", c->cat, 256, 128, Hc, Wc, lowp, 0},
       {"desc_out.0", c->lo0, 128, 128, Hc, Wc, lowp, 0},
-      {"desc_out.1", c->desc_map, 128, 128, Hc, Wc, false, 0},
+      {"desc_out.1", c->desc_map, 128, 128, Hc, Wc, lowp, 0},
   };
   for (const Tap& t : taps) {
     if (strcmp(t.name, name)) continue;

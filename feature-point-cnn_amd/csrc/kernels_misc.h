@@ -1135,11 +1135,15 @@ __device__ __forceinline__ void descriptor_sample(const float* base, int cs, int
 // instructions per keypoint (one wave per keypoint, descriptor_sample above, spends them on 8-byte loads and a 6-step
 // cross-lane sum for one norm) and four keypoints' requests in flight per wave.  Same per-channel sums in the same order; the sum of
 // squares is taken over a lane's channels first, then a 4-step butterfly inside the sixteen lanes.
-template <int CPL>
+// BF16MAP (FPC_BF16, round 3): the descriptor map is bf16 -- the kernel runs at the fabric's rate for its bytes (1.7 GB
+// in 0.34 ms per 64 HD frames with an fp32 map), and the map is half of them; a lane's eight channels are ONE 16-byte
+// load per corner.  The arithmetic on the converted values is the same.
+template <int CPL, bool BF16MAP = false>
 __global__ __launch_bounds__(256) void descriptor16_kernel(const float* dmap, int cs, int Hc, int Wc, int H, int W,
                                                            const int32_t* count, const int32_t* xy, int cap,
                                                            float* out, int nframes, int by_xcd) {
 #pragma clang fp contract(off)   // products and sums rounded separately, as grid_sample's C++ and the oracle do
+  static_assert(!BF16MAP || CPL == 8, "a lane's channels of a bf16 map are one 16-byte load");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, sub = lane >> 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int b0 = by_xcd ? xcd : 0, bstep = by_xcd ? 8 : 1;
@@ -1147,6 +1151,7 @@ __global__ __launch_bounds__(256) void descriptor16_kernel(const float* dmap, in
   for (int b = b0; b < nframes; b += bstep) {
     const int K = min(count[b], cap);
     const float* base = dmap + (size_t)b * Hc * Wc * cs + CPL * q;
+    const unsigned short* base16 = reinterpret_cast<const unsigned short*>(dmap) + (size_t)b * Hc * Wc * cs + CPL * q;
     for (int kw = k0; kw < K; kw += kstep) {
       const bool live = kw + sub < K;
       const int k = live ? kw + sub : K - 1;
@@ -1167,9 +1172,15 @@ __global__ __launch_bounds__(256) void descriptor16_kernel(const float* dmap, in
 #pragma unroll
       for (int c = 0; c < 4; ++c) {   // a corner outside the map: a clamped position with weight 0
         const int yc = min(max(cy[c], 0), Hc - 1), xc = min(max(cx[c], 0), Wc - 1);
-        const float4* qp = reinterpret_cast<const float4*>(base + (size_t)(yc * Wc + xc) * cs);
+        if constexpr (BF16MAP) {
+          const uint4 u = *reinterpret_cast<const uint4*>(base16 + (size_t)(yc * Wc + xc) * cs);
+          t[c][0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+          t[c][1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+        } else {
+          const float4* qp = reinterpret_cast<const float4*>(base + (size_t)(yc * Wc + xc) * cs);
 #pragma unroll
-        for (int i = 0; i < CPL / 4; ++i) t[c][i] = qp[i];
+          for (int i = 0; i < CPL / 4; ++i) t[c][i] = qp[i];
+        }
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c)

@@ -144,7 +144,9 @@ _BF16_BLOCKS = {  # name -> (checkpoint prefix, stride, projection shortcut, fp3
     "layer2.0": ("encoder.layer2.0", 2, True, False), "layer2.1": ("encoder.layer2.1", 1, False, False),
     "det.0": ("detector.layer.0", 1, True, False), "det.1": ("detector.layer.1", 1, False, True),
     "desc_in.0": ("descriptor.layer_in.0", 2, True, False), "desc_in.1": ("descriptor.layer_in.1", 1, False, False),
-    "desc_out.0": ("descriptor.layer_out.0", 1, True, False), "desc_out.1": ("descriptor.layer_out.1", 1, False, True)}
+    "desc_out.0": ("descriptor.layer_out.0", 1, True, False),
+    # (round 3: the mode stores the descriptor map as bf16 too -- descriptor sampling reads half the bytes; the logits stay fp32)
+    "desc_out.1": ("descriptor.layer_out.1", 1, False, False)}
 
 
 def _relu(v):
