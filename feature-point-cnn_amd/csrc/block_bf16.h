@@ -453,11 +453,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
     if (fused) {
       if constexpr (WN == 1 && MB == 1 && NB == 3) {
         // exp-softmax over the 65 channels of a cell, dustbin dropped, depth-to-space, threshold (superpoint.py:111-114,
-        // netutils.py:56-75) -- softmax_d2s_kernel's arithmetic on the logits this epilogue would have stored, BIT FOR BIT:
-        // the same expf, the sum of a cell's 64 exps in the same tree (that kernel: lane q of sixteen holds channels
+        // netutils.py:56-75) -- softmax_d2s_kernel<true>'s arithmetic on the logits this epilogue would have stored, BIT FOR
+        // BIT: the same exponential (sm_exp<true>: kernels_misc.h), the sum of a cell's 64 exps in the same tree (that kernel: lane q of sixteen holds channels
         // 4 q ..+3, (e0 + e1) + (e2 + e3), then a butterfly over q ^ 8, 4, 2, 1; here q = 8 nb + 2 g + half, so the first
         // three levels are sums of this lane's own registers and the last one is the partner lane of the other half),
-        // the same (s + ed) + 1e-5 and division.  The 295 MB of fp32 logits per 64 HD frames are neither written nor
+        // the same (s + ed) + 1e-5 and reciprocal (sm_scale / sm_prob).  The 295 MB of fp32 logits per 64 HD frames are neither written nor
         // read back, and a launch disappears.
         __shared__ int s_cnt, s_base;
         unsigned short* s_list = reinterpret_cast<unsigned short*>(lds16);   // [TH * TW * 64] local ids (m << 6 | c)
@@ -476,20 +476,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const float4 bias = *reinterpret_cast<const float4*>(bl + nl + nb * 32 + 8 * g);
-            e[nb][4 * g + 0] = expf(fmaxf(acc[0][nb][4 * g + 0] + bias.x, floor_));
-            e[nb][4 * g + 1] = expf(fmaxf(acc[0][nb][4 * g + 1] + bias.y, floor_));
-            e[nb][4 * g + 2] = expf(fmaxf(acc[0][nb][4 * g + 2] + bias.z, floor_));
-            e[nb][4 * g + 3] = expf(fmaxf(acc[0][nb][4 * g + 3] + bias.w, floor_));
+            e[nb][4 * g + 0] = sm_exp<true>(fmaxf(acc[0][nb][4 * g + 0] + bias.x, floor_));
+            e[nb][4 * g + 1] = sm_exp<true>(fmaxf(acc[0][nb][4 * g + 1] + bias.y, floor_));
+            e[nb][4 * g + 2] = sm_exp<true>(fmaxf(acc[0][nb][4 * g + 2] + bias.z, floor_));
+            e[nb][4 * g + 3] = sm_exp<true>(fmaxf(acc[0][nb][4 * g + 3] + bias.w, floor_));
             P[nb][g] = (e[nb][4 * g] + e[nb][4 * g + 1]) + (e[nb][4 * g + 2] + e[nb][4 * g + 3]);
           }
-        float ed = expf(fmaxf(acc[0][2][0] + bl[64], floor_));   // the dustbin: channel 64 = block 2, register 0 of the half-0 lanes
+        float ed = sm_exp<true>(fmaxf(acc[0][2][0] + bl[64], floor_));   // the dustbin: channel 64 = block 2, register 0 of the half-0 lanes
         ed = __shfl(ed, l31);
         const float a0 = P[0][0] + P[1][0], a1 = P[0][1] + P[1][1], a2 = P[0][2] + P[1][2], a3 = P[0][3] + P[1][3];
         const float b0_ = a0 + a2, b1_ = a1 + a3;
         float ssum = b0_ + b1_;
         ssum += __shfl_xor(ssum, 32);
-        const float den = (ssum + ed) + .00001f;
+        const float den = sm_scale<true>((ssum + ed) + .00001f);
         const unsigned mapbase = (unsigned)(((b - a.frame0) * a.Ho * 8 + 8 * y) * W8 + 8 * x + 4 * half);
+        unsigned cmask = 0;   // this lane's candidates among its 32 probabilities: bit 16 nb + 4 g + j
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -498,21 +499,38 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
             unsigned* wp_ = reinterpret_cast<unsigned*>(&wv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float p = e[nb][4 * g + j] / den;
+              const float p = sm_prob<true>(e[nb][4 * g + j], den);
               const bool c = live & (p >= a.thresh);
               wp_[j] = c ? nms_state_word(p) : 0u;
-              const unsigned long long mask = __ballot(c);
-              if (mask) {
-                const int lead = __ffsll((long long)mask) - 1;
-                int off = 0;
-                if (lane == lead) off = atomicAdd(&s_cnt, __popcll(mask));
-                off = __shfl(off, lead);
-                if (c) s_list[off + __popcll(mask & ((1ull << lane) - 1))] = (unsigned short)((m << 6) | (nb * 32 + 8 * g + 4 * half + j));
-              }
+              cmask |= c ? 1u << (16 * nb + 4 * g + j) : 0u;
             }
             const unsigned off = (mapbase + (unsigned)((4 * nb + g) * W8)) * 4u;
             __builtin_amdgcn_raw_buffer_store_b128(wv, mrsrc, (int)(live ? off : 0xfffffff0u), 0, 0);
           }
+        // The tile's candidates -> s_list: ONE LDS atomic per wave (round 3).  Round 2 compacted every one of the 32
+        // probabilities of a lane on its own -- ballot, and wherever a wave had a candidate (four times in five at
+        // real densities) an LDS atomic whose result the wave waits for: 32 serial LDS round trips per wave and tile.
+        // Now: a lane counts its own, an inclusive scan over the wave, one atomicAdd of the wave's total.  (The list's
+        // order inside a tile changes; nothing depends on it.)
+        {
+          const int cnt = __popc(cmask);
+          int pre = cnt;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(pre, d);
+            pre += lane >= d ? t : 0;
+          }
+          const int total = __shfl(pre, 63);
+          if (total) {   // (wave-uniform)
+            int off = 0;
+            if (lane == 63) off = atomicAdd(&s_cnt, total);
+            off = __shfl(off, 63) + pre - cnt;
+            for (unsigned mk = cmask; mk; mk &= mk - 1) {
+              const int i = __ffs((int)mk) - 1;
+              s_list[off++] = (unsigned short)((m << 6) | ((i >> 4) * 32 + ((i >> 2) & 3) * 8 + 4 * half + (i & 3)));
+            }
+          }
+        }
         FPC_LDS_BARRIER();
         const int ncl = s_cnt;
         if (tid == 0 && ncl) s_base = atomicAdd(&a.ncand[b - a.frame0], ncl);   // ONE global atomic per tile

@@ -2302,7 +2302,9 @@ static void run_softmax(fpc_ctx* c, const Sub& sb, bool dense_map = true) {
   const size_t HW = (size_t)c->H * c->W;
   hipMemsetAsync(c->ncand + sb.f0, 0, sizeof(int32_t) * sb.n, sb.st);
   LaunchTimer t(c, op_index(c, OP_SOFTMAX), sb.st, sb.n);
-  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(sb.n * c->Hc), dim3(256), (size_t)12 * c->W * sizeof(float), sb.st,
+  // (FPC_BF16: the arithmetic of that mode's fused epilogue -- v_exp_f32, one reciprocal per cell; nms_word.h)
+  const auto kern = c->bf16 ? softmax_d2s_kernel<true> : softmax_d2s_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3(sb.n * c->Hc), dim3(256), (size_t)12 * c->W * sizeof(float), sb.st,
                      c->lg + (size_t)sb.f0 * c->Hc * c->Wc * c->lgcs, c->lgcs, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
                      dense_map ? c->prob + sb.f0 * HW : nullptr, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
 }
@@ -2645,7 +2647,9 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     fprintf(stderr, "[diag] %s: lds %d B, regs %d, scratch %zu, occupancy %d blocks/CU\n", g_fkinds[k].name, g_fkinds[k].lds_bytes, fa.numRegs, fa.localSizeBytes, nb);
 #endif
   }
-  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               12 * cfg->width * (int)sizeof(float)));
+  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                12 * cfg->width * (int)sizeof(float)));
   HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<1>::LDS_BYTES));
   HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<3>::LDS_BYTES));

@@ -364,6 +364,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* 
 // ---------------------------------------------------------------------------------
 // (nms_state_word / nms_state_conf: nms_word.h)
 
+// (sm_exp / sm_scale / sm_prob, the arithmetic of FAST = true: nms_word.h)
+template <bool FAST = false>
 __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
                                                           float thresh, float* prob, uint32_t* nmsmap,
                                                           uint32_t* cand, int32_t* ncand) {
@@ -395,14 +397,15 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = j0 + 4 * u + gidx;
-      const float e0 = expf(lv[u].x), e1 = expf(lv[u].y), e2 = expf(lv[u].z), e3 = expf(lv[u].w);
-      const float ed = expf(ld[u]);
+      const float e0 = sm_exp<FAST>(lv[u].x), e1 = sm_exp<FAST>(lv[u].y), e2 = sm_exp<FAST>(lv[u].z), e3 = sm_exp<FAST>(lv[u].w);
+      const float ed = sm_exp<FAST>(ld[u]);
       float s = (e0 + e1) + (e2 + e3);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      const float den = (s + ed) + .00001f;
+      const float den = sm_scale<FAST>((s + ed) + .00001f);
       if (j < Wc)
-        *reinterpret_cast<float4*>(strip + (q >> 1) * W + j * 8 + 4 * (q & 1)) = make_float4(e0 / den, e1 / den, e2 / den, e3 / den);
+        *reinterpret_cast<float4*>(strip + (q >> 1) * W + j * 8 + 4 * (q & 1)) =
+            make_float4(sm_prob<FAST>(e0, den), sm_prob<FAST>(e1, den), sm_prob<FAST>(e2, den), sm_prob<FAST>(e3, den));
     }
   }
   __syncthreads();
