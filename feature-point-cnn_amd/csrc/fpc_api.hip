@@ -254,7 +254,7 @@ static WKind w36_kind(int cout, int H, int W) {
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
 #define FPC_BF16_KINDS(X)                                                                   \
   X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
-  X(F620_s2_K16_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)   \
+  X(F620_s2_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)   \
   X(F816_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 1, 4, 4, 1, 128)   \
   X(F816_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 4, 1, 1, 3, 80)     \
   X(F816_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 80, 4, 1, 1, 3, 80)     \
@@ -947,7 +947,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   // pull 64 B/clk of weight fragments from L2 and 64 B/clk of pixels from LDS for a 2 x 2 register blocking.)
   add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
-  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K16_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
+  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K32_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
   add_fblock(c, {"encoder.layer2.1", FK_F816_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
   // detector.layer.0 on the 2 x 2 blocking of the 128-wide layers (N = 128 for 65 channels: a quarter of the MFMAs on
   // zeros, but four MFMAs per four operand fetches instead of three per four: 0.47 -> 0.40 ms per 64 HD frames);
