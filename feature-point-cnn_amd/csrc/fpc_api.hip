@@ -259,7 +259,7 @@ static WKind w36_kind(int cout, int H, int W) {
   X(F816_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 4, 1, 1, 3, 80)     \
   X(F816_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 80, 4, 1, 1, 3, 80)     \
   X(F816_s1_K64_C80w, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 1, 4, 4, 1, 80)   \
-  X(F320_s2_K32_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 32, 1, 4, 2, 2, 256)   \
+  X(F320_s2_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 64, 1, 4, 2, 2, 256)   \
   X(F416_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 4, 16, 1, 3, 64, 1, 4, 2, 2, 256)   \
   X(F816_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 2, 64, 1, 4, 4, 1, 128)   \
   X(S816_s1_K64_C64, block_x3_kernel, BlockX3Cfg, 3, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)       \
@@ -963,7 +963,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
     c->convw.push_back({});
   }
   if (de) {
-    add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K32_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K64_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
     add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
     add_fconvT(c, FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
     add_fblock(c, {"descriptor.layer_out.0", FK_F816_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
