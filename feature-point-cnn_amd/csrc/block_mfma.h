@@ -100,7 +100,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
     abase[mb] = ((py * S) * HW + px * S) * ROW4 + half;
   }
   constexpr int stepstride = NBT * 64;
-  const float4* wp = a.w1 + (size_t)(wn * NB) * 64 + lane;
+  // conv1's fragments through a buffer descriptor (round 3): the lane's offset in a VGPR that never changes, the step
+  // in the SCALAR offset.  As wp[nb * 64], wp += stepstride every step was a 64-bit pointer addition -- two VALU
+  // instructions between fp32 MFMAs, each of which holds the matrix core up (generation 3).
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float4*>(a.w1), 0, (int)((unsigned)(a.nchunk * 9 * K8 + 2) * (unsigned)(stepstride * 16)), 0x00020000);
+  const int wlane = ((wn * NB) * 64 + lane) * 16;
+  int wstep = 0;   // (scalar) byte offset of the next step to request
+  auto wfrag = [&](int nb) {
+    typedef float f32x4w __attribute__((ext_vector_type(4)));
+    const f32x4w r = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + nb * 1024, wstep, 0));
+    return make_float4(r.x, r.y, r.z, r.w);
+  };
 
   const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
   // The halo chunk through a buffer descriptor: a position outside the frame (or a chunk past the last one) gets an
@@ -151,11 +162,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   load_chunk(0);
   float4 b0[NB], b1[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) b0[nb] = wp[nb * 64];
-  wp += stepstride;
+  for (int nb = 0; nb < NB; ++nb) b0[nb] = wfrag(nb);
+  wstep += stepstride * 16;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
-  wp += stepstride;
+  for (int nb = 0; nb < NB; ++nb) b1[nb] = wfrag(nb);
+  wstep += stepstride * 16;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     FPC_LDS_BARRIER();
     store_chunk();
@@ -175,8 +186,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
       for (int k8 = 0; k8 < K8; ++k8) {
         float4 b2[NB], an[MB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b2[nb] = wp[nb * 64];
-        wp += stepstride;
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = wfrag(nb);
+        wstep += stepstride * 16;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
           an[mb] = lds4[abase[mb] + (k8 + 1 < K8 ? toff + (k8 + 1) * 2 : toffn)];  // last step of a chunk: unused
