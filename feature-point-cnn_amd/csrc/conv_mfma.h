@@ -118,7 +118,22 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArg
     abase[mb] = ((py * S) * HW + px * S) * ROW4 + half;
   }
   const int stepstride = a.nbt * 64;
+  // the fragments through a buffer descriptor (round 3; as block_mfma.h: no 64-bit pointer arithmetic between fp32 MFMAs)
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float4*>(sp.wfrag), 0, (int)((unsigned)((a.nchunk0 * sp.ntaps + a.nchunk1) * K8 + 2) * (unsigned)(stepstride * 16)), 0x00020000);
+  const int wlane = (((blockIdx.y * WN + wn) * NB) * 64 + lane) * 16;
+  int wstep = 0;   // (scalar) byte offset of the next step to request
+  // (EXT == 1, the 1x1 instances -- few steps per chunk -- measured 12 % SLOWER with it and keep the pointer)
   const float4* wp = sp.wfrag + (size_t)((blockIdx.y * WN + wn) * NB) * 64 + lane;
+  auto wfrag = [&](int nb) {
+    if constexpr (EXT == 1) {
+      return wp[(wstep >> 4) + nb * 64];
+    } else {
+      typedef float f32x4w __attribute__((ext_vector_type(4)));
+      const f32x4w r = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + nb * 1024, wstep, 0));
+      return make_float4(r.x, r.y, r.z, r.w);
+    }
+  };
 
   const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
   float4 stage[ITER];
@@ -174,11 +189,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArg
   // padded by two steps so the tail prefetch stays in bounds).
   float4 b0[NB], b1[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) b0[nb] = wp[nb * 64];
-  wp += stepstride;
+  for (int nb = 0; nb < NB; ++nb) b0[nb] = wfrag(nb);
+  wstep += stepstride * 16;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) b1[nb] = wp[nb * 64];
-  wp += stepstride;
+  for (int nb = 0; nb < NB; ++nb) b1[nb] = wfrag(nb);
+  wstep += stepstride * 16;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk) __syncthreads();
@@ -191,8 +206,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArg
       for (int k8 = 0; k8 < K8; ++k8) {
         float4 b2[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b2[nb] = wp[nb * 64];
-        wp += stepstride;
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = wfrag(nb);
+        wstep += stepstride * 16;
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue up here
         float4 av[MB];
 #pragma unroll
