@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "../../feature-point-cnn_amd/csrc/block_mfma.h"
 #include "../../feature-point-cnn_amd/csrc/block_bf16.h"
 #include "../../feature-point-cnn_amd/csrc/block_x3.h"
@@ -69,6 +70,25 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     hipEventElapsedTime(&ms, e0, e1); if (ms < best2) best2 = ms;
   }
+#ifdef FPC_DIAG
+  {   // phase times of every workgroup's tenth tile (wave 0's s_memtime stamps), two workgroups per CU at work
+    unsigned long long* st;
+    CK(hipMalloc(&st, (size_t)G * 8 * 8)); CK(hipMemset(st, 0, (size_t)G * 8 * 8));
+    StemX3Args as = a1; as.stamps = st;
+    hipLaunchKernelGGL((stem_bf16_kernel<CIN, STEM_ABL>), dim3(G), dim3(SB2_THREADS), StemB2Cfg<CIN>::LDS_BYTES, 0, as);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hs((size_t)G * 8);
+    CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[6] = {"wait for the window + convert + stage", "barrier", "request + acc init + K loop", "tile write", "barrier", "pool + store"};
+    for (int ph = 0; ph < 6; ++ph) {
+      std::vector<double> d;
+      for (int g = 0; g < G; ++g) if (hs[(size_t)g * 8] && hs[(size_t)g * 8 + 6]) d.push_back((double)(hs[(size_t)g * 8 + ph + 1] - hs[(size_t)g * 8 + ph]));
+      if (d.empty()) continue;
+      std::sort(d.begin(), d.end());
+      printf("  %-40s median %7.0f  p90 %7.0f cycles (%zu workgroups)\n", names[ph], d[d.size() / 2], d[d.size() * 9 / 10], d.size());
+    }
+  }
+#endif
   printf("B=%d %dx%d cin=%d G=%d/%d: round 2 %.3f ms (%d tiles)  stem_bf16 %.3f ms  stem_bf16_ws %.3f ms (%d tiles, abl %d)\n", B, H, W, CIN, G, G3, best0,
          a0.tiles_x * a0.tiles_y * B, best1, best2, a1.tiles_x * a1.tiles_y * B, STEM_ABL);
   if (STEM_ABL == 0) {

@@ -82,6 +82,19 @@ __device__ __forceinline__ int sb2_slot(int r, int q) { return r * 16 + ((q >> 3
 // byte offset of channel group cg (8 channels) of pixel (r, q)
 __device__ __forceinline__ int sb2_tile_addr(int r, int q, int cg) { return sb2_slot(r, q) * SB2_PIX + 16 * (cg ^ sb2_swz(r, q)); }
 
+// (diagnostic build only: wave 0 of every workgroup records the shader clock at the phase boundaries of its TENTH tile --
+// a tile in the steady state, both workgroups of the CU at work -- experiments/harness/stem_bf16_bench.hip -DFPC_DIAG)
+#ifdef FPC_DIAG
+#define SB2_STAMP(i)                                                                     \
+  if (a.stamps && threadIdx.x == 0 && ntile == 10) {                                     \
+    unsigned long long t_;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    a.stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                         \
+  }
+#else
+#define SB2_STAMP(i)
+#endif
+
 template <int CIN, unsigned ABL = 0>
 __global__ __launch_bounds__(SB2_THREADS, 2) void stem_bf16_kernel(const StemX3Args a) {
   using C = StemB2Cfg<CIN>;
@@ -173,9 +186,11 @@ __global__ __launch_bounds__(SB2_THREADS, 2) void stem_bf16_kernel(const StemX3A
   // pooling role of this thread: pooled row pj, channels 8 pc .. 8 pc + 7, pooled columns 2 pg and 2 pg + 1
   const int pc = tid & 7, pg = (tid >> 3) & 3, pj = tid >> 5;
 
-  for (; tcur < t_end; tcur += per) {
+  int ntile = 0;
+  for (; tcur < t_end; tcur += per, ++ntile) {
     const int b = tcur / tiles, t = tcur - b * tiles;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    SB2_STAMP(0)
     // (every wave is past the previous tile's K loop -- the barrier in front of its pooling -- so the window is free)
     {
       // (no branch anywhere in the tile loop: behind one the compiler waits for EVERY outstanding request, the
@@ -193,7 +208,9 @@ __global__ __launch_bounds__(SB2_THREADS, 2) void stem_bf16_kernel(const StemX3A
         o[1] = hi;
       }
     }
+    SB2_STAMP(1)
     __syncthreads();   // window complete; the previous tile's pooling reads of the tile region are done as well
+    SB2_STAMP(2)
     if constexpr (!(ABL & STEMB_ABL_LOAD)) request(tcur + per);  // lands behind the K loop and the epilogue
 
     // accumulators start at the bias; a pixel of the 17 x 15 outside the convolution's output starts (and stays) hugely
@@ -234,6 +251,7 @@ __global__ __launch_bounds__(SB2_THREADS, 2) void stem_bf16_kernel(const StemX3A
         for (int nb = 0; nb < 2; ++nb) mfma_split<1>(acc[mb][nb], &wreg[s][nb], &av[mb]);   // weights as A: the tile comes out transposed
     }
 
+    SB2_STAMP(3)
     // the tile -> LDS as bf16: [slot][64 channels], 8 bytes per write (a lane holds one pixel, four groups of four channels per block)
 #pragma unroll
     for (int mb = 0; mb < ((ABL & STEMB_ABL_TILE) ? 0 : 2); ++mb) {
@@ -245,7 +263,9 @@ __global__ __launch_bounds__(SB2_THREADS, 2) void stem_bf16_kernel(const StemX3A
           *reinterpret_cast<uint2*>(row + 16 * ((nb * 4 + g) ^ tswz[mb])) =
               make_uint2(pk_bf16(acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1]), pk_bf16(acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]));
     }
+    SB2_STAMP(4)
     __syncthreads();   // tile complete (and every wave has finished reading the window)
+    SB2_STAMP(5)
     // 3x3/2 max-pool + ReLU on packed bf16 pairs as signed 16-bit integers (stem_pool_bf16_kernel's argument)
     const int gpy = ty * SB2_PH + pj;
     if constexpr (!(ABL & STEMB_ABL_POOL)) {
@@ -278,6 +298,7 @@ __global__ __launch_bounds__(SB2_THREADS, 2) void stem_bf16_kernel(const StemX3A
         __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)(on ? ooff + px * 128 : 0xfffffff0u), 0, 0);   // a dead pixel's store: dropped by the bounds check
       }
     }
+    SB2_STAMP(6)
   }
 }
 
