@@ -139,12 +139,25 @@ def truncated_normal(n, mean=0.0, stddev=1.0, rng=None):
     return truncnorm(mean - 2 * stddev, mean + 2 * stddev).rvs(n, random_state=rng).astype(np.float32)
 
 
-def sample_homography(shape, config=None, rng=None):
-    """sample_homography (python/src/homographies.py:78-182) step by step: a centred patch is perturbed
+def sample_homography(shape, config=None, rng=None, reference_aliasing=True):
+    """sample_homography (python/src/homographies.py:78-192) step by step: a centred patch is perturbed
     (perspective, scale, translation, rotation), each step keeping the corners inside the unit square unless
-    allow_artifacts, and the 8 coefficients mapping output points to input points are solved for.  Random numbers come
-    from `rng` (numpy Generator) instead of torch's / scipy's global state, so a run is reproducible from a seed but
-    not bit-identical to the reference's stream.  shape = (H, W).  -> float32 [8]."""
+    allow_artifacts, and the 8 coefficients mapping output points to input points are solved for.
+
+    REPRODUCED QUIRK (round 4; the review measured it on the reference's own function): `pts2 = pts1` (:117) is an
+    ALIAS, and the perspective step (:127) and the translation step (:155) perturb it IN PLACE, while the scaling
+    (:142) and rotation (:174) steps rebind `pts2` to a new tensor.  So the output corners `pts1` receive the
+    perspective displacement too (and the translation, when scaling is off), and the transform solved from
+    pts1 -> pts2 is a SIMILARITY (scale, rotation, translation): h7 = h8 = 0 up to rounding for every configuration
+    -- no perspective term is ever drawn, whatever `perspective_amplitude_*` says.  The same aliasing makes `:179-180`
+    multiply the shared corners by the frame size twice when neither scaling nor rotation rebinds pts2 (the solve is
+    then the identity).  numpy's in-place operators and basic-index views alias exactly like torch's here, so the
+    statements below are written with the reference's own mix of `+=` and rebinding.  `reference_aliasing=False` gives
+    the sampler the docstring of the reference describes (pts1 stays the centred patch: real perspective terms).
+
+    Random numbers come from `rng` (numpy Generator) instead of torch's / scipy's global state, so a run is reproducible
+    from a seed but not bit-identical to the reference's stream (fixture F10 holds the reference's draws; the CPU test
+    compares distributions).  shape = (H, W).  -> float32 [8]."""
     cfg = config or HomographyConfig()
     rng = rng or np.random.default_rng()
 
@@ -153,19 +166,19 @@ def sample_homography(shape, config=None, rng=None):
 
     margin = (1 - cfg.patch_ratio) / 2
     pts1 = margin + np.array([[0, 0], [0, cfg.patch_ratio], [cfg.patch_ratio, cfg.patch_ratio], [cfg.patch_ratio, 0]], np.float32)
-    pts2 = pts1.copy()
+    pts2 = pts1 if reference_aliasing else pts1.copy()          # :117 `pts2 = pts1`
     if cfg.perspective:
         ax_, ay_ = cfg.perspective_amplitude_x, cfg.perspective_amplitude_y
         if not cfg.allow_artifacts:
             ax_, ay_ = min(ax_, margin), min(ay_, margin)
         pd, hl, hr = tn(1, 0., ay_ / 2)[0], tn(1, 0., ax_ / 2)[0], tn(1, 0., ax_ / 2)[0]
-        pts2 += np.array([[hl, pd], [hl, -pd], [hr, pd], [hr, -pd]], np.float32)
+        pts2 += np.array([[hl, pd], [hl, -pd], [hr, pd], [hr, -pd]], np.float32)      # :127 in place: pts1 moves too
     if cfg.scaling:
         scales = np.concatenate([[1.], tn(cfg.n_scales, 1, cfg.scaling_amplitude / 2)]).astype(np.float32)
         center = pts2.mean(0, keepdims=True)
         scaled = (pts2 - center)[None] * scales[:, None, None] + center
         valid = np.arange(cfg.n_scales) if cfg.allow_artifacts else np.nonzero(((scaled >= 0.) & (scaled < 1.)).sum((1, 2)))[0]
-        pts2 = scaled[valid[rng.integers(len(valid))]]
+        pts2 = scaled[valid[rng.integers(len(valid))]]          # :142 rebinds: from here on pts2 is its own array
     if cfg.translation:
         t_min, t_max = pts2.min(0), (1. - pts2).min(0)
         if cfg.allow_artifacts:
@@ -174,21 +187,23 @@ def sample_homography(shape, config=None, rng=None):
         def uni(lo, hi):        # random_uniform :70-75
             lo, hi = (hi, lo) if lo > hi else (lo, hi)
             return rng.uniform(lo, hi if hi > lo else lo + 0.00001)
-        pts2 = pts2 + np.array([[uni(-t_min[0], t_max[0]), uni(-t_min[1], t_max[1])]], np.float32)
+        pts2 += np.array([[uni(-t_min[0], t_max[0]), uni(-t_min[1], t_max[1])]], np.float32)      # :155 in place
     if cfg.rotation:
         angles = np.concatenate([[0.], np.linspace(-cfg.max_angle, cfg.max_angle, cfg.n_angles)]).astype(np.float32)
         center = pts2.mean(0, keepdims=True)
         rot = np.stack([np.cos(angles), -np.sin(angles), np.sin(angles), np.cos(angles)], 1).reshape(-1, 2, 2)
         rotated = np.matmul(np.tile((pts2 - center)[None], (cfg.n_angles + 1, 1, 1)), rot) + center
         valid = np.arange(cfg.n_angles) if cfg.allow_artifacts else np.nonzero(((rotated >= 0.) & (rotated < 1.)).sum((1, 2)))[0]
-        pts2 = rotated[valid[rng.integers(len(valid))]]
+        pts2 = rotated[valid[rng.integers(len(valid))]]         # :174 rebinds
     size = np.array(shape[::-1], np.float32)[None]      # (W, H)
-    p1, p2 = pts1 * size, pts2 * size
+    pts1 *= size                                        # :179-180, in place as there (twice on a still-shared array)
+    pts2 *= size
+    p1, p2 = pts1, pts2
     a_mat = np.array([f(p1[i], p2[i]) for i in range(4) for f in (
         lambda p, q: [p[0], p[1], 1, 0, 0, 0, -p[0] * q[0], -p[1] * q[0]],
         lambda p, q: [0, 0, 0, p[0], p[1], 1, -p[0] * q[1], -p[1] * q[1]])], np.float64)
     p_mat = np.array([p2[i][j] for i in range(4) for j in range(2)], np.float64)
-    return np.linalg.solve(a_mat, p_mat).astype(np.float32)
+    return np.linalg.solve(a_mat, p_mat).astype(np.float32)     # (the reference solves in float32; float64 here)
 
 
 def get_points(prob_map, img_h, img_w, settings, engine=None):

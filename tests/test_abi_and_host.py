@@ -209,11 +209,67 @@ def test_public_header_is_plain_c(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
 
 
+def _affine_parameters(h):
+    """[n, 8] homographies -> [n, 6]: sqrt|det|, rotation angle, tx, ty, a - d, b + c of the 2 x 3 affine part, rounded so
+    that the rounding noise of the reference's float32 solve (atoms such as `scale == 1` are smeared by 1e-4 there)
+    does not read as a difference of distributions."""
+    a, b, tx, c, d, ty = (h[:, i].astype(np.float64) for i in range(6))
+    return np.stack([np.round(np.sqrt(np.abs(a * d - b * c)), 3), np.round(np.arctan2(c - b, a + d), 2), np.round(tx, 0),
+                     np.round(ty, 0), np.round(a - d, 3), np.round(b + c, 3)], 1)
+
+
+def test_sample_homography_draws_what_the_reference_draws():
+    """Fixture F10 = 1000 homographies per configuration drawn by the reference's OWN sample_homography
+    (python/src/homographies.py:78-192, run by tests/golden/make_golden_homography.py).  What they show, and what
+    fpc_amd.inference.sample_homography must therefore do:
+      * `pts2 = pts1` (:117) aliases and :127 perturbs in place -> the solved transform has NO perspective term:
+        |h7|, |h8| < 1e-5 in every one of the reference's draws, for the class defaults and for init_for_preprocess;
+      * the distribution of the affine part (scale, angle, translation, anisotropy) over 1000 draws: two-sample
+        Kolmogorov-Smirnov against the fixture, every parameter, three seeds (p > 1e-3 each);
+      * with scaling off, the translation moves pts1 too (still the alias): same check on that configuration;
+      * perspective alone: the identity (both corner sets are one array).
+    And the sampler WITHOUT the alias (round 3's, `reference_aliasing=False`) is rejected by the same test."""
+    from scipy import stats
+    from fpc_amd.inference import HomographyConfig, sample_homography
+    f = np.load(os.path.join(ROOT, "tests", "golden", "f10_sample_homography.npz"))
+    h, w = (int(v) for v in f["shape"])
+    for name in ("defaults", "preprocess", "no_scaling"):
+        ref = f[name]
+        assert np.abs(ref[:, 6:]).max() < 1e-5                  # the reference never draws a perspective term
+        cfg = HomographyConfig()
+        if name == "preprocess":
+            cfg.init_for_preprocess()                            # preprocess_coco.py:57-58
+        if name == "no_scaling":
+            cfg.scaling = False
+        pr = _affine_parameters(ref)
+        for seed in (5, 6, 7):
+            rng = np.random.default_rng(seed)
+            mine = np.stack([sample_homography((h, w), cfg, rng) for _ in range(1000)])
+            assert np.abs(mine[:, 6:]).max() < 1e-5, (name, seed)
+            pm = _affine_parameters(mine)
+            for k in range(6):
+                p = stats.ks_2samp(pm[:, k], pr[:, k]).pvalue
+                assert p > 1e-3, (name, seed, k, p)
+    # round 3's sampler (pts1 kept apart from pts2) draws real perspective terms and a different scale distribution
+    rng = np.random.default_rng(5)
+    old = np.stack([sample_homography((h, w), HomographyConfig(), rng, reference_aliasing=False) for _ in range(1000)])
+    assert np.abs(old[:, 6]).max() > 1e-3
+    assert stats.ks_2samp(_affine_parameters(old)[:, 0], _affine_parameters(f["defaults"])[:, 0]).pvalue < 1e-6
+    # perspective alone: identity (the reference's float32 solve leaves up to 0.1 px of noise in the translation)
+    cfg = HomographyConfig()
+    cfg.scaling = cfg.rotation = cfg.translation = False
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0], np.float32)
+    np.testing.assert_allclose(sample_homography((h, w), cfg, np.random.default_rng(1)), ident, atol=1e-6)
+    for r in f["perspective_only"]:
+        np.testing.assert_allclose(r[[0, 1, 3, 4, 6, 7]], ident[[0, 1, 3, 4, 6, 7]], atol=1e-5)
+        np.testing.assert_allclose(r[[2, 5]], 0, atol=0.2)
+
+
 def test_sample_homography_restatement():
     """sample_homography (python/src/homographies.py:78-182) restated: invertible matrices, reproducible from a seed,
-    the perspective row independent of the affine steps (c7 = 0 for the reference's symmetric perturbation), and the
-    centre of the patch staying in the frame.  (The reference keeps a scale / angle if ANY corner coordinate is inside
-    the unit square -- `nonzero(sum(...))`, :133, :164 -- so single corners may leave the frame; restated as is.)"""
+    no perspective row (the reference's aliasing, see the test above), and the centre of the patch staying near the
+    frame.  (The reference keeps a scale / angle if ANY corner coordinate is inside the unit square --
+    `nonzero(sum(...))`, :133, :164 -- so single corners may leave the frame; restated as is.)"""
     from fpc_amd.inference import HomographyConfig, sample_homography
     cfg = HomographyConfig()
     h, w = 240, 320
@@ -223,12 +279,15 @@ def test_sample_homography_restatement():
     for _ in range(50):
         k = sample_homography((h, w), cfg, rng).astype(np.float64)
         m = np.append(k, 1.0).reshape(3, 3)
-        assert abs(np.linalg.det(m)) > 1e-6 and abs(k[7]) < 1e-6
+        assert abs(np.linalg.det(m)) > 1e-6 and abs(k[6]) < 1e-6 and abs(k[7]) < 1e-6
         c = m @ np.array([w / 2, h / 2, 1.0])
         c = c[:2] / c[2]
         assert -0.25 * w <= c[0] <= 1.25 * w and -0.25 * h <= c[1] <= 1.25 * h
     cfg.init_for_preprocess()          # preprocess_coco.py:57-58
     assert sample_homography((h, w), cfg, rng).shape == (8,)
+    # the sampler the reference's docstring describes stays available
+    k = sample_homography((h, w), HomographyConfig(), np.random.default_rng(3), reference_aliasing=False)
+    assert k.shape == (8,) and np.isfinite(k).all()
 
 
 def test_truncated_normal_draws_what_the_reference_draws():
