@@ -27,16 +27,18 @@ SYMBOLS = [
     "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
     "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation", "fpc_detect_u8_resized",
     "fpc_sample_descriptors", "fpc_plan_hash", "fpc_broadcast_weights", "fpc_read_activation",
+    "fpc_pack_layout_revision", "fpc_check_guards",
 ]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+PACK_LAYOUT_REVISION = 3      # include/fpc.h FPC_PACK_LAYOUT_REVISION
 
 # fpc_config.plan_flags (include/fpc.h, FPC_PLAN_*)
 PLAN_FLAGS = {
     "no_fused_blocks": 1 << 0, "no_winograd": 1 << 1, "no_winograd_detector": 1 << 2, "no_winograd_layer_in1": 1 << 3,
     "no_xcd_order": 1 << 4, "no_fused_stem_pool": 1 << 5, "split_heads": 1 << 6, "nms_in_line": 1 << 7,
     "no_persistent_grid": 1 << 8, "layer1_tile_8x16": 1 << 9, "winograd_gen1": 1 << 10, "no_latency_tiles": 1 << 11,
-    "nms_one_workgroup": 1 << 12, "no_fused_softmax": 1 << 13, "winograd_gen2": 1 << 14,
+    "nms_one_workgroup": 1 << 12, "no_fused_softmax": 1 << 13, "winograd_gen2": 1 << 14, "guard_zones": 1 << 15,
 }
 
 
@@ -130,6 +132,8 @@ def load():
     l.fpc_plan_hash.argtypes = [vp]
     l.fpc_plan_hash.restype = ctypes.c_uint64
     l.fpc_broadcast_weights.argtypes = [vp, vp, ci]
+    l.fpc_pack_layout_revision.restype = ci
+    l.fpc_check_guards.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     l.fpc_set_timing.argtypes = [vp, ci]
     l.fpc_get_timings.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double),
@@ -139,6 +143,9 @@ def load():
     if l.fpc_abi_version() != ABI_VERSION:
         raise ImportError("libfpc.so has ABI version %d, this binding is for %d: rebuild (make -C %s)"
                           % (l.fpc_abi_version(), ABI_VERSION, CSRC))
+    if l.fpc_pack_layout_revision() != PACK_LAYOUT_REVISION:
+        raise ImportError("libfpc.so packs fragment-layout revision %d, this binding expects %d: rebuild (make -C %s)"
+                          % (l.fpc_pack_layout_revision(), PACK_LAYOUT_REVISION, CSRC))
     _lib = l
     return l
 

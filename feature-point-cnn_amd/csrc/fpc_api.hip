@@ -413,6 +413,8 @@ struct fpc_ctx {
   // one slab for all activations / results; carved below
   char* slab = nullptr;
   size_t slab_bytes = 0;
+  bool guard_zones = false;                                    // FPC_PLAN_GUARD_ZONES
+  std::vector<std::pair<size_t, size_t>> guards;               // (offset, bytes) of the canary zones in the slab
   float *stem_out, *x0, *h4, *x1, *x2, *h8, *x3, *cat, *dh, *dproj, *d0, *lg;
   float *h16, *y16a, *y16b, *lo_h, *lo0, *desc_map, *desc_in_nhwc;
   float* prob;
@@ -450,15 +452,53 @@ namespace fpc {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// FPC_PLAN_GUARD_ZONES (a test facility, include/fpc.h): `guard` bytes of a canary pattern behind EVERY carved buffer and
+// GUARD_TAIL bytes behind the last one -- the out-of-range store this exists for ("a fault worth
+// recording") landed W36_MARKER = 2 GiB behind its tensor, so the tail zone spans that distance from any buffer of a
+// small configuration.  fpc_check_guards counts the words that no longer hold the pattern.
+constexpr size_t GUARD_BYTES = 64 << 10;
+constexpr size_t GUARD_TAIL = (size_t)0x80000000u + (4u << 20);
+constexpr uint32_t GUARD_PATTERN = 0xA5C3F00Du;
+
 struct Carver {
   size_t off = 0;
+  size_t guard = 0;
+  std::vector<std::pair<size_t, size_t>>* zones = nullptr;   // (offset, bytes) of every guard zone
   template <typename T>
   size_t take(size_t n) {
     const size_t o = off;
     off = align_up(off + n * sizeof(T), 256);
+    if (guard) {
+      zones->push_back({off, guard});
+      off += guard;
+    }
     return o;
   }
+  void finish() {
+    if (guard) {
+      zones->push_back({off, GUARD_TAIL});
+      off += GUARD_TAIL;
+    }
+  }
 };
+
+
+__global__ void guard_fill_kernel(uint32_t* p, size_t n, uint32_t v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void guard_count_kernel(const uint32_t* p, size_t n, uint32_t v, unsigned long long* bad) {
+  unsigned long long mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += p[i] != v;
+  if (mine) atomicAdd(bad, mine);
+}
+static int fill_guards(fpc_ctx* c) {
+  for (const auto& z : c->guards) {
+    const size_t n = z.second / 4;
+    guard_fill_kernel<<<(unsigned)std::min<size_t>(4096, (n + 255) / 256), 256, 0, c->stream>>>(reinterpret_cast<uint32_t*>(c->slab + z.first), n, GUARD_PATTERN);
+  }
+  if (!c->guards.empty()) HIPCHECK(hipStreamSynchronize(c->stream));
+  return FPC_OK;
+}
 
 // ---- architecture walk ---------------------------------------------------------------
 // Builds ctx->ops with geometry and buffer pointers, and assigns blob offsets.  The
@@ -1059,6 +1099,8 @@ static int build_vgg_plan(fpc_ctx* c) {
   const int H = c->H, W = c->W, B = c->B, Hc = H / 8, Wc = W / 8;
   const size_t npix8 = (size_t)B * Hc * Wc;
   Carver cv;
+  cv.zones = &c->guards;
+  cv.guard = c->guard_zones ? GUARD_BYTES : 0;
   // activations: one buffer per tensor (sub-batches of one call run different layers at the same time)
   const int ah[4] = {H, H / 2, H / 4, Hc}, aw[4] = {W, W / 2, W / 4, Wc}, ac[4] = {64, 64, 128, 128};
   size_t o_a[4], o_b[4], o_p[3];
@@ -1077,12 +1119,14 @@ static int build_vgg_plan(fpc_ctx* c) {
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
   const size_t o_aux = cv.take<int32_t>((size_t)B * NMS_AUX_INTS);
   const size_t o_rowbest = cv.take<unsigned long long>(c->cap), o_colbest = cv.take<unsigned long long>(c->cap);
+  cv.finish();
   c->slab_bytes = cv.off;
   if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
     g_hip_err = "hipMalloc(workspace " + std::to_string(c->slab_bytes >> 20) + " MiB) failed";
     return FPC_E_HIP;
   }
   HIPCHECK(hipMemset(c->slab, 0, c->slab_bytes));
+  if (int grc = fill_guards(c)) return grc;
   auto F = [&](size_t o) { return reinterpret_cast<float*>(c->slab + o); };
   c->lg = F(o_lg); c->desc_map = F(o_desc); c->desc_in_nhwc = F(o_descin); c->prob = F(o_prob);
   c->nmsmap = reinterpret_cast<uint32_t*>(c->slab + o_map);
@@ -1247,6 +1291,8 @@ static int build_plan(fpc_ctx* c) {
   const bool de = c->cfg.descriptor_enabled != 0;
   // ---- carve the slab
   Carver cv;
+  cv.zones = &c->guards;
+  cv.guard = c->guard_zones ? GUARD_BYTES : 0;
   const size_t o_stem = cv.take<float>((size_t)B * H2 * W2 * 64);
   const size_t o_x0 = cv.take<float>((size_t)B * H4 * W4 * 64), o_h4 = cv.take<float>((size_t)B * H4 * W4 * 64);
   const size_t o_x1 = cv.take<float>((size_t)B * H4 * W4 * 64), o_x2 = cv.take<float>((size_t)B * H4 * W4 * 64);
@@ -1267,12 +1313,14 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
   const size_t o_aux = cv.take<int32_t>((size_t)B * NMS_AUX_INTS);
   const size_t o_rowbest = cv.take<unsigned long long>(c->cap), o_colbest = cv.take<unsigned long long>(c->cap);
+  cv.finish();
   c->slab_bytes = cv.off;
   if (hipMalloc((void**)&c->slab, c->slab_bytes) != hipSuccess) {
     g_hip_err = "hipMalloc(workspace " + std::to_string(c->slab_bytes >> 20) + " MiB) failed";
     return FPC_E_HIP;
   }
   HIPCHECK(hipMemset(c->slab, 0, c->slab_bytes));
+  if (int grc = fill_guards(c)) return grc;
   auto F = [&](size_t o) { return reinterpret_cast<float*>(c->slab + o); };
   c->stem_out = F(o_stem); c->x0 = F(o_x0); c->h4 = F(o_h4); c->x1 = F(o_x1); c->x2 = F(o_x2);
   c->h8 = F(o_h8); c->x3 = F(o_x3); c->cat = F(o_cat); c->dh = F(o_dh); c->dproj = F(o_dproj);
@@ -1328,7 +1376,10 @@ static int build_plan(fpc_ctx* c) {
       const BlockSpec bs{p, bk, x, csx, cin, cinp, Hx, Wx, y, csy, cout, coutp, proj, desc};
       WKind wk = WK_COUNT;
       if (c->winograd && stride == 1) {
-        const int gen = c->winograd_gen == 3 && !w36_fits(c->B, Hx, Wx, csx, csy) ? 2 : c->winograd_gen;
+        // generation 3's projection pass walks x in 16-channel steps, 4 or 8 per pass (wblock36_mfma.h: gemm_over advances
+        // by 4): k8_x = cinp / 8 must be a multiple of 8, i.e. cinp of 64 -- true of every layer of both networks; a
+        // layer that is not falls back to generation 2 instead of running extra K steps over stale staging rows
+        const int gen = c->winograd_gen == 3 && (!w36_fits(c->B, Hx, Wx, csx, csy) || (proj && cinp % 64 != 0)) ? 2 : c->winograd_gen;
         if (cinp % 32 == 0 && cout == 64) wk = gen == 3 ? w36_kind(64, Hx, Wx) : gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
         else if (cinp % 32 == 0 && cout == 128) wk = gen == 3 ? w36_kind(128, Hx, Wx) : gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
         else if (c->winograd_det && cinp % 32 == 0 && coutp == 72) wk = WK_W816_K32_C72;
@@ -1550,7 +1601,7 @@ static uint64_t plan_hash(const fpc_ctx* c) {
       h *= 1099511628211ull;
     }
   };
-  mix(FPC_ABI_VERSION); mix((uint64_t)c->cfg.dtype); mix((uint64_t)c->cfg.arch); mix((uint64_t)c->cin);
+  mix(FPC_ABI_VERSION); mix(FPC_PACK_LAYOUT_REVISION); mix((uint64_t)c->cfg.dtype); mix((uint64_t)c->cfg.arch); mix((uint64_t)c->cin);
   mix((uint64_t)(c->cfg.descriptor_enabled != 0)); mix(c->blob_floats); mix(c->stem_w_off); mix(c->stem_b_off);
   mix(c->vconv0_off);
   for (size_t i = 0; i < c->ops.size(); ++i) {
@@ -1572,13 +1623,15 @@ static void fill_blob_header(const fpc_ctx* c, uint32_t* h) {
   h[4] = (uint32_t)ph; h[5] = (uint32_t)(ph >> 32);
   h[6] = (uint32_t)c->blob_floats; h[7] = (uint32_t)((uint64_t)c->blob_floats >> 32);
   h[8] = 1;  // holds weights
+  h[9] = FPC_PACK_LAYOUT_REVISION;
 }
 
 static bool check_blob_header(const fpc_ctx* c, const uint32_t* h, std::string* why) {
   uint32_t want[BLOB_HEADER_FLOATS];
   fill_blob_header(c, want);
-  static const char* what[9] = {"magic", "ABI version", "dtype", "arch", "launch plan", "launch plan", "size", "size", "weights-present flag"};
-  for (int i = 0; i < 9; ++i)
+  static const char* what[10] = {"magic", "ABI version", "dtype", "arch", "launch plan", "launch plan", "size", "size", "weights-present flag",
+                                 "fragment-layout revision"};
+  for (int i = 0; i < 10; ++i)
     if (h[i] != want[i]) {
       *why = std::string("packed weights do not match this context: ") + what[i] + " differs (the blob was packed by another "
              "build, dtype, arch or plan, or holds no weights)";
@@ -2456,6 +2509,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb0, bool de, i
 extern "C" {
 
 int fpc_abi_version(void) { return FPC_ABI_VERSION; }
+int fpc_pack_layout_revision(void) { return FPC_PACK_LAYOUT_REVISION; }
 
 // What this binary was compiled with: the target, whether it is the diagnostic build (in-kernel stamps: never the
 // product), and that no experiment switch of earlier rounds reached it (they are gone from the headers; a build
@@ -2567,6 +2621,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     int nsub = cfg->num_streams > 0 ? std::min(8, cfg->num_streams) : (c->split ? 3 : 2);   // measured: 2 sub-batches for the fp32-MFMA kernels, 3 for the (shorter) split-operand ones
     const unsigned pf = cfg->plan_flags;
     c->fuse_blocks = !(pf & FPC_PLAN_NO_FUSED_BLOCKS);
+    c->guard_zones = (pf & FPC_PLAN_GUARD_ZONES) != 0;
     c->winograd = !(pf & FPC_PLAN_NO_WINOGRAD);
     c->winograd_det = !(pf & FPC_PLAN_NO_WINOGRAD_DETECTOR);
     c->winograd_in1 = !(pf & FPC_PLAN_NO_WINOGRAD_LAYER_IN1);
@@ -2765,6 +2820,29 @@ int fpc_mark_weights_loaded(fpc_ctx* c) {
 
 uint64_t fpc_plan_hash(const fpc_ctx* c) { return c ? plan_hash(c) : 0; }
 
+int fpc_check_guards(fpc_ctx* c, long long* bad_words) {
+  if (!c || !bad_words) return FPC_E_INVALID;
+  *bad_words = 0;
+  if (!c->guard_zones || c->guards.empty()) return FPC_E_INVALID;      // the context was not created with FPC_PLAN_GUARD_ZONES
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipDeviceSynchronize());
+  unsigned long long* d = nullptr;
+  HIPCHECK(hipMalloc((void**)&d, sizeof(*d)));
+  HIPCHECK(hipMemset(d, 0, sizeof(*d)));
+  for (const auto& z : c->guards) {
+    const size_t n = z.second / 4;
+    guard_count_kernel<<<(unsigned)std::min<size_t>(4096, (n + 255) / 256), 256, 0, c->stream>>>(reinterpret_cast<const uint32_t*>(c->slab + z.first), n, GUARD_PATTERN, d);
+  }
+  unsigned long long h = 0;
+  const hipError_t e1 = hipStreamSynchronize(c->stream);
+  const hipError_t e2 = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  hipFree(d);
+  HIPCHECK(e1);
+  HIPCHECK(e2);
+  *bad_words = (long long)h;
+  return FPC_OK;
+}
+
 // RCCL is resolved at run time: first among the libraries the process already holds (a torch host has
 // torch/lib/librccl.so mapped; the communicator the caller passes came from THAT copy), then the system's.
 namespace {
@@ -2836,19 +2914,25 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
   const bool match = check_blob_header(c, tag, &why);
   void* dst = c->blob;
   void* scratch = nullptr;
-  bool clobbered = false;
+  bool slab_used = false;
   if (!match) {
-    // somewhere to receive root_bytes: scratch; if that cannot be had, this rank's own blob when it is large enough
-    // (its weights are then gone and it says so) -- what it must NOT do is return before the collective
+    // Somewhere to receive root_bytes.  What this rank must NOT do is return before the collective (the others would wait
+    // in ncclBroadcast until the backend's time-out), so three places are tried: scratch memory; this rank's own blob
+    // when it is large enough (its weights are declared gone BEFORE the bytes arrive -- a broadcast that fails half way
+    // leaves the blob undefined); the activation workspace, which holds nothing between calls and is re-zeroed after.
     if (hipMalloc(&scratch, root_bytes) == hipSuccess) {
       dst = scratch;
     } else {
       (void)hipGetLastError();
       scratch = nullptr;
       if (root_bytes <= c->blob_floats * sizeof(float)) {
-        clobbered = true;
+        c->weights_loaded = false;
+      } else if (root_bytes <= c->slab_bytes) {
+        dst = c->slab;
+        slab_used = true;
       } else {
-        g_hip_err = "no memory to take part in the weight broadcast (" + std::to_string(root_bytes) + " bytes); the other ranks of this communicator will wait for this one";
+        g_hip_err = "no memory to take part in the weight broadcast (" + std::to_string(root_bytes) + " bytes: no scratch, and neither this "
+                    "context's blob nor its workspace is that large); the other ranks of this communicator will wait for this one";
         return FPC_E_HIP;
       }
     }
@@ -2856,8 +2940,13 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
   nrc = g_rccl.bcast(dst, dst, root_bytes, 1, root, nccl_comm, c->stream);
   he = hipStreamSynchronize(c->stream);
   if (scratch) hipFree(scratch);
-  if (clobbered) c->weights_loaded = false;
+  if (slab_used) {      // foreign bytes in the workspace: back to the state fpc_create left (zeros, canary zones)
+    hipMemsetAsync(c->slab, 0, std::min(c->slab_bytes, align_up(root_bytes, 256)), c->stream);
+    hipStreamSynchronize(c->stream);
+    if (c->guard_zones) fill_guards(c);
+  }
   if (nrc != 0 || he != hipSuccess) {
+    if (match) c->weights_loaded = false;      // the blob may hold part of the new bytes
     g_hip_err = nrc ? "ncclBroadcast(weights) failed: ncclResult " + std::to_string(nrc) : std::string("broadcast: ") + hipGetErrorString(he);
     return FPC_E_HIP;
   }

@@ -335,6 +335,14 @@ class Engine:
         return out.cpu().numpy()
 
     # -- timing ----------------------------------------------------------------------
+    def check_guards(self):
+        """Contexts created with plan_flags=["guard_zones"] (a test facility): waits for the device and returns the number
+        of 32-bit words of the workspace's canary zones that a kernel has overwritten (0 = every store stayed inside
+        its tensor)."""
+        bad = ctypes.c_longlong(0)
+        _lib.check(self._l.fpc_check_guards(self._ctx, ctypes.byref(bad)), "fpc_check_guards")
+        return int(bad.value)
+
     def set_timing(self, on):
         _lib.check(self._l.fpc_set_timing(self._ctx, int(bool(on))), "fpc_set_timing")
 

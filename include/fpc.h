@@ -29,7 +29,14 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 2
+#define FPC_ABI_VERSION 3
+/* Revision of the packed-weight FRAGMENT LAYOUTS (what the packing routines of this build write at the offsets the launch
+ * plan names).  It is part of the blob's tag and of fpc_plan_hash: bump it whenever a packing routine changes the order
+ * of values inside a layer's fragments -- offsets and sizes, which the plan hash covers anyway, do not change then, and
+ * a blob of the older build would otherwise be accepted and multiplied with the wrong weights.
+ *   1: rounds 1-2.   2: round 3 (fp32 stem fragments in the column / row tap-pair K order, stem_pair).
+ *   3: round 4. */
+#define FPC_PACK_LAYOUT_REVISION 3
 
 enum {
   FPC_OK = 0,
@@ -101,7 +108,10 @@ enum {
   FPC_PLAN_NO_LATENCY_TILES = 1 << 11,     /* calls of a few frames keep the 8x16 tiles of the batch plan (FPC_LATENCY_TILES=0) */
   FPC_PLAN_NMS_ONE_WORKGROUP = 1 << 12,    /* survivors of a frame sorted by one workgroup, not in slices (FPC_NMS_CHUNKED=0)   */
   FPC_PLAN_NO_FUSED_SOFTMAX = 1 << 13,     /* FPC_BF16: exp-softmax as its own launch in fpc_detect too  (FPC_FUSE_SOFTMAX=0)   */
-  FPC_PLAN_WINOGRAD_GEN2 = 1 << 14         /* round-2 Winograd kernel, F(2x2,3x3), instead of F(4x4,3x3) (FPC_WINOGRAD_GEN=2)   */
+  FPC_PLAN_WINOGRAD_GEN2 = 1 << 14,        /* round-2 Winograd kernel, F(2x2,3x3), instead of F(4x4,3x3) (FPC_WINOGRAD_GEN=2)   */
+  FPC_PLAN_GUARD_ZONES = 1 << 15           /* TEST FACILITY: 64 KiB of a canary pattern behind every buffer of the workspace and
+                                              2 GiB behind the last one (the workspace grows by that much); fpc_check_guards
+                                              counts the words a kernel has overwritten.  Not for production contexts.          */
 };
 
 /* One checkpoint entry: name and shape as in ckpt['model_state_dict']
@@ -165,6 +175,13 @@ int fpc_import_packed(fpc_ctx* ctx, const void* host_src, size_t n);
 int fpc_mark_weights_loaded(fpc_ctx* ctx);
 /* Hash of everything the blob layout depends on -- equal on two contexts iff they can exchange packed weights. */
 uint64_t fpc_plan_hash(const fpc_ctx* ctx);
+/* FPC_PACK_LAYOUT_REVISION of the library as built (a binding compares it with the header it was written against). */
+int fpc_pack_layout_revision(void);
+
+/* TEST FACILITY (contexts created with FPC_PLAN_GUARD_ZONES only; FPC_E_INVALID otherwise): waits for the device, then
+ * counts the 32-bit words of the workspace's canary zones -- behind every activation / result buffer, and 2 GiB behind
+ * the last one -- that no longer hold the pattern written at fpc_create.  0 = no kernel stored outside its tensors. */
+int fpc_check_guards(fpc_ctx* ctx, long long* bad_words);
 
 /* Frame-batch sharding over the GPUs of a node (the heaviest batch caller to shard is
  * python/src/preprocess_coco.py:64-74): the ONE exchange of the path.  The root rank has loaded the checkpoint

@@ -29,7 +29,14 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fpc_abi_version() == 2
+    hdr = open(os.path.join(ROOT, "include", "fpc.h")).read()
+    # the header, the library as built and the binding agree on the ABI and on the fragment-layout revision -- the
+    # latter is part of the packed blob's tag and of fpc_plan_hash (advisor, round 3: round 3 changed the stem's
+    # fragment order under an unchanged ABI version and plan hash, so a round-2 blob would have been accepted)
+    assert int(re.search(r"#define FPC_ABI_VERSION (\d+)", hdr).group(1)) == lib.fpc_abi_version() == _lib.ABI_VERSION == 3
+    assert int(re.search(r"#define FPC_PACK_LAYOUT_REVISION (\d+)", hdr).group(1)) == lib.fpc_pack_layout_revision() == _lib.PACK_LAYOUT_REVISION
+    api = open(os.path.join(ROOT, "feature-point-cnn_amd", "csrc", "fpc_api.hip")).read()
+    assert "mix(FPC_PACK_LAYOUT_REVISION)" in api and "h[9] = FPC_PACK_LAYOUT_REVISION" in api
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fpc_[a-z_0-9]+)", out))
     assert set(declared) <= exported

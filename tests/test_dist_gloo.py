@@ -146,7 +146,29 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
+    threads = out.pop("host_threads_per_rank")
     assert out == {"rendezvous": "ok", "world": 2, "ranks": [0, 1], "backend": "gloo"}
+    assert 1 <= threads <= max(1, len(os.sched_getaffinity(0)) // 2)      # each rank binds cores // N host threads
+
+
+def test_bench_timing_reduction_with_four_ranks():
+    """The N > 1 bookkeeping of bench.py on 4 gloo ranks that pretend to have run their K steps at different speeds
+    (FPC_BENCH_FAKE_STEP_MS): `value` = frames of ALL ranks / the SLOWEST rank's time (max over ranks, the contract's
+    rule), `per_rank` lists every rank's own rate in rank order.  The reduction is bench.aggregate_over_ranks, the
+    function the real run calls -- so the first 8-GPU lease cannot fail in the bookkeeping."""
+    import json
+    r = _bench(["--gpus", "4", "--steps", "20"], FPC_BENCH_RENDEZVOUS_ONLY="1", FPC_DIST_BACKEND="gloo",
+               FPC_BENCH_FAKE_STEP_MS="3.0,3.2,4.0,2.5")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["world"] == 4 and out["ranks"] == [0, 1, 2, 3] and out["n_gpus"] == 4 and out["steps"] == 20
+    assert abs(out["ms_per_step"] - 4.0) < 1e-6                           # the slowest rank
+    assert abs(out["value"] - 4 * 32 * 20 / (4.0e-3 * 20)) < 0.5           # whole-job frames / that time = 32 000 frames/s
+    want = [32 / 3.0e-3, 32 / 3.2e-3, 32 / 4.0e-3, 32 / 2.5e-3]
+    assert all(abs(a - b) < 0.5 for a, b in zip(out["per_rank"]["frames_per_s"], want))
+    assert out["per_rank"]["weights_start_up_ms"] == [10.0, 11.0, 12.0, 13.0]
 
 
 def test_bench_parent_reports_a_failing_rank():

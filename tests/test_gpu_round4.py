@@ -1,0 +1,131 @@
+"""Round-4 parity / safety tests (pytest -m gpu), all through the C-ABI.
+
+* The fault of round 3 by name: a map NARROWER than a wblock36_kernel tile made the store descriptor's masked columns
+  land W36_MARKER (2 GiB) behind the tensor -- an out-of-range STORE, which no comparison of the tensor itself can see.
+  Contexts created with FPC_PLAN_GUARD_ZONES carry a canary pattern behind every buffer of the workspace and 2 GiB
+  behind the last one; fpc_check_guards counts overwritten words.
+* The bench's headline plan (the whole 32-frame VGA batch as ONE sub-batch on one stream: 640 tiles on a 216-workgroup
+  persistent grid, the 2 x 8 instance at layer1) against the oracle and against the library's default plan.
+* A packed blob whose tag names another fragment-layout revision / ABI version is refused.
+"""
+import numpy as np
+import pytest
+
+import fpc_amd  # noqa: F401
+from fpc_amd import _lib, arch, synth
+
+pytestmark = pytest.mark.gpu
+
+SPEC = arch.state_dict_spec()
+ATOL = 1e-4
+
+
+def engine(h, w, b=1, **kw):
+    from fpc_amd.engine import Engine
+    return Engine(h, w, max_batch=b, **kw)
+
+
+def oracle_mod():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("h,w", [(32, 48), (64, 96), (48, 160)])
+def test_maps_narrower_than_a_tile_store_nothing_outside_their_tensors(h, w):
+    """wblock36_kernel<NB, 4, 4> (16 x 16 pixels) / <NB, 2, 8> (8 x 32) on maps of 4 x 6 ... 12 x 40 pixels, driven through
+    the batch plan (`no_latency_tiles`: calls of a few frames otherwise take the 4 x 16 latency instances), batch 2:
+    every canary word behind every workspace buffer -- and in the 2 GiB behind the workspace, where round 3's masked
+    stores went -- is unchanged after forward + detect, and the dense maps are the oracle's at 1e-4."""
+    sd = synth.make_state_dict(3, dustbin_bias=4.0)
+    frames = synth.make_batch(11, 2, h, w)
+    e = engine(h, w, 2, plan_flags=["no_latency_tiles", "guard_zones"])
+    e.load_state_dict(sd)
+    assert e.check_guards() == 0                       # the pattern is in place before anything ran
+    prob, desc, logits = e.forward(frames)
+    res = e.detect(frames)
+    assert e.check_guards() == 0, "a kernel stored outside its tensor"
+    o_prob, o_desc, o_logits = oracle_mod().forward(frames, sd, SPEC)
+    assert np.max(np.abs(logits.cpu().numpy() - o_logits)) < ATOL
+    assert np.max(np.abs(desc.cpu().numpy() - o_desc)) < ATOL
+    assert np.max(np.abs(prob.cpu().numpy() - o_prob)) < ATOL
+    assert len(res) == 2
+    e.close()
+    # the facility itself: a context without the flag refuses the call
+    e2 = engine(h, w, 1)
+    with pytest.raises(_lib.FpcError):
+        e2.check_guards()
+    e2.close()
+
+
+def test_guard_zones_see_a_planted_store():
+    """The checker itself: overwrite four words right behind one buffer and 2 GiB behind the workspace's last buffer
+    (through a torch view of the library's memory) -- both are counted."""
+    import ctypes
+    import torch
+    from fpc_amd.engine import _DevArray
+    e = engine(32, 48, 1, plan_flags=["guard_zones"])
+    res = e._res
+    # `count` is one of the carved buffers (int32[B]); its guard zone starts at the next 256-byte boundary
+    base = int(res.count)
+    view = torch.as_tensor(_DevArray(base + 256, 64), device=e.torch_device)
+    view[:16] = 0
+    torch.cuda.synchronize()
+    assert e.check_guards() == 4
+    e.close()
+
+
+def test_headline_plan_one_sub_batch_on_one_stream_matches_oracle_and_default_plan():
+    """bench.py's headline runs every 32-frame VGA batch as ONE sub-batch on one stream (num_streams = 1): wblock36 grids
+    of 216 workgroups walking 640 tiles in three rounds, the 2 x 8 instance at layer1.  Held to (a) the oracle's own
+    forward on two frames at 1e-4, (b) the oracle's post-processing of the device's maps, exactly, (c) the library's
+    default plan (two 16-frame sub-batches on two streams): bit-identical keypoints, confidences and descriptors."""
+    h, w, n = 480, 640, 32
+    sd = synth.make_state_dict(0, dustbin_bias=7.0)
+    frames = synth.make_batch(100, n, h, w)
+    e1 = engine(h, w, n, num_streams=1)
+    e1.load_state_dict(sd)
+    prob, desc, logits = e1.forward(frames)
+    res1 = e1.detect(frames)
+    oracle = oracle_mod()
+    for i in (3, 20):
+        o_prob, o_desc, o_logits = oracle.forward(frames[i:i + 1], sd, SPEC)
+        assert np.max(np.abs(logits[i].cpu().numpy() - o_logits[0])) < ATOL
+        assert np.max(np.abs(prob[i].cpu().numpy() - o_prob[0])) < ATOL
+        assert np.max(np.abs(desc[i].cpu().numpy() - o_desc[0])) < ATOL
+    for i in (0, 17, 31):
+        xy, conf, d, ncand = res1[i]
+        oxs, oys, oconf, oncand = oracle.get_points(prob[i].cpu().numpy())
+        assert ncand == oncand
+        np.testing.assert_array_equal(xy[:, 0], oxs)
+        np.testing.assert_array_equal(xy[:, 1], oys)
+        np.testing.assert_array_equal(conf, oconf)
+    e2 = engine(h, w, n)
+    e2.import_packed(e1.export_packed())
+    res2 = e2.detect(frames)
+    for a, b in zip(res1, res2):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+    e1.close()
+    e2.close()
+
+
+def test_blob_of_another_fragment_layout_revision_is_refused():
+    """The packed blob's 64-byte tag carries FPC_PACK_LAYOUT_REVISION (word 9) beside magic, ABI version, dtype, arch, plan
+    hash and size: a blob that names the previous revision (a file kept from an older build, a rank on another build)
+    is refused by fpc_import_packed -- round 3 changed the stem's fragment order under an unchanged tag."""
+    e = engine(32, 48, 1)
+    e.load_state_dict(synth.make_state_dict(1, dustbin_bias=4.0))
+    blob = e.export_packed().copy()
+    words = blob.view(np.uint32)
+    assert words[0] == 0x57435046 and words[1] == _lib.ABI_VERSION and words[9] == _lib.PACK_LAYOUT_REVISION
+    e2 = engine(32, 48, 1)
+    e2.import_packed(blob)                              # the untouched blob is accepted
+    for word, value in ((9, _lib.PACK_LAYOUT_REVISION - 1), (1, _lib.ABI_VERSION - 1)):
+        bad = blob.copy()
+        bad.view(np.uint32)[word] = value
+        with pytest.raises(_lib.FpcError) as ei:
+            e2.import_packed(bad)
+        assert ei.value.code == -1                      # FPC_E_INVALID
+    e.close()
+    e2.close()

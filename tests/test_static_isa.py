@@ -1,0 +1,235 @@
+"""Static checks on the SHIPPED gfx950 code object (CPU suite: llvm-objdump, no GPU).
+
+wblock36_mfma.h hides 7 / 15 MFMAs of every block inside one `asm volatile`; the compiler's hazard recogniser sees only
+the block's last MFMA (its own builtin).  Whether an accumulator written by an MFMA *inside* the asm is old enough when
+the first non-MFMA instruction touches it rests on a timing argument (wblock36_mfma.h, fpc_mfma_step): this test turns
+that argument into a build-time fact.  It disassembles every `wblock36_kernel` instance of feature-point-cnn_amd/lib/
+libfpc.so and checks
+
+  (i)  MFMA result hazards: `v_mfma_f32_16x16x4_f32` is an 8-pass XDL instruction; a VALU / LDS / VMEM / accvgpr
+       instruction that reads or overwrites its destination needs >= 11 wait states after the MFMA's issue (CDNA3 ISA
+       guide 4.5 "XDL write VGPR -> VALU read/write, VMEM/LDS/FLAT read": passes + 3; LLVM's GCNHazardRecognizer
+       GFX940_XDL_N_PassWriteVgprVALU*WaitStates).  Wait states are counted the way the hardware spends them, as a LOWER
+       bound on elapsed issue cycles: every instruction 1, `s_nop k` k + 1, and an MFMA cannot issue earlier than 8 wait
+       states (its 8 passes) after the previous MFMA.  s_waitcnt stalls only add to that, so a pass here is safe.
+       Straight-line order and every backward branch (loop back edges: tail of the body followed by its head) are scanned.
+  (ii) the spill facts DESIGN.md section 3.1 states: per instance `.sgpr_spill_count`, `.vgpr_spill_count`,
+       `.private_segment_fixed_size` and the number of scratch instructions -- and that NONE of the spill traffic
+       (v_readlane / v_writelane / scratch_*) sits inside the chunk loop (the MFMA-dense loop every tile runs
+       nchunk / 2 times).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "feature-point-cnn_amd", "lib", "libfpc.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# What DESIGN.md section 3.1 ("Spills, as the code object has them") states.  SGPR spills are v_writelane / v_readlane
+# pairs of uniform values (tile coordinates, row offsets of the tail's loads and stores); the VGPR spills of the
+# 128-channel instances are 4 registers around the tile loop's head.  Update BOTH places when the kernel changes.
+SPILLS = {
+    # instance (NB, TYT, TXT): (sgpr_spill_count max, vgpr_spill_count max, private_segment_fixed_size max)
+    (1, 4, 4): (80, 0, 0),
+    (1, 2, 8): (80, 0, 0),
+    (2, 4, 4): (96, 4, 16),
+    (2, 2, 8): (96, 4, 16),
+}
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.skip("libfpc.so not built")
+    d = tmp_path_factory.mktemp("isa")
+    lib = os.path.join(d, "libfpc.so")
+    shutil.copy(LIB, lib)
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], stdout=subprocess.DEVNULL, cwd=d)
+    co = [f for f in os.listdir(d) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(d)
+    co = os.path.join(d, co[0])
+    dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", co]).decode()
+    notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co]).decode()
+    funcs, cur = {}, None
+    for ln in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        elif cur and ln.strip() and not ln.startswith("Disassembly"):
+            ins = ln.split("//")[0].strip()
+            if ins:
+                addr = int(ln.split("//")[1].split(":")[0].strip(), 16) if "//" in ln else None
+                funcs[cur].append((addr, ins))
+    meta = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+                      for k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+    return funcs, meta
+
+
+def _instances(funcs):
+    out = {}
+    for name in funcs:
+        m = re.match(r"_ZN3fpc15wblock36_kernelILi(\d+)ELi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
+        if m:
+            out[tuple(int(v) for v in m.groups())] = name
+    return out
+
+
+_REG = re.compile(r"\b([av])(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def _regs(operand_text):
+    """set of ('a'|'v', index) named in an operand string."""
+    out = set()
+    for m in _REG.finditer(operand_text):
+        f = m.group(1)
+        if m.group(4) is not None:
+            out.add((f, int(m.group(4))))
+        else:
+            out.update((f, i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def _touches_vector_registers(op):
+    return op.startswith(("v_", "ds_", "buffer_", "global_", "flat_", "scratch_"))
+
+
+def _scan(seq, need=11, mfma_passes=8):
+    """seq: list of instruction strings in issue order -> list of (index, instruction, writer index, wait states)."""
+    bad = []
+    t = 0
+    last_mfma_t = -10 ** 9
+    pending = {}          # register -> (issue time of the MFMA that writes it, index)
+    for i, ins in enumerate(seq):
+        op = ins.split()[0]
+        rest = ins[len(op):]
+        if op.startswith("v_mfma"):
+            t = max(t + 1, last_mfma_t + mfma_passes)
+            last_mfma_t = t
+            dst = rest.split(",")[0]
+            # (an MFMA reading another MFMA's result as SrcC / A / B is interlocked by the hardware: not checked here)
+            for r in _regs(dst):
+                pending[r] = (t, i)
+            continue
+        if op == "s_nop":
+            t += int(rest.strip(), 0) + 1
+            continue
+        t += 1
+        if _touches_vector_registers(op):
+            for r in _regs(rest):
+                if r in pending:
+                    t0, j = pending[r]
+                    if t - t0 < need:
+                        bad.append((i, ins, j, t - t0))
+                    else:
+                        del pending[r]
+    return bad
+
+
+def test_wblock36_uses_only_the_8_pass_mfma(code_object):
+    funcs, _ = code_object
+    inst = _instances(funcs)
+    assert set(inst) == set(SPILLS), sorted(inst)
+    for key, name in inst.items():
+        ops = {i.split()[0] for _, i in funcs[name] if i.startswith("v_mfma")}
+        assert ops == {"v_mfma_f32_16x16x4_f32"}, (key, ops)      # the wait-state figure below is this instruction's
+
+
+def test_no_instruction_touches_an_mfma_result_too_early(code_object):
+    """(i) of the module docstring, for every wblock36_kernel instance."""
+    funcs, _ = code_object
+    for key, name in _instances(funcs).items():
+        body = funcs[name]
+        seq = [i for _, i in body]
+        bad = _scan(seq)
+        assert not bad, "%s: %s" % (key, [(seq[j], ins, ws) for _, ins, j, ws in bad[:5]])
+        # loop back edges: the 40 instructions in front of a backward branch, then the 40 at its target
+        addr_to_idx = {a: k for k, (a, _) in enumerate(body) if a is not None}
+        first = body[0][0]
+        n_back = 0
+        for k, (a, ins) in enumerate(body):
+            if not ins.startswith(("s_cbranch", "s_branch")):
+                continue
+            # llvm-objdump prints the target as `<symbol+0xOFFSET>` in the comment we stripped, or a simm16 in words
+            simm = int(ins.split()[1], 0)
+            if simm >= 0x8000:
+                simm -= 0x10000
+            tgt = (a + 4 + 4 * simm) if a is not None else None
+            if tgt is None or tgt not in addr_to_idx or addr_to_idx[tgt] > k:
+                continue
+            n_back += 1
+            head = addr_to_idx[tgt]
+            bad = _scan(seq[max(0, k - 40):k] + seq[head:head + 40])
+            assert not bad, "%s back edge at %d: %s" % (key, k, bad[:3])
+        assert n_back >= 2, (key, n_back, hex(first or 0))      # the chunk loop and the tile loop at least
+
+
+def _back_edges(body):
+    addr_to_idx = {a: k for k, (a, _) in enumerate(body) if a is not None}
+    out = []
+    for k, (a, ins) in enumerate(body):
+        if ins.startswith(("s_cbranch", "s_branch")) and a is not None:
+            simm = int(ins.split()[1], 0)
+            if simm >= 0x8000:
+                simm -= 0x10000
+            tgt = a + 4 + 4 * simm
+            if tgt in addr_to_idx and addr_to_idx[tgt] < k:
+                out.append((addr_to_idx[tgt], k))
+    return out
+
+
+def _chunk_loop(body):
+    """(first, last, MFMAs) of the innermost loop (no other back edge inside) that holds the most MFMAs."""
+    edges = _back_edges(body)
+    best = None
+    for head, k in edges:
+        if any(h2 >= head and k2 <= k and (h2, k2) != (head, k) for h2, k2 in edges):
+            continue
+        n = sum(1 for _, i in body[head:k] if i.startswith("v_mfma"))
+        if best is None or n > best[2]:
+            best = (head, k, n)
+    return best
+
+
+def test_the_scanner_sees_a_planted_hazard():
+    """The checker itself: a reader 3 wait states behind an asm-style MFMA is reported, the same reader behind a second
+    MFMA (8 passes) + s_nop 1 is not; a store of the accumulator and an accvgpr read count as readers."""
+    blk = ["v_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]"]
+    assert _scan(blk + ["s_nop 1", "v_accvgpr_read_b32 v5, a2"])
+    assert _scan(blk + ["s_nop 1", "ds_write_b32 v9, a1"])                     # LDS data straight from an AGPR: a reader too
+    assert _scan(blk + ["s_nop 1", "v_add_f32_e32 v7, v7, v8"]) == []         # unrelated registers
+    # a nop in front of the next MFMA is absorbed by the 8 passes the matrix pipe is busy anyway: 8 + 1 = 9 wait states
+    assert _scan(blk + ["s_nop 1", "v_mfma_f32_16x16x4_f32 a[4:7], v1, v2, a[4:7]", "v_accvgpr_read_b32 v5, a2"])
+    ok = blk + ["v_mfma_f32_16x16x4_f32 a[4:7], v1, v2, a[4:7]", "s_nop 1", "v_accvgpr_read_b32 v5, a2"]
+    assert _scan(ok) == []                                                     # 8 + 2 + 1 = 11 wait states
+    assert _scan(blk + ["v_mfma_f32_16x16x4_f32 a[4:7], v1, v2, a[4:7]", "v_accvgpr_read_b32 v5, a6"])   # the second one's result
+    assert _scan(["v_mfma_f32_16x16x4_f32 v[10:13], v1, v2, v[10:13]", "s_nop 7", "v_max_f32_e32 v11, v11, v0"])
+    assert _scan(["v_mfma_f32_16x16x4_f32 v[10:13], v1, v2, v[10:13]", "s_nop 7", "s_nop 1", "v_max_f32_e32 v11, v11, v0"]) == []
+
+
+def test_spills_are_what_design_md_says_and_outside_the_chunk_loop(code_object):
+    """(ii) of the module docstring."""
+    funcs, meta = code_object
+    for key, name in _instances(funcs).items():
+        m = meta[name]
+        s_max, v_max, p_max = SPILLS[key]
+        assert m["sgpr_spill_count"] <= s_max, (key, m)
+        assert m["vgpr_spill_count"] <= v_max, (key, m)
+        assert m["private_segment_fixed_size"] <= p_max, (key, m)
+        body = funcs[name]
+        n_scratch = sum(1 for _, i in body if i.startswith("scratch_"))
+        assert n_scratch <= (0 if v_max == 0 else 12), (key, n_scratch)
+        loop = _chunk_loop(body)
+        assert loop is not None, key
+        head, tail, n_mfma = loop
+        # two chunks per trip: 2 x 36 positions x 4 k-steps x NB channel blocks
+        assert n_mfma == 2 * 36 * 4 * key[0], (key, n_mfma)
+        inside = [i for _, i in body[head:tail] if i.startswith(("v_readlane", "v_writelane", "scratch_"))]
+        assert not inside, (key, inside[:5])
