@@ -492,6 +492,11 @@ __global__ void guard_count_kernel(const uint32_t* p, size_t n, uint32_t v, unsi
   if (mine) atomicAdd(bad, mine);
 }
 static int fill_guards(fpc_ctx* c) {
+  // (the hipMemset of the workspace in front of this call runs on the null stream and need not have finished when it
+  // returns; c->stream is non-blocking, so nothing orders the two -- the first version lost 2 MB of pattern to it.
+  // Waited for in every context: the first call's kernels must not race the zeroing either.)
+  HIPCHECK(hipDeviceSynchronize());
+  if (c->guards.empty()) return FPC_OK;
   for (const auto& z : c->guards) {
     const size_t n = z.second / 4;
     guard_fill_kernel<<<(unsigned)std::min<size_t>(4096, (n + 255) / 256), 256, 0, c->stream>>>(reinterpret_cast<uint32_t*>(c->slab + z.first), n, GUARD_PATTERN);
@@ -825,19 +830,25 @@ static void add_wconv(fpc_ctx* c, const std::string& prefix, bool bn, WKind wk, 
   op.flops_per_frame = 2.0 * H * W * (double)k.CMID * cin * 9;
   op.mfma_flops_per_frame = wkind_mfma_flops(k, a.tiles_x * a.tiles_y, a.nchunk, 0);
   op.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)std::min(k.CMID, cout - n0) * H * W);
-  if (k.gen >= 2 && n0 == k.CMID && cout == 2 * k.CMID && !c->ops.empty() && c->ops.back().wconv && c->ops.back().prefix == prefix &&
-      c->ops.back().n0 == 0 && c->ops.back().wkind == wk) {
-    // second half of a 256-wide layer: ONE launch computes both halves (gridDim.y = 2); this op only carries the
-    // half's checkpoint -> fragment packing
-    Op& first = c->ops.back();
-    fpc_ctx::ConvW& cf = c->convw.back();
-    first.grid_y = 2;
-    first.wargs.ysplit_floats = (int)(cw.w_off[0] - cf.w_off[0]);
-    first.flops_per_frame *= 2;
-    first.mfma_flops_per_frame *= 2;
-    first.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)cout * H * W);
-    first.name = prefix + (bn ? ".conv1+bn1+relu [winograd, both 128-channel halves]" : " [winograd conv+bias+relu, both 128-channel halves]");
-    op.shadow = true;
+  const int part = n0 / k.CMID;
+  if (k.gen >= 2 && part > 0 && n0 % k.CMID == 0 && cout % k.CMID == 0 && (int)c->ops.size() >= part) {
+    // part 1 .. G - 1 of a layer wider than the instance (256 channels as 2 x 128 or 4 x 64): ONE launch computes all
+    // parts (gridDim.y = G; the kernel finds part y's fragments and bias y * ysplit_floats behind part 0's and its
+    // outputs y * CMID channels behind `out`); this op only carries the part's checkpoint -> fragment packing
+    Op& first = c->ops[c->ops.size() - part];
+    fpc_ctx::ConvW& cf = c->convw[c->convw.size() - part];
+    if (first.wconv && first.prefix == prefix && first.n0 == 0 && first.wkind == wk && first.grid_y == part) {
+      const int ys = (int)((cw.w_off[0] - cf.w_off[0]) / part);
+      if (part == 1) first.wargs.ysplit_floats = ys;
+      else if (first.wargs.ysplit_floats != ys) { c->plan_error = true; return; }
+      first.grid_y = part + 1;
+      first.flops_per_frame += op.flops_per_frame;
+      first.mfma_flops_per_frame += op.mfma_flops_per_frame;
+      first.bytes_per_frame = 4.0 * ((double)cin * H * W + (double)std::min(cout, (part + 1) * k.CMID) * H * W);
+      const std::string parts = std::to_string(part + 1) + " parts of " + std::to_string(k.CMID) + " channels";
+      first.name = prefix + (bn ? ".conv1+bn1+relu [winograd, " : " [winograd conv+bias+relu, ") + parts + "]";
+      op.shadow = true;
+    }
   }
   c->ops.push_back(op);
   c->convw.push_back(cw);
@@ -1472,8 +1483,14 @@ static int build_plan(fpc_ctx* c) {
       // 256 channels are too wide for the fused Winograd block (accumulators): conv1 as two conv-only Winograd
       // launches of 128 output channels each, then conv2 + identity + ReLU as a 1x1 launch (h makes one round trip)
       const std::string p = "descriptor.layer_in.1";
-      for (int n0 = 0; n0 < 256; n0 += 128)
-        add_wconv(c, p, true, c->winograd_gen == 3 && w36_fits(c->B, H16, W16, 256, 256) ? w36_kind(128, H16, W16) : c->winograd_gen >= 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+      // Generation 3: FOUR parts of 64 channels (the NB = 1 instance, gridDim.y = 4).  A 30 x 40 map is 6 tiles per
+      // frame: 192 tiles x 2 halves were 384 one-tile workgroups = 1.5 rounds of the 256 CUs at the 128-channel tile's
+      // time; 192 x 4 = 768 half-as-long tiles are 3 full rounds (64 workgroups per part walk 3 tiles each).
+      const bool g3 = c->winograd_gen == 3 && w36_fits(c->B, H16, W16, 256, 256);
+      const int in1_parts = g3 ? 4 : 2;
+      for (int n0 = 0; n0 < 256; n0 += 256 / in1_parts)
+        add_wconv(c, p, true, g3 ? w36_kind(64, H16, W16) : c->winograd_gen >= 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+      const size_t in1_ops = in1_parts + 1;      // [the launch, its shadows, the 1x1 below]
       ConvSpec t{};
       t.name = p + ".conv2+bn2+identity+relu";
       t.kind = K_T620_1x1_K64_N128; t.ksize = 1; t.stride = 1;
@@ -1483,10 +1500,10 @@ static int build_plan(fpc_ctx* c) {
       t.desc_branch = true;
       add_conv(c, t, &bo);
       retile_last(c, K_T320_1x1_K64_N128);
-      if (g_wkinds[c->ops[c->ops.size() - 3].wkind].gen == 2 && c->latency_tiles) {
+      if (g_wkinds[c->ops[c->ops.size() - in1_ops].wkind].gen == 2 && c->latency_tiles) {
         // calls of a few frames: the same two-half launch on 4 x 16 tiles (24 tiles x 2 halves per frame instead of
         // 12 x 2), then the same 1x1 -- 0.10 ms for one frame against 0.16 ms for the fused direct block on 20 tiles
-        const size_t ia = c->ops.size() - 3;   // [two-half launch, its shadow, 1x1]
+        const size_t ia = c->ops.size() - in1_ops;   // [two-half launch, its shadow, 1x1]
         c->ops[ia].when = 2;
         Op oh = c->ops[ia];
         oh.when = 1;
@@ -1496,10 +1513,10 @@ static int build_plan(fpc_ctx* c) {
         const fpc_ctx::ConvW cwa = c->convw[ia];
         c->ops.insert(c->ops.begin() + ia + 1, oh);
         c->convw.insert(c->convw.begin() + ia + 1, cwa);
-      } else if (g_wkinds[c->ops[c->ops.size() - 3].wkind].gen == 3 && c->latency_tiles) {
+      } else if (g_wkinds[c->ops[c->ops.size() - in1_ops].wkind].gen == 3 && c->latency_tiles) {
         // generation 3's fragments have 36 positions: the small-call variant (generation 2 on 4 x 16 tiles, then the same
         // 1x1) gets fragments of its own
-        for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
+        for (size_t k = c->ops.size() - in1_ops; k < c->ops.size(); ++k) c->ops[k].when = 2;
         const size_t ib = c->ops.size();
         for (int n0 = 0; n0 < 256; n0 += 128)
           add_wconv(c, p, true, WK_W16_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
@@ -1511,7 +1528,7 @@ static int build_plan(fpc_ctx* c) {
         oh.mfma_flops_per_frame = 2 * 2.0 * oh.wargs.tiles_x * oh.wargs.tiles_y * 128.0 * (16.0 * 16 * 256);
         for (size_t k = ib; k < c->ops.size(); ++k) c->ops[k].when = 1;
       } else if (c->latency_tiles || c->winograd_gen == 1) {
-      for (size_t k = c->ops.size() - 3; k < c->ops.size(); ++k) c->ops[k].when = 2;
+      for (size_t k = c->ops.size() - in1_ops; k < c->ops.size(); ++k) c->ops[k].when = 2;
       // a call of a few frames has 12 tiles per frame here: three dependent launches cost more latency than they save
       // work, so small calls take the fused direct block instead (its weights sit in the blob next to the others)
       block("descriptor.layer_in.1", K_T620_3x3_K64_N128, K_T620_1x1_K64_N128, 1, c->y16a, 256, 256, 256, H16, W16,
@@ -2250,7 +2267,8 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
           // the SMALLEST grid that still finishes in that many rounds (a multiple of 8: the tile walk is per XCD) and
           // leave the other CUs to the launches of the other sub-batch's stream -- 640 tiles: 216 workgroups x 3 rounds
           // instead of 256 of which 128 idle through the third; 320 tiles: 160 x 2.
-          const int cus8 = std::max(1, c->num_cus / 8), per_xcd = (a.total + 7) / 8;
+          // (a launch of gridDim.y parts shares the CUs between them: each part's tile walk gets CUs / parts)
+          const int cus8 = std::max(1, c->num_cus / 8 / std::max(1, op.grid_y)), per_xcd = (a.total + 7) / 8;
           const int rounds = (per_xcd + cus8 - 1) / cus8;
           grid = 8 * std::min(cus8, (per_xcd + rounds - 1) / rounds);
         }
