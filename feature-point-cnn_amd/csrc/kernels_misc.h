@@ -209,6 +209,24 @@ __device__ __forceinline__ void stem_pool_emit(const float* lds, float* out, int
   }
 }
 
+// The pooled map's cells that stem_pool_emit completes ACROSS tiles with atomicMax -- pooled rows / columns that are
+// multiples of 8 (window row / column 0 and 8 of a 16 x 16 conv tile) -- must hold +0 before the stem runs; every other
+// cell is written by a plain store of the one tile that holds its whole window.  Zeroing just those cells (23 % of the
+// map: whole rows y % 8 == 0, and every eighth pixel of the other rows) replaces the hipMemsetAsync of the whole map
+// (round 3: a 29 us fill launch per sub-batch at VGA x 32).  One workgroup per pooled row; out = [n, Hp, Wp, 64] floats.
+__global__ __launch_bounds__(256) void stem_border_clear_kernel(float4* out, int Hp, int Wp) {
+  const int row = blockIdx.x;                 // frame * Hp + y
+  const int y = row % Hp;
+  float4* p = out + (size_t)row * Wp * 16;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((y & 7) == 0) {
+    for (int i = threadIdx.x; i < Wp * 16; i += 256) p[i] = z;
+  } else {
+    const int n = ((Wp + 7) / 8) * 16;        // pixels 0, 8, 16, ...: 16 float4 each
+    for (int i = threadIdx.x; i < n; i += 256) p[(i >> 4) * 128 + (i & 15)] = z;
+  }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   constexpr int KREAL = CIN * 49, KG = (KREAL + 7) / 8;  // 147 -> 19 groups of 8; 49 -> 7
