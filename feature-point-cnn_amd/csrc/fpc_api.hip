@@ -164,11 +164,17 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
   X(W36_C128_4x4, 2, 4, 4) \
   X(W36_C128_2x8, 2, 2, 8)
 
+// W36DKIND(name, TYT, TXT): wblock36_dust_kernel -- the 64-channel instance + the detector's 65th channel on the VALU
+#define FPC_W36D_KINDS(X) \
+  X(W36_C65_4x4, 4, 4)    \
+  X(W36_C65_2x8, 2, 8)
+
 enum WKind {
 #define X(name, ...) WK_##name,
   FPC_WBLOCK_KINDS(X)
   FPC_W16_KINDS(X)
   FPC_W36_KINDS(X)
+  FPC_W36D_KINDS(X)
 #undef X
       WK_COUNT
 };
@@ -184,6 +190,7 @@ struct WKindInfo {
   int threads;           // workgroup size (512; generation 3: 256)
   const void* fn;
   void (*launch)(const WBlockArgs&, dim3, hipStream_t);
+  bool dust = false;     // generation 3: the 65-channel (64 + dustbin) instance
 };
 
 #define X(name, KC, NBT, CMID)                                                                            \
@@ -207,6 +214,13 @@ FPC_W16_KINDS(X)
   }
 FPC_W36_KINDS(X)
 #undef X
+#define X(name, TYT, TXT)                                                                                  \
+  static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
+    constexpr int lds = W36Cfg<1, TYT, TXT, true>::LDS_BYTES;                                             \
+    hipLaunchKernelGGL((wblock36_dust_kernel<TYT, TXT>), grid, dim3(256), lds, st, a);                    \
+  }
+FPC_W36D_KINDS(X)
+#undef X
 
 static const WKindInfo g_wkinds[WK_COUNT] = {
 #define X(name, KC, NBT, CMID)                                                                            \
@@ -223,6 +237,11 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
   {#name, "wblock36_kernel<" #NB ", " #TYT ", " #TXT ">", 3, 16, 2 * NB, 64 * NB,                          \
    W36Cfg<NB, TYT, TXT>::LDS_BYTES, 4 * NB, 4 * TYT, 4 * TXT, 256, (const void*)wblock36_kernel<NB, TYT, TXT>, launchw_##name},
     FPC_W36_KINDS(X)
+#undef X
+#define X(name, TYT, TXT)                                                                                 \
+  {#name, "wblock36_dust_kernel<" #TYT ", " #TXT ">", 3, 16, 2, 64,                                        \
+   W36Cfg<1, TYT, TXT, true>::LDS_BYTES, 4, 4 * TYT, 4 * TXT, 256, (const void*)wblock36_dust_kernel<TYT, TXT>, launchw_##name, true},
+    FPC_W36D_KINDS(X)
 #undef X
 };
 
@@ -246,6 +265,7 @@ static bool w36_fits(int B, int H, int W, int cs_in, int cs_out) {
 // Generation 3: the arrangement of the 16 Winograd tiles (4 x 4 or 2 x 8) that covers the map with fewer tiles
 static WKind w36_kind(int cout, int H, int W) {
   const int t44 = ((H + 15) / 16) * ((W + 15) / 16), t28 = ((H + 7) / 8) * ((W + 31) / 32);
+  if (cout == 65) return t28 < t44 ? WK_W36_C65_2x8 : WK_W36_C65_4x4;
   if (cout == 64) return t28 < t44 ? WK_W36_C64_2x8 : WK_W36_C64_4x4;
   return t28 < t44 ? WK_W36_C128_2x8 : WK_W36_C128_4x4;
 }
@@ -403,6 +423,7 @@ struct fpc_ctx {
 #endif
   bool winograd_in1 = true;          // descriptor.layer_in.1 (256 ch): conv-only Winograd x2 + 1x1 (FPC_WINOGRAD_IN1=0: fused direct block)
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
+  bool winograd_det_gen3 = true;     // ... on wblock36_dust_kernel in batch calls (FPC_PLAN_DETECTOR_GEN1 / FPC_WINOGRAD_DET_GEN=1: round 1's kernel)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool latency_tiles = true;         // calls of a few frames run the 128-channel Winograd blocks on 4 x 16 tiles (FPC_LATENCY_TILES=0: 8 x 16)
   int winograd_gen = 3;              // 64- and 128-channel Winograd layers on wblock36_kernel (3: F(4x4,3x3)), wblock16_kernel (2) or wblock_mfma_kernel (1; FPC_WINOGRAD_GEN)
@@ -720,7 +741,16 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   a.x = s.x;
   a.csx = s.csx;
   a.nchunk = s.cin_pad / k.KC;
-  if (s.cin_pad % k.KC) { c->plan_error = true; return; }
+  a.dust = nullptr;
+  a.dust_in = 0;
+  if (k.dust) {
+    // the detector's 65 channels: 64 on the MFMAs (this instance's 4 channel groups), channel 64 beside them (W36Dust).
+    // Input: 64 k channels through the chunk loop (+ a projection over them), or 65 = 4 chunks + input channel 64
+    // (detector.layer.1, identity shortcut).
+    if (s.cout != 65 || !(s.cin == 65 ? !s.proj : (s.cin == s.cin_pad && s.cin_pad % 64 == 0 && s.cin_pad <= 256))) { c->plan_error = true; return; }
+    a.dust_in = s.cin == 65;
+    a.nchunk = a.dust_in ? 4 : s.cin_pad / 16;
+  } else if (s.cin_pad % k.KC) { c->plan_error = true; return; }
   a.H = s.H;
   a.W = s.W;
   a.k8_h = k.CMID / 8;
@@ -745,10 +775,23 @@ static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_of
   else *blob_off += ((size_t)(a.k8_h + a.k8_x) + 2) * k.NBT * 64 * 4;
   cw.b2_off = *blob_off;
   *blob_off += (size_t)k.NBT * 32;
+  if (k.dust) {
+    cw.w_off[2] = *blob_off;
+    *blob_off += (size_t)W36Dust::floats(a.nchunk);
+  }
   op.flops_per_frame = 2.0 * s.H * s.W * s.cout * ((double)s.cin * 9 + s.cout + (s.proj ? s.cin : 0));
   // 16 (36) GEMMs over the tile's Winograd tiles instead of 9 taps over its pixels; then the 1x1 on its pixels
   op.mfma_flops_per_frame = wkind_mfma_flops(k, a.tiles_x * a.tiles_y, a.nchunk, a.k8_h + a.k8_x);
+  if (k.dust && a.dust_in) op.mfma_flops_per_frame += 2.0 * a.tiles_x * a.tiles_y * 64.0 * 36 * 16 * 4;   // input channel 64: one K = 4 MFMA per position
   op.bytes_per_frame = 4.0 * ((double)s.cin * s.H * s.W + (double)s.cout * s.H * s.W);
+  if (k.dust) {
+    // calls of a few frames keep the round-1 instance (its own fragments), as the 64- / 128-channel layers keep generation 2
+    op.when = c->latency_tiles ? 2 : 0;
+    c->ops.push_back(op);
+    c->convw.push_back(cw);
+    if (c->latency_tiles) add_wblock(c, s, s.cin == 65 ? WK_W816_K24_C72 : WK_W816_K32_C72, blob_off, true);
+    return;
+  }
   if (k.gen == 3 && c->latency_tiles) {
     // Generation 3's tile is 256 pixels: a frame has 20 of them at 60 x 80, and the latency of a single frame's layer is
     // one tile's time.  Calls of a few frames keep generation 2 (its own fragments: 16 positions instead of 36), on its
@@ -1393,6 +1436,9 @@ static int build_plan(fpc_ctx* c) {
         const int gen = c->winograd_gen == 3 && (!w36_fits(c->B, Hx, Wx, csx, csy) || (proj && cinp % 64 != 0)) ? 2 : c->winograd_gen;
         if (cinp % 32 == 0 && cout == 64) wk = gen == 3 ? w36_kind(64, Hx, Wx) : gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
         else if (cinp % 32 == 0 && cout == 128) wk = gen == 3 ? w36_kind(128, Hx, Wx) : gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
+        else if (c->winograd_det && cout == 65 && c->winograd_det_gen3 && c->winograd_gen == 3 && w36_fits(c->B, Hx, Wx, csx, csy) &&
+                 (cin == 65 ? !proj : (cin == cinp && cinp % 64 == 0 && cinp <= 256)))
+          wk = w36_kind(65, Hx, Wx);
         else if (c->winograd_det && cinp % 32 == 0 && coutp == 72) wk = WK_W816_K32_C72;
         else if (c->winograd_det && cinp == 72 && coutp == 72) wk = WK_W816_K24_C72;
       }
@@ -1442,7 +1488,8 @@ static int build_plan(fpc_ctx* c) {
         128, 128, feat, 256, false, false, BK_B620_s1_K64_C128);
   if (c->fuse_blocks) {
     const BlockSpec bs{"detector.layer.0", BK_B620_s1_K64_C72, feat, 256, 128, 128, Hc, Wc, c->d0, 72, 65, 72, true, false};
-    if (c->winograd && c->winograd_det) add_wblock(c, bs, WK_W816_K32_C72, &bo);
+    if (c->winograd && c->winograd_det)
+      add_wblock(c, bs, c->winograd_det_gen3 && c->winograd_gen == 3 && w36_fits(c->B, Hc, Wc, 256, 72) ? w36_kind(65, Hc, Wc) : WK_W816_K32_C72, &bo);
     else add_block(c, bs, &bo);
   } else {  // detector.layer.0: the projection shortcut has K = 128 while conv2 has K = 72 (65 padded):
      // run the shortcut as its own 1x1 and add it as the residual of conv2
@@ -1579,6 +1626,7 @@ postproc:
       op.wargs.b1 = c->blob + c->convw[i].b_off;
       op.wargs.w2 = reinterpret_cast<const float4*>(c->blob + c->convw[i].w_off[1]);
       op.wargs.b2 = c->blob + c->convw[i].b2_off;
+      op.wargs.dust = g_wkinds[op.wkind].dust ? c->blob + c->convw[i].w_off[2] : nullptr;
     }
     if (op.type == OP_BF16) {
       op.fargs.w1 = reinterpret_cast<const uint4*>(c->blob + c->convw[i].w_off[0]);
@@ -1906,7 +1954,7 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
                   d4[j] = (n < co && cc < ci) ? (float)U[((size_t)n * ci + cc) * 16 + xi] : 0.f;
                 }
               }
-      for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)f1.t[n];
+      for (int n = 0; n < std::min(co, nbt * 32); ++n) blob[cw.b_off + n] = (float)f1.t[n];
       std::vector<PackSource> srcs;
       srcs.push_back({co, a.k8_h * 8, 1, [&](int n, int c_, int) { return (double)w2[(size_t)n * co + c_]; }, &f2.s});
       std::vector<double> bias(f2.t);
@@ -1923,7 +1971,27 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
         std::vector<float> frag = pack_conv(srcs, co, nbt, 8);
         memcpy(blob.data() + cw.w_off[1], frag.data(), frag.size() * sizeof(float));
       }
-      for (int n = 0; n < co; ++n) blob[cw.b2_off + n] = (float)bias[n];
+      for (int n = 0; n < std::min(co, nbt * 32); ++n) blob[cw.b2_off + n] = (float)bias[n];
+      if (k.dust) {   // the 65th channel's weights (W36Dust, wblock36_mfma.h)
+        float* d = blob.data() + cw.w_off[2];
+        for (int n = 0; n < 64; ++n) d[W36Dust::W2ROW + n] = (float)((double)w2[(size_t)n * co + 64] * f2.s[n]);
+        for (int kk = 0; kk < 65; ++kk) d[W36Dust::W2COL + kk] = (float)((double)w2[(size_t)64 * co + kk] * f2.s[64]);
+        if (wp)
+          for (int cc = 0; cc < ci; ++cc) d[W36Dust::WPCOL + cc] = (float)((double)wp[(size_t)64 * ci + cc] * fp.s[64]);
+        d[W36Dust::B1] = (float)f1.t[64];
+        d[W36Dust::B2] = (float)bias[64];
+        if (a.dust_in) {
+          for (int pp = 0; pp < 36; ++pp) d[W36Dust::UIN64 + pp] = (float)U[((size_t)64 * ci + 64) * 36 + pp];
+          for (int cg = 0; cg < 4; ++cg)
+            for (int pp = 0; pp < 36; ++pp)
+              for (int n16 = 0; n16 < 16; ++n16)
+                d[W36Dust::UIN + (cg * 36 + pp) * 16 + n16] = (float)U[((size_t)(16 * cg + n16) * ci + 64) * 36 + pp];
+        }
+        for (int ch = 0; ch < a.nchunk; ++ch)
+          for (int pp = 0; pp < 36; ++pp)
+            for (int kk = 0; kk < 16; ++kk)
+              d[W36Dust::UOUT + (ch * 36 + pp) * 16 + kk] = 16 * ch + kk < ci ? (float)U[((size_t)64 * ci + 16 * ch + kk) * 36 + pp] : 0.f;
+      }
       continue;
     }
     if (op.type == OP_BF16) {
@@ -2641,6 +2709,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     const unsigned pf = cfg->plan_flags;
     c->fuse_blocks = !(pf & FPC_PLAN_NO_FUSED_BLOCKS);
     c->guard_zones = (pf & FPC_PLAN_GUARD_ZONES) != 0;
+    c->winograd_det_gen3 = !(pf & FPC_PLAN_DETECTOR_GEN1);
+    if (const char* e = getenv("FPC_WINOGRAD_DET_GEN")) c->winograd_det_gen3 = atoi(e) >= 3;
     c->winograd = !(pf & FPC_PLAN_NO_WINOGRAD);
     c->winograd_det = !(pf & FPC_PLAN_NO_WINOGRAD_DETECTOR);
     c->winograd_in1 = !(pf & FPC_PLAN_NO_WINOGRAD_LAYER_IN1);

@@ -51,9 +51,25 @@ __device__ __forceinline__ void fpc_static_for(F&& f) {
   fpc_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int NB_, int TYT_, int TXT_>
+// Layout of the dust block (floats) a DUST instance reads through WBlockArgs::dust -- the 65th ("dustbin") channel of the
+// detector's blocks, packed by fpc_api.hip (pack_w36_dust):
+//   W2ROW[64]   conv2 weight of h[64] into outputs 0..63            (x folded-BN scale of the output)
+//   W2COL[80]   conv2 weights of h[0..64] into output 64 (65 real)
+//   WPCOL[256]  projection weights of x[0..cin) into output 64
+//   B1, B2      folded biases of h[64] / out[64] (projection's bias included)
+//   UIN64[36]   Winograd-domain filter  in 64 -> out 64
+//   UIN[4][36][16]   ... in 64 -> out n (channel group, position, n & 15)
+//   UOUT[nchunk][36][16]  ... in 16 c + k -> out 64
+struct W36Dust {
+  static constexpr int W2ROW = 0, W2COL = 64, WPCOL = 144, B1 = 400, B2 = 401, UIN64 = 404, UIN = 448, UOUT = 448 + 4 * 36 * 16;
+  static constexpr int floats(int nchunk) { return UOUT + nchunk * 36 * 16; }
+};
+
+template <int NB_, int TYT_, int TXT_, bool DUST_ = false>
 struct W36Cfg {
   static constexpr int NB = NB_, TYT = TYT_, TXT = TXT_;
+  static constexpr bool DUST = DUST_;
+  static_assert(!DUST || NB == 1, "the dust channel rides on the 64-channel instance");
   static_assert(TYT * TXT == 16 && (TYT == 4 || TYT == 2), "16 Winograd tiles per workgroup tile: 4 x 4 or 2 x 8");
   static_assert(NB == 1 || NB == 2, "a wave owns 16 or 32 output channels");
   static constexpr int NT = 256, NPOS = 36, KC = 16;
@@ -73,7 +89,12 @@ struct W36Cfg {
   static constexpr int RX = 128 + 8;                                // x staging row (up to 128 channels per pass)
   static constexpr int HPX = 128;                                   // pixels of one half
   static constexpr int T_FLOATS = HPX * (RH > RX ? RH : RX);
-  static constexpr int LDS_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
+  static constexpr int BASE_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
+  // DUST: W2COL | WPCOL (336), UIN (2304), V of input channel 64 [36][16], M of output channel 64 [36][16], the halo of input
+  // channel 64 (one 16-byte slot per pixel by LDS-DMA: HIT64 requests per thread)
+  static constexpr int HIT64 = (NHALO + NT - 1) / NT;
+  static constexpr int D_COL = BASE_FLOATS, D_UIN = D_COL + 336, D_V64 = D_UIN + 2304, D_M64 = D_V64 + 576, D_H64 = D_M64 + 576;
+  static constexpr int LDS_FLOATS = DUST ? D_H64 + HIT64 * NT * 4 : BASE_FLOATS;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   // one ring step = TWO positions: 16 MFMAs (NB = 2: two positions x two channel blocks, four accumulators in turn) or 8
@@ -82,7 +103,9 @@ struct W36Cfg {
   // Ring depth in steps (8 NB registers each; must divide STEPS so that slot indices are compile-time constants across
   // chunks).  vmcnt retires in order: a fragment requested after the chunk's halo request waits for it, so the ring has
   // to hold the fragments of that whole latency (RING - 1 steps of 256 NB cycles).
-  static constexpr int RING = NB == 2 ? 6 : 18;
+  // (DUST: the 65th channel's filter quads and V rows need 60 of the 256 architectural VGPRs the 18-step ring fills: 9 steps,
+  // 2 k cycles of cover like the 128-channel instance's)
+  static constexpr int RING = NB == 2 ? 6 : DUST ? 9 : 18;
   static_assert(STEPS % RING == 0, "ring slots must line up across chunks");
   static constexpr int PAG = NB == 2 ? 30 : 36;                     // positions whose accumulators live in AGPRs (240 of 256; the other 48 registers in VGPRs)
   static constexpr int WPAD = 36;                                   // zero POSITIONS behind every channel group's stream (>= 2 RING)
@@ -159,9 +182,9 @@ __device__ __forceinline__ void fpc_mfma_step16(f32x4& c00, f32x4& c01, f32x4& c
 #undef FPC_MFMA16_IN
 }
 
-template <int NB, int TYT, int TXT>
-__global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
-  using C = W36Cfg<NB, TYT, TXT>;
+template <int NB, int TYT, int TXT, bool DUST>
+__device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
+  using C = W36Cfg<NB, TYT, TXT, DUST>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HW = C::HW, HH = C::HH, HROW = C::HROW, HIT = C::HIT;
   constexpr int N = C::N, RH = C::RH, RX = C::RX, RING = C::RING, STEPS = C::STEPS, HPX = C::HPX;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -197,6 +220,7 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
   // check): one VALU instruction per slot and chunk (the first version recomputed rows, columns and flags per chunk: 13
   // instructions per element in the MFMA stream, and the VALU excludes the MFMA).
   int okoff[HIT];
+  int okoff64[DUST ? C::HIT64 : 1];            // DUST: the same for input channel 64, one slot per halo pixel
   struct TilePos { int b, ty, tx, live; };
   auto tile_pos = [&](int wg) {                          // uniform (SALU) arithmetic: once per tile, not per chunk
     TilePos q;
@@ -227,6 +251,16 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       const int off = (((hy - 1) * a.W + (hx - 1)) * a.csx + c4 * 4) * 4;
       okoff[i] = ok ? off : W36_MARKER;
     }
+    if constexpr (DUST) {
+#pragma unroll
+      for (int i = 0; i < C::HIT64; ++i) {
+        const int pix = tl + i * NT;
+        const int hy = HW == 18 ? (pix * 3641) >> 16 : (pix * 1928) >> 16;
+        const int hx = pix - hy * HW;
+        const bool ok = ((unsigned)(iy0 + hy) < (unsigned)hlim) & ((unsigned)(ix0 + hx) < (unsigned)a.W) & (hy < HH) & (a.dust_in != 0);
+        okoff64[i] = ok ? (((hy - 1) * a.W + (hx - 1)) * a.csx + 64) * 4 : W36_MARKER;
+      }
+    }
   };
   auto load_halo = [&](int base, int hoff) {             // base: halo_base of the tile + 64 bytes per chunk; hoff: the halo buffer (floats)
 #pragma unroll
@@ -235,6 +269,16 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(okoff[i]), "s"(base));
       // (the instruction's LDS address is M0 + 16 lane: M0 = this wave's 64 slots of request i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(lds + hoff + (i * NT + wave * 64) * 4), 16, voff, 0, 0, 0);
+    }
+  };
+  auto load_halo64 = [&](int base) {                     // DUST: channels 64..67 of the tile's halo pixels -> D_H64 [pixel][4]
+    if constexpr (DUST) {
+#pragma unroll
+      for (int i = 0; i < C::HIT64; ++i) {
+        int voff;
+        asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(okoff64[i]), "s"(base));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(lds + C::D_H64 + (i * NT + wave * 64) * 4), 16, voff, 0, 0, 0);
+      }
     }
   };
   // the transform item of this thread: Winograd tile wt (0..15), channel ch (0..15) of the chunk; V row m = Tinv(wt)
@@ -295,10 +339,38 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
     return r;
   };
 
+  // ---------------------------------------------------------------- DUST: the 65th output (and input) channel beside the 64 on the MFMAs
+  // Output channel 64 of the 3x3 is a dot product per (position, Winograd tile) and chunk IN THE WINOGRAD DOMAIN -- the V the
+  // MFMAs read is in LDS anyway: 576 items of 16 products per chunk, three per thread (v_fma at the fp32 MFMA's rate, where
+  // a fifth 16-channel group would issue 36 more MFMAs per wave and chunk for one real channel in sixteen):
+  //   items A, B: position tid >> 3 (0..31), V rows m = 2 (tid & 7), + 1;   item C: position 32 + ((tid >> 4) & 3), row tid & 15
+  //   (C is computed by every wave -- no wave-dependent branch in the MFMA stream -- and written by wave 0)
+  // A V row's four channel quads lie XOR-swizzled by 2 (m >> 3): the filter quads are LOADED in that order.
+  const int d_pos = tid >> 3, d_m0 = 2 * (tid & 7), d_pos2 = 32 + ((tid >> 4) & 3), d_m2 = tid & 15;
+  [[maybe_unused]] int d_va = d_pos * 64 + d_m0 * 4, d_vc = d_pos2 * 64 + d_m2 * 4;                 // float4 index of V row (pos, m), quad slot 0
+  [[maybe_unused]] int d_ua[4], d_uc[4];                                                           // byte offsets of the filter quads in slot order
+  // (the filter quads of output channel 64 by chunk; a DUST-less instance points it at the input and never uses it)
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t drsrc =
+      DUST ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dust + W36Dust::UOUT), 0, nchunk * 36 * 16 * 4, 0x00020000) : xrsrc;
+  [[maybe_unused]] f32x4 du[2][4];
+  [[maybe_unused]] float dacc[3];
+  if constexpr (DUST) {
+    const int swa = 2 * ((tid & 7) >> 2), swc = 2 * ((tid & 15) >> 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      d_ua[j] = (d_pos * 16 + 4 * (j ^ swa)) * 4;
+      d_uc[j] = (d_pos2 * 16 + 4 * (j ^ swc)) * 4;
+    }
+    // once per workgroup: W2COL | WPCOL and UIN into LDS (read back as broadcasts / MFMA operands at every tile's end)
+    for (int i = tid; i < 336 / 4; i += NT) lds4[C::D_COL / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::W2COL)[i];
+    for (int i = tid; i < 2304 / 4; i += NT) lds4[C::D_UIN / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::UIN)[i];
+  }
+
   // ---------------------------------------------------------------- pipeline fill for the first tile
   TilePos pos_cur = tile_pos(wg_first);
   int base_cur = halo_base(pos_cur);
   halo_tile(pos_cur);
+  load_halo64(base_cur);
   load_halo(base_cur, C::OFF_H0);
   load_halo(base_cur + 64, C::OFF_H1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HIT) : "memory");      // chunk 0 has landed (this wave's part of it)
@@ -342,6 +414,11 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
     BF bq[RING];
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) bq[i] = ldb(i);
+    if constexpr (DUST) {
+      float zf = 0.f;
+      asm volatile("" : "+v"(zf));
+      dacc[0] = dacc[1] = dacc[2] = zf;
+    }
 
     // ---------------------------------------------------------------- phase 1: 36 GEMMs per chunk, input side of the next chunks in between
     auto chunk_body = [&](auto PAR, const int c) {
@@ -354,6 +431,9 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       const int l_base = (nxt ? base_next : base_cur) + (nxt ? c3 - nchunk : c3) * 64;
       int ao = aoff4 + VB_OFF / 4, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
       asm volatile("" : "+v"(ao), "+v"(trd_c), "+v"(twr_c));
+      [[maybe_unused]] int dva = d_va + VB_OFF / 4, dvc = d_vc + VB_OFF / 4;      // DUST: V rows of this thread's items, this chunk's buffer
+      [[maybe_unused]] f32x4 dv[4];
+      if constexpr (DUST) asm volatile("" : "+v"(dva), "+v"(dvc));
       // A operand: two register sets, the next step's read while this step's MFMAs run
       constexpr int AQ = 2;                     // positions per step
       f32x4 ac[2][AQ];
@@ -391,6 +471,37 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           } else if (slot >= 15 && slot < 33) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int e = (slot - 15) * 2 + k; t_write(twr_c, e / 6, e % 6); }
+          }
+          if constexpr (DUST) {
+            // output channel 64: the chunk's filter quads are requested early (L2, a chunk's worth of cover), the V rows are
+            // read one item at a time and multiplied a step later
+            auto dfma = [&](float& s_, const f32x4 (&u)[4]) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_ = __builtin_fmaf(dv[j][e], u[j][e], s_);
+            };
+            auto dread = [&](int at) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dv[j] = lds4[at + j];
+            };
+            if (slot == 3) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                du[0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_ua[j], c * (36 * 16 * 4), 0));
+                du[1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_uc[j], c * (36 * 16 * 4), 0));
+              }
+            } else if (slot == 29) {
+              dread(dva);
+            } else if (slot == 30) {
+              dfma(dacc[0], du[0]);
+              dread(dva + 4);
+            } else if (slot == 31) {
+              dfma(dacc[1], du[0]);
+              dread(dvc);
+            } else if (slot == 32) {
+              dfma(dacc[2], du[1]);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -434,6 +545,90 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
     // (the last MFMAs' results are read by VALU instructions below: a wait the compiler manages for its own MFMAs and
     // cannot see through the asm -- 8 passes need at most 18 wait states)
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+
+    if constexpr (DUST) {
+      // (every per-thread index below comes from a copy of the thread id the optimiser cannot see through: computed from
+      // threadIdx.x they are invariants of the persistent tile loop, hoisted in front of it -- a hundred registers -- and
+      // spilled: the first build of this instance had 101 scratch stores in its prologue)
+      int tid_d = tid;
+      asm volatile("" : "+v"(tid_d));
+      const int lane_d = tid_d & 63, p_ab = tid_d >> 3, m_ab = 2 * (tid_d & 7), p_c = 32 + ((tid_d >> 4) & 3), m_c = tid_d & 15;
+      if (a.dust_in) {
+        // INPUT channel 64 (detector.layer.1): its halo arrived at the tile's start (D_H64, 16 bytes per pixel); threads
+        // 0..15 transform the 6x6 patch of one Winograd tile each into V64 [position][row m] ...
+        if (tid_d < 16) {
+          const int rd = C::D_H64 + ((4 * (tid_d / TXT)) * HW + 4 * (tid_d % TXT)) * 4;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) td[i][j] = lds[rd + (i * HW + j) * 4];
+          t_burst();
+          const int mrow = ((tid_d & 7) >> 1) * 4 + (tid_d >> 3) * 2 + (tid_d & 1);
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) lds[C::D_V64 + (i * 6 + j) * 16 + mrow] = td[i][j];
+        }
+        FPC_LDS_BARRIER();
+        // ... and every wave adds its 16 output channels' share: ONE MFMA per position, K = 4 of which k = 0 is real (the
+        // A operand of lanes 16..63 is zero, so their B operand only has to be finite)
+        {
+          const int va = C::D_V64 + (lane_d & 15), ub = C::D_UIN + wave * 576 + (lane_d & 15);
+#pragma unroll
+          for (int p = 0; p < 36; ++p) {
+            float av = lds[va + p * 16];
+            const float bv = lds[ub + p * 16];
+            av = lane_d < 16 ? av : 0.f;
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[p][0], 0, 0, 0);
+          }
+        }
+        // in 64 -> out 64
+        dacc[0] = __builtin_fmaf(lds[C::D_V64 + p_ab * 16 + m_ab], a.dust[W36Dust::UIN64 + p_ab], dacc[0]);
+        dacc[1] = __builtin_fmaf(lds[C::D_V64 + p_ab * 16 + m_ab + 1], a.dust[W36Dust::UIN64 + p_ab], dacc[1]);
+        dacc[2] = __builtin_fmaf(lds[C::D_V64 + p_c * 16 + m_c], a.dust[W36Dust::UIN64 + p_c], dacc[2]);
+      }
+      lds[C::D_M64 + p_ab * 16 + m_ab] = dacc[0];
+      lds[C::D_M64 + p_ab * 16 + m_ab + 1] = dacc[1];
+      if (wave == 0) lds[C::D_M64 + p_c * 16 + m_c] = dacc[2];
+      FPC_LDS_BARRIER();
+      load_halo64(base_next);            // D_H64 has been read: the next tile's input channel 64 (okoff64 is the next tile's by now)
+      if (tid_d < 16) {
+        // Y = A^T M A + bias, ReLU for output channel 64 of Winograd tile T(m), m = tid
+        float mm[36];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) mm[p] = lds[C::D_M64 + p * 16 + tid_d];
+        const float bias1 = a.dust[W36Dust::B1];
+        float tt[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float m0 = mm[0 * 6 + j], m1 = mm[1 * 6 + j], m2 = mm[2 * 6 + j], m3 = mm[3 * 6 + j], m4 = mm[4 * 6 + j], m5 = mm[5 * 6 + j];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          tt[0][j] = m0 + s12 + s34;
+          tt[1][j] = __builtin_fmaf(2.f, d34, d12);
+          tt[2][j] = __builtin_fmaf(4.f, s34, s12);
+          tt[3][j] = __builtin_fmaf(8.f, d34, d12) + m5;
+        }
+        const int T = 8 * ((tid_d >> 1) & 1) + 2 * (tid_d >> 2) + (tid_d & 1), th = T & 7;
+        const int hb = C::OFF_H0 + ((4 * (th / TXT)) * TW + 4 * (th % TXT)) * RH + 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float m0 = tt[i][0], m1 = tt[i][1], m2 = tt[i][2], m3 = tt[i][3], m4 = tt[i][4], m5 = tt[i][5];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          float yv[4];
+          yv[0] = m0 + s12 + s34 + bias1;
+          yv[1] = __builtin_fmaf(2.f, d34, d12) + bias1;
+          yv[2] = __builtin_fmaf(4.f, s34, s12) + bias1;
+          yv[3] = __builtin_fmaf(8.f, d34, d12) + m5 + bias1;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            // a first-half tile goes to h at once; a second-half tile's values wait in D_V64 (read, by now, for this tile;
+            // registers held them at first -- and were spilled to scratch across the first half's GEMMs)
+            const float v = yv[jj] > 0.f ? yv[jj] : 0.f;
+            lds[T < 8 ? hb + (i * TW + jj) * RH : C::D_V64 + tid_d * 16 + i * 4 + jj] = v;
+          }
+        }
+      }
+    }
 
     // ---------------------------------------------------------------- output transform in registers; then the two halves of the tile
     int tid_t = tid;
@@ -509,9 +704,41 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) lds[hw_base[rr] + 16 * nb + (i * TW + jj) * RH] = yh1[nb][rr][i * 4 + jj];
+        if constexpr (DUST) {
+          const int T = 8 * ((tid_t >> 1) & 1) + 2 * (tid_t >> 2) + (tid_t & 1), th = T & 7;
+          if (tid_t < 16 && T >= 8) {
+            const int hb = C::OFF_H0 + ((4 * (th / TXT)) * TW + 4 * (th % TXT)) * RH + 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) lds[hb + (i * TW + jj) * RH] = lds[C::D_V64 + tid_t * 16 + i * 4 + jj];
+          }
+        }
       }
       FPC_LDS_BARRIER();
       if (wg == wg_stamp && half == 0) { FPC_STAMP(2) }
+      // DUST: output channel 64 of the half's 128 pixels -- two threads per pixel (K halves), a dot product over h here, over
+      // the projection's x in its passes below; and h[64]'s share of outputs 0..63 as the INITIAL VALUE of their accumulators
+      [[maybe_unused]] float dsum = 0.f, dw2r = 0.f;
+      [[maybe_unused]] float dhv[8][4];
+      [[maybe_unused]] const int dpx = tid_t >> 1, dhf = tid_t & 1, drow = dpx / TW, dcol = dpx % TW;
+      if constexpr (DUST) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 hq = lds4[TL4 + dpx * (RH / 4) + 8 * dhf + j], wq = lds4[C::D_COL / 4 + 8 * dhf + j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dsum = __builtin_fmaf(hq[e], wq[e], dsum);
+        }
+        {
+          const float h64 = lds[C::OFF_H0 + dpx * RH + 64], w64 = lds[C::D_COL + 64];
+          dsum = dhf ? __builtin_fmaf(h64, w64, dsum) : dsum;
+        }
+        dw2r = a.dust[W36Dust::W2ROW + 16 * wave + (lane_t & 15)];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhv[mb][r] = lds[C::OFF_H0 + (16 * mb + 4 * (lane_t >> 4) + r) * RH + 64];
+      }
       // output float4 i of this thread: LDS [m0 + PPI i][c4t], global row i / CPR, column step i % CPR
       int erd = TL4 + m0 * (RH / 4) + c4t;
       asm volatile("" : "+v"(erd));
@@ -610,6 +837,12 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{zf, zf, zf, zf};
+          if constexpr (DUST) {
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc2[mb][0][r] = dhv[mb][r] * dw2r;
+          }
         }
         gemm_over(RH / 4, KH, 0);
         if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
@@ -624,6 +857,14 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
           }
           FPC_LDS_BARRIER();
           if (pass + 1 < npass) load_x(pass + 1);
+          if constexpr (DUST) {      // x[px][64 dhf .. + 63] of this pass against the projection's column for output 64
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const f32x4 xq = lds4[TL4 + dpx * (RX / 4) + 16 * dhf + j], wq = lds4[C::D_COL / 4 + 20 + pass * 32 + 16 * dhf + j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dsum = __builtin_fmaf(xq[e], wq[e], dsum);
+            }
+          }
           const int steps = min(8, a.k8_x / 2 - pass * 8);   // 16-channel steps of this pass: 4 or 8
           gemm_over(RX / 4, steps, KH + pass * 8);
         }
@@ -642,6 +883,14 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
             for (int nb = 0; nb < NB; ++nb)
               acc2[mb][nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xl + so + 64 * nb, 0, 0));
           }
+        if constexpr (DUST) {
+          const float x64 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ((drow * a.W + dcol) * a.csx + 64) * 4, xbase, 0));
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[mb][0][r] = __builtin_fmaf(dhv[mb][r], dw2r, acc2[mb][0][r]);
+          dsum += dhf ? 0.f : x64;
+        }
         gemm_over(RH / 4, KH, 0);
         if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
       }
@@ -664,12 +913,36 @@ __global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
       }
       FPC_LDS_BARRIER();
       store_out();
+      if constexpr (DUST) {
+        // channels 64..71 of the pixel: (out[64], 0, 0, 0) from the pair's first thread, zeros from the second (pad
+        // channels are exact zeros: the next layer's 16-byte slot of input channel 64 relies on it)
+        float tot = dsum + __shfl_xor(dsum, 1);
+        tot += a.dust[W36Dust::B2];
+        tot = tot > 0.f ? tot : 0.f;
+        const bool ok = (drow < rows_valid) & (x0 + dcol < a.W);
+        const int doff = ok ? ((drow * a.W + dcol) * a.cso + 64 + 4 * dhf) * 4 : W36_MARKER;
+        int voff;
+        asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(doff), "s"(obase));
+        const f32x4 v = {dhf ? 0.f : tot, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), orsrc, voff, 0, 0);
+      }
       if (wg == wg_stamp && half == 0) { FPC_STAMP(5) }
       FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
     }  // halves
     pos_cur = pos_next;
     base_cur = base_next;
   }  // persistent tile loop
+}
+
+template <int NB, int TYT, int TXT>
+__global__ __launch_bounds__(256, 1) void wblock36_kernel(const WBlockArgs a) {
+  wblock36_body<NB, TYT, TXT, false>(a);
+}
+
+// The detector's blocks: 64 channels as wblock36_kernel<1, ...> + the 65th ("dustbin") channel beside them (W36Dust).
+template <int TYT, int TXT>
+__global__ __launch_bounds__(256, 1) void wblock36_dust_kernel(const WBlockArgs a) {
+  wblock36_body<1, TYT, TXT, true>(a);
 }
 
 }  // namespace fpc

@@ -37,6 +37,8 @@ struct WBlockArgs {
   unsigned x_bytes;      // wblock16_kernel: bytes from `x` to the end of the input tensor's frames of this launch (buffer descriptor range)
   int conv_only;         // 1: stop after h = relu(conv3x3(x) + b1) and store it (a plain Conv2d + bias/BN + ReLU:
                          // the layers of the C++ network, conv1 of a block too wide to fuse); w2 / b2 unused
+  const float* dust;     // wblock36_kernel<..., DUST>: the 65th channel's weights (W36Dust, wblock36_mfma.h); else unused
+  int dust_in;           // ... 1: the INPUT has a 65th channel too (x[..][64]: detector.layer.1), not covered by nchunk
 #ifdef FPC_DIAG
   unsigned long long* stamps;
 #endif

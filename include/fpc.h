@@ -109,6 +109,7 @@ enum {
   FPC_PLAN_NMS_ONE_WORKGROUP = 1 << 12,    /* survivors of a frame sorted by one workgroup, not in slices (FPC_NMS_CHUNKED=0)   */
   FPC_PLAN_NO_FUSED_SOFTMAX = 1 << 13,     /* FPC_BF16: exp-softmax as its own launch in fpc_detect too  (FPC_FUSE_SOFTMAX=0)   */
   FPC_PLAN_WINOGRAD_GEN2 = 1 << 14,        /* round-2 Winograd kernel, F(2x2,3x3), instead of F(4x4,3x3) (FPC_WINOGRAD_GEN=2)   */
+  FPC_PLAN_DETECTOR_GEN1 = 1 << 16,        /* the detector's 65-channel blocks on round 1's kernel in batch calls too       (FPC_WINOGRAD_DET_GEN=1) */
   FPC_PLAN_GUARD_ZONES = 1 << 15           /* TEST FACILITY: 64 KiB of a canary pattern behind every buffer of the workspace and
                                               2 GiB behind the last one (the workspace grows by that much); fpc_check_guards
                                               counts the words a kernel has overwritten.  Not for production contexts.          */
