@@ -341,26 +341,20 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
 
   // ---------------------------------------------------------------- DUST: the 65th output (and input) channel beside the 64 on the MFMAs
   // Output channel 64 of the 3x3 is a dot product per (position, Winograd tile) and chunk IN THE WINOGRAD DOMAIN -- the V the
-  // MFMAs read is in LDS anyway: 576 items of 16 products per chunk, three per thread (v_fma at the fp32 MFMA's rate, where
-  // a fifth 16-channel group would issue 36 more MFMAs per wave and chunk for one real channel in sixteen):
-  //   items A, B: position tid >> 3 (0..31), V rows m = 2 (tid & 7), + 1;   item C: position 32 + ((tid >> 4) & 3), row tid & 15
-  //   (C is computed by every wave -- no wave-dependent branch in the MFMA stream -- and written by wave 0)
-  // A V row's four channel quads lie XOR-swizzled by 2 (m >> 3): the filter quads are LOADED in that order.
-  const int d_pos = tid >> 3, d_m0 = 2 * (tid & 7), d_pos2 = 32 + ((tid >> 4) & 3), d_m2 = tid & 15;
-  [[maybe_unused]] int d_va = d_pos * 64 + d_m0 * 4, d_vc = d_pos2 * 64 + d_m2 * 4;                 // float4 index of V row (pos, m), quad slot 0
-  [[maybe_unused]] int d_ua[4], d_uc[4];                                                           // byte offsets of the filter quads in slot order
-  // (the filter quads of output channel 64 by chunk; a DUST-less instance points it at the input and never uses it)
+  // MFMAs read is in LDS anyway (v_fma at the fp32 MFMA's rate, where a fifth 16-channel group would issue 36 more MFMAs
+  // per wave and chunk for one real channel in sixteen).  Wave w takes positions w, w + 4, ..., w + 32; its lane l reads
+  // float4 l of a position's V block (row m = l >> 2, quad slot l & 3: the wave reads the block's 1 KB in order, no bank
+  // conflict -- the first mapping, a thread per (position, two rows), hit two bank groups with 64 lanes and cost 28 k cycles
+  // a tile) and keeps one partial sum per position over ITS four channels; the four lanes of a row are added up at the
+  // tile's end.  A row's quads lie XOR-swizzled by 2 (m >> 3): the filter quad is LOADED accordingly.
+  [[maybe_unused]] int d_va = 0, d_ua = 0;
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t drsrc =
       DUST ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dust + W36Dust::UOUT), 0, nchunk * 36 * 16 * 4, 0x00020000) : xrsrc;
-  [[maybe_unused]] f32x4 du[2][4];
-  [[maybe_unused]] float dacc[3];
+  [[maybe_unused]] f32x4 du[9];
+  [[maybe_unused]] float dacc[9];
   if constexpr (DUST) {
-    const int swa = 2 * ((tid & 7) >> 2), swc = 2 * ((tid & 15) >> 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      d_ua[j] = (d_pos * 16 + 4 * (j ^ swa)) * 4;
-      d_uc[j] = (d_pos2 * 16 + 4 * (j ^ swc)) * 4;
-    }
+    d_va = wave * 64 + lane;                                                    // float4 index of (position w, this lane) in a V buffer
+    d_ua = wave * 64 + 16 * ((lane & 3) ^ (2 * (lane >> 5)));                   // byte offset of its filter quad in a chunk's [36][16]
     // once per workgroup: W2COL | WPCOL and UIN into LDS (read back as broadcasts / MFMA operands at every tile's end)
     for (int i = tid; i < 336 / 4; i += NT) lds4[C::D_COL / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::W2COL)[i];
     for (int i = tid; i < 2304 / 4; i += NT) lds4[C::D_UIN / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::UIN)[i];
@@ -417,7 +411,8 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
     if constexpr (DUST) {
       float zf = 0.f;
       asm volatile("" : "+v"(zf));
-      dacc[0] = dacc[1] = dacc[2] = zf;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) dacc[i] = zf;
     }
 
     // ---------------------------------------------------------------- phase 1: 36 GEMMs per chunk, input side of the next chunks in between
@@ -431,9 +426,9 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
       const int l_base = (nxt ? base_next : base_cur) + (nxt ? c3 - nchunk : c3) * 64;
       int ao = aoff4 + VB_OFF / 4, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
       asm volatile("" : "+v"(ao), "+v"(trd_c), "+v"(twr_c));
-      [[maybe_unused]] int dva = d_va + VB_OFF / 4, dvc = d_vc + VB_OFF / 4;      // DUST: V rows of this thread's items, this chunk's buffer
-      [[maybe_unused]] f32x4 dv[4];
-      if constexpr (DUST) asm volatile("" : "+v"(dva), "+v"(dvc));
+      [[maybe_unused]] int dva = d_va + VB_OFF / 4;      // DUST: this lane's float4 of position w, this chunk's buffer
+      [[maybe_unused]] f32x4 dv[3];
+      if constexpr (DUST) asm volatile("" : "+v"(dva));
       // A operand: two register sets, the next step's read while this step's MFMAs run
       constexpr int AQ = 2;                     // positions per step
       f32x4 ac[2][AQ];
@@ -473,34 +468,32 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
             for (int k = 0; k < 2; ++k) { const int e = (slot - 15) * 2 + k; t_write(twr_c, e / 6, e % 6); }
           }
           if constexpr (DUST) {
-            // output channel 64: the chunk's filter quads are requested early (L2, a chunk's worth of cover), the V rows are
-            // read one item at a time and multiplied a step later
-            auto dfma = [&](float& s_, const f32x4 (&u)[4]) {
+            // output channel 64: the chunk's nine filter quads are requested early (L2, most of a chunk of cover); the V
+            // quads are read three positions at a time and multiplied two slots later
+            auto dread = [&](int i0) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s_ = __builtin_fmaf(dv[j][e], u[j][e], s_);
+              for (int k = 0; k < 3; ++k) dv[k] = lds4[dva + (i0 + k) * 256];
             };
-            auto dread = [&](int at) {
+            auto dfma = [&](int i0) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) dv[j] = lds4[at + j];
+              for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dacc[i0 + k] = __builtin_fmaf(dv[k][e], du[i0 + k][e], dacc[i0 + k]);
             };
             if (slot == 3) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                du[0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_ua[j], c * (36 * 16 * 4), 0));
-                du[1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_uc[j], c * (36 * 16 * 4), 0));
-              }
+              for (int i = 0; i < 9; ++i)
+                du[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_ua + i * 256, c * (36 * 16 * 4), 0));
+            } else if (slot == 23) {
+              dread(0);
+            } else if (slot == 25) {
+              dfma(0);
+              dread(3);
+            } else if (slot == 27) {
+              dfma(3);
+              dread(6);
             } else if (slot == 29) {
-              dread(dva);
-            } else if (slot == 30) {
-              dfma(dacc[0], du[0]);
-              dread(dva + 4);
-            } else if (slot == 31) {
-              dfma(dacc[1], du[0]);
-              dread(dvc);
-            } else if (slot == 32) {
-              dfma(dacc[2], du[1]);
+              dfma(6);
             }
           }
         }
@@ -552,7 +545,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
       // spilled: the first build of this instance had 101 scratch stores in its prologue)
       int tid_d = tid;
       asm volatile("" : "+v"(tid_d));
-      const int lane_d = tid_d & 63, p_ab = tid_d >> 3, m_ab = 2 * (tid_d & 7), p_c = 32 + ((tid_d >> 4) & 3), m_c = tid_d & 15;
+      const int lane_d = tid_d & 63;
       if (a.dust_in) {
         // INPUT channel 64 (detector.layer.1): its halo arrived at the tile's start (D_H64, 16 bytes per pixel); threads
         // 0..15 transform the 6x6 patch of one Winograd tile each into V64 [position][row m] ...
@@ -582,14 +575,21 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
             acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[p][0], 0, 0, 0);
           }
         }
-        // in 64 -> out 64
-        dacc[0] = __builtin_fmaf(lds[C::D_V64 + p_ab * 16 + m_ab], a.dust[W36Dust::UIN64 + p_ab], dacc[0]);
-        dacc[1] = __builtin_fmaf(lds[C::D_V64 + p_ab * 16 + m_ab + 1], a.dust[W36Dust::UIN64 + p_ab], dacc[1]);
-        dacc[2] = __builtin_fmaf(lds[C::D_V64 + p_c * 16 + m_c], a.dust[W36Dust::UIN64 + p_c], dacc[2]);
       }
-      lds[C::D_M64 + p_ab * 16 + m_ab] = dacc[0];
-      lds[C::D_M64 + p_ab * 16 + m_ab + 1] = dacc[1];
-      if (wave == 0) lds[C::D_M64 + p_c * 16 + m_c] = dacc[2];
+      {
+        // the four lanes of a V row add their partial sums up; lane 0 of the row adds input channel 64's share (in 64 -> out 64)
+        // and writes M64[position][m]
+        const int m_d = lane_d >> 2;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          float v = dacc[i];
+          v += __shfl_xor(v, 1);
+          v += __shfl_xor(v, 2);
+          const int pos = wave + 4 * i;
+          if (a.dust_in) v = __builtin_fmaf(lds[C::D_V64 + pos * 16 + m_d], a.dust[W36Dust::UIN64 + pos], v);
+          if ((lane_d & 3) == 0) lds[C::D_M64 + pos * 16 + m_d] = v;
+        }
+      }
       FPC_LDS_BARRIER();
       load_halo64(base_next);            // D_H64 has been read: the next tile's input channel 64 (okoff64 is the next tile's by now)
       if (tid_d < 16) {
@@ -717,21 +717,32 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
       }
       FPC_LDS_BARRIER();
       if (wg == wg_stamp && half == 0) { FPC_STAMP(2) }
-      // DUST: output channel 64 of the half's 128 pixels -- two threads per pixel (K halves), a dot product over h here, over
-      // the projection's x in its passes below; and h[64]'s share of outputs 0..63 as the INITIAL VALUE of their accumulators
-      [[maybe_unused]] float dsum = 0.f, dw2r = 0.f;
+      // DUST: output channel 64 of the half's 128 pixels.  Lane (pxl = l >> 4, q = l & 15) of wave w takes float4 q of the
+      // rows of pixels 32 w + 4 it + pxl, it = 0..7 (a wave instruction reads four rows' 256 contiguous bytes: no bank
+      // conflict; two threads per pixel with a K half each were 8-way conflicts on every read): a partial dot product per
+      // pixel over h here and over the projection's x in its passes below, added up across the 16 lanes in the epilogue.
+      // And h[64]'s share of outputs 0..63 is the INITIAL VALUE of their accumulators.
+      [[maybe_unused]] float dpart[8];
+      [[maybe_unused]] float dw2r = 0.f;
       [[maybe_unused]] float dhv[8][4];
-      [[maybe_unused]] const int dpx = tid_t >> 1, dhf = tid_t & 1, drow = dpx / TW, dcol = dpx % TW;
+      [[maybe_unused]] const int dq = lane_t & 15, dpxl = lane_t >> 4;
+      [[maybe_unused]] float dx64 = 0.f;      // identity shortcut: x[px][64] of the pixel this lane stores (requested here, used in the epilogue)
       if constexpr (DUST) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x4 hq = lds4[TL4 + dpx * (RH / 4) + 8 * dhf + j], wq = lds4[C::D_COL / 4 + 8 * dhf + j];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dsum = __builtin_fmaf(hq[e], wq[e], dsum);
+        if (!proj) {
+          const int px = 32 * wave + 4 * (dq >> 1) + dpxl;
+          dx64 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (((px / TW) * a.W + px % TW) * a.csx + 64) * 4, xbase, 0));
         }
-        {
-          const float h64 = lds[C::OFF_H0 + dpx * RH + 64], w64 = lds[C::D_COL + 64];
-          dsum = dhf ? __builtin_fmaf(h64, w64, dsum) : dsum;
+        const f32x4 wq = lds4[C::D_COL / 4 + dq];
+        const float w64 = dq == 0 ? lds[C::D_COL + 64] : 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int px = 32 * wave + 4 * it + dpxl;
+          const f32x4 hq = lds4[TL4 + px * (RH / 4) + dq];
+          const float h64 = lds[C::OFF_H0 + px * RH + 64];
+          float v = h64 * w64;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v = __builtin_fmaf(hq[e], wq[e], v);
+          dpart[it] = v;
         }
         dw2r = a.dust[W36Dust::W2ROW + 16 * wave + (lane_t & 15)];
 #pragma unroll
@@ -857,12 +868,16 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
           }
           FPC_LDS_BARRIER();
           if (pass + 1 < npass) load_x(pass + 1);
-          if constexpr (DUST) {      // x[px][64 dhf .. + 63] of this pass against the projection's column for output 64
+          if constexpr (DUST) {      // this pass's 128 channels of x against the projection's column for output 64
+            const f32x4 wa = lds4[C::D_COL / 4 + 20 + pass * 32 + dq], wb = lds4[C::D_COL / 4 + 20 + pass * 32 + 16 + dq];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-              const f32x4 xq = lds4[TL4 + dpx * (RX / 4) + 16 * dhf + j], wq = lds4[C::D_COL / 4 + 20 + pass * 32 + 16 * dhf + j];
+            for (int it = 0; it < 8; ++it) {
+              const int px = 32 * wave + 4 * it + dpxl;
+              const f32x4 xa = lds4[TL4 + px * (RX / 4) + dq], xb = lds4[TL4 + px * (RX / 4) + 16 + dq];
+              float v = dpart[it];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) dsum = __builtin_fmaf(xq[e], wq[e], dsum);
+              for (int e = 0; e < 4; ++e) v = __builtin_fmaf(xb[e], wb[e], __builtin_fmaf(xa[e], wa[e], v));
+              dpart[it] = v;
             }
           }
           const int steps = min(8, a.k8_x / 2 - pass * 8);   // 16-channel steps of this pass: 4 or 8
@@ -884,12 +899,10 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
               acc2[mb][nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xl + so + 64 * nb, 0, 0));
           }
         if constexpr (DUST) {
-          const float x64 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ((drow * a.W + dcol) * a.csx + 64) * 4, xbase, 0));
 #pragma unroll
           for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc2[mb][0][r] = __builtin_fmaf(dhv[mb][r], dw2r, acc2[mb][0][r]);
-          dsum += dhf ? 0.f : x64;
         }
         gemm_over(RH / 4, KH, 0);
         if (wg == wg_stamp && half == 0) { FPC_STAMP(3) }
@@ -916,8 +929,19 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
       if constexpr (DUST) {
         // channels 64..71 of the pixel: (out[64], 0, 0, 0) from the pair's first thread, zeros from the second (pad
         // channels are exact zeros: the next layer's 16-byte slot of input channel 64 relies on it)
-        float tot = dsum + __shfl_xor(dsum, 1);
-        tot += a.dust[W36Dust::B2];
+        // The 16 lanes of a pixel add up in a halving butterfly: each step a lane keeps the half of its values its q bit
+        // selects and receives the partner's -- 4 + 2 + 1 + 1 exchanges instead of 8 x 4 -- and ends with the total of
+        // pixel it = q >> 1 in both lanes q & 1: exactly the pair that stores that pixel's channels 64..67 and 68..71.
+        const bool b3 = (dq & 8) != 0, b2 = (dq & 4) != 0, b1 = (dq & 2) != 0;
+        float r1[4], r2[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r1[k] = (b3 ? dpart[4 + k] : dpart[k]) + __shfl_xor(b3 ? dpart[k] : dpart[4 + k], 8);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) r2[k] = (b2 ? r1[2 + k] : r1[k]) + __shfl_xor(b2 ? r1[k] : r1[2 + k], 4);
+        float tot = (b1 ? r2[1] : r2[0]) + __shfl_xor(b1 ? r2[0] : r2[1], 2);
+        tot += __shfl_xor(tot, 1);
+        const int dpx = 32 * wave + 4 * (dq >> 1) + dpxl, dhf = dq & 1, drow = dpx / TW, dcol = dpx % TW;
+        tot += dx64 + a.dust[W36Dust::B2];
         tot = tot > 0.f ? tot : 0.f;
         const bool ok = (drow < rows_valid) & (x0 + dcol < a.W);
         const int doff = ok ? ((drow * a.W + dcol) * a.cso + 64 + 4 * dhf) * 4 : W36_MARKER;

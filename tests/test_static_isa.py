@@ -4,7 +4,7 @@ wblock36_mfma.h hides 7 / 15 MFMAs of every block inside one `asm volatile`; the
 the block's last MFMA (its own builtin).  Whether an accumulator written by an MFMA *inside* the asm is old enough when
 the first non-MFMA instruction touches it rests on a timing argument (wblock36_mfma.h, fpc_mfma_step): this test turns
 that argument into a build-time fact.  It disassembles every `wblock36_kernel` instance of feature-point-cnn_amd/lib/
-libfpc.so and checks
+libfpc.so (and of `wblock36_dust_kernel`, the same body with the detector's 65th channel) and checks
 
   (i)  MFMA result hazards: `v_mfma_f32_16x16x4_f32` is an 8-pass XDL instruction; a VALU / LDS / VMEM / accvgpr
        instruction that reads or overwrites its destination needs >= 11 wait states after the MFMA's issue (CDNA3 ISA
@@ -33,11 +33,14 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # pairs of uniform values (tile coordinates, row offsets of the tail's loads and stores); the VGPR spills of the
 # 128-channel instances are 4 registers around the tile loop's head.  Update BOTH places when the kernel changes.
 SPILLS = {
-    # instance (NB, TYT, TXT): (sgpr_spill_count max, vgpr_spill_count max, private_segment_fixed_size max)
+    # instance (NB, TYT, TXT[, "dust"]): (sgpr_spill_count max, vgpr_spill_count max, private_segment_fixed_size max)
     (1, 4, 4): (80, 0, 0),
     (1, 2, 8): (80, 0, 0),
     (2, 4, 4): (96, 4, 16),
     (2, 2, 8): (96, 4, 16),
+    # wblock36_dust_kernel<TYT, TXT> (the detector's 64 + 1 channels: NB = 1 and the dustbin channel on the VALU)
+    (1, 4, 4, "dust"): (176, 0, 0),
+    (1, 2, 8, "dust"): (176, 0, 0),
 }
 
 
@@ -79,6 +82,9 @@ def _instances(funcs):
         m = re.match(r"_ZN3fpc15wblock36_kernelILi(\d+)ELi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
         if m:
             out[tuple(int(v) for v in m.groups())] = name
+        m = re.match(r"_ZN3fpc20wblock36_dust_kernelILi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
+        if m:
+            out[(1,) + tuple(int(v) for v in m.groups()) + ("dust",)] = name
     return out
 
 
@@ -232,4 +238,9 @@ def test_spills_are_what_design_md_says_and_outside_the_chunk_loop(code_object):
         # two chunks per trip: 2 x 36 positions x 4 k-steps x NB channel blocks
         assert n_mfma == 2 * 36 * 4 * key[0], (key, n_mfma)
         inside = [i for _, i in body[head:tail] if i.startswith(("v_readlane", "v_writelane", "scratch_"))]
-        assert not inside, (key, inside[:5])
+        if "dust" in key:
+            # the dust instance reloads the LDS-DMA's M0 values (the halo request's VALU burst, once per chunk) from spilled
+            # SGPRs: a dozen v_readlane in 288 MFMAs' worth of loop, no v_writelane, nothing in scratch
+            assert len(inside) <= 12 and all(i.startswith("v_readlane") for i in inside), (key, inside[:5])
+        else:
+            assert not inside, (key, inside[:5])
