@@ -103,9 +103,10 @@ struct W36Cfg {
   // Ring depth in steps (8 NB registers each; must divide STEPS so that slot indices are compile-time constants across
   // chunks).  vmcnt retires in order: a fragment requested after the chunk's halo request waits for it, so the ring has
   // to hold the fragments of that whole latency (RING - 1 steps of 256 NB cycles).
-  // (DUST: the 65th channel's filter quads and V rows need 60 of the 256 architectural VGPRs the 18-step ring fills: 9 steps,
-  // 2 k cycles of cover like the 128-channel instance's)
-  static constexpr int RING = NB == 2 ? 6 : DUST ? 9 : 18;
+  // (NB = 1: 9 steps = 2 k cycles of cover, like the 128-channel instance's.  Round 3 ran 18: 144 of the 256 ARCHITECTURAL
+  // VGPRs, so the compiler parked ring slots in AGPRs -- 50 v_accvgpr moves per chunk in the MFMA stream; 9 measured 3 %
+  // faster on layer1, and 6 the same as 9)
+  static constexpr int RING = NB == 2 ? 6 : 9;
   static_assert(STEPS % RING == 0, "ring slots must line up across chunks");
   static constexpr int PAG = NB == 2 ? 30 : 36;                     // positions whose accumulators live in AGPRs (240 of 256; the other 48 registers in VGPRs)
   static constexpr int WPAD = 36;                                   // zero POSITIONS behind every channel group's stream (>= 2 RING)
@@ -286,28 +287,42 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
   const int m_t = ((wt_t & 7) >> 1) * 4 + (wt_t >> 3) * 2 + (wt_t & 1);
   const int trd = ((4 * (wt_t / TXT)) * HW + 4 * (wt_t % TXT)) * HROW + ch_t;                          // halo read base
   const int twr = m_t * 16 + ((((ch_t >> 2) ^ (2 * ((m_t >> 3) & 1))) << 2) | (ch_t & 3));            // V write base (swizzled)
-  float td[6][6];
-    auto t_read = [&](int rd, int i, int j) { td[i][j] = lds[rd + (i * HW + j) * HROW]; };
+  // The 6x6 patch lives in register PAIRS (v_pk_fma_f32 / v_pk_add_f32 do two fp32 operations per VALU slot, and on this GPU
+  // every VALU slot is taken from the MFMAs): pairs along j for the column pass, re-paired along i (a 2x2 transpose of
+  // pairs is two v_pk_mov_b32) for the row pass -- 36 + 18 + 36 instructions where scalar code had 144.  Same operations
+  // in the same order on every element: bit-identical results.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 tp[6][3];      // (d[i][2 jj], d[i][2 jj + 1]) as read from the halo; after the burst tp[2 ii + (j & 1)][j >> 1] = (V[2 ii][j], V[2 ii + 1][j])
+  auto t_read = [&](int rd, int i, int j) { tp[i][j >> 1][j & 1] = lds[rd + (i * HW + j) * HROW]; };
   // B^T x for the six values x0..x5 (in place): the F(4x4,3x3) input transform along one axis, 12 operations
-  auto bt6 = [&](float& x0, float& x1, float& x2, float& x3, float& x4, float& x5) {
-    const float p = __builtin_fmaf(-4.f, x2, x4), q = __builtin_fmaf(-4.f, x1, x3);
-    const float r = x4 - x2, s = x3 - x1;
-    const float y0 = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));
-    const float y5 = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));
+  auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
+    const f32x2 k4 = {4.f, 4.f}, km4 = {-4.f, -4.f}, k5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
+    const f32x2 p = __builtin_elementwise_fma(km4, x2, x4), q = __builtin_elementwise_fma(km4, x1, x3);
+    const f32x2 r = x4 - x2, s = x3 - x1;
+    const f32x2 y0 = __builtin_elementwise_fma(k4, x0, __builtin_elementwise_fma(k5, x2, x4));
+    const f32x2 y5 = __builtin_elementwise_fma(k4, x1, __builtin_elementwise_fma(k5, x3, x5));
     x0 = y0;
     x1 = p + q;
     x2 = p - q;
-    x3 = __builtin_fmaf(2.f, s, r);
-    x4 = __builtin_fmaf(-2.f, s, r);
+    x3 = __builtin_elementwise_fma(k2, s, r);
+    x4 = __builtin_elementwise_fma(km2, s, r);
     x5 = y5;
   };
   auto t_burst = [&]() {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bt6(td[0][j], td[1][j], td[2][j], td[3][j], td[4][j], td[5][j]);
+    for (int jj = 0; jj < 3; ++jj) bt6(tp[0][jj], tp[1][jj], tp[2][jj], tp[3][jj], tp[4][jj], tp[5][jj]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bt6(td[i][0], td[i][1], td[i][2], td[i][3], td[i][4], td[i][5]);
+    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const f32x2 ra = tp[2 * ii][jj], rb = tp[2 * ii + 1][jj];      // the 2x2 block in place: no second array alive
+        tp[2 * ii][jj] = __builtin_shufflevector(ra, rb, 0, 2);
+        tp[2 * ii + 1][jj] = __builtin_shufflevector(ra, rb, 1, 3);
+      }
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii) bt6(tp[2 * ii][0], tp[2 * ii + 1][0], tp[2 * ii][1], tp[2 * ii + 1][1], tp[2 * ii][2], tp[2 * ii + 1][2]);
   };
-  auto t_write = [&](int wr, int i, int j) { lds[wr + (i * 6 + j) * 256] = td[i][j]; };
+  auto t_write = [&](int wr, int i, int j) { lds[wr + (i * 6 + j) * 256] = tp[2 * (i >> 1) + (j & 1)][j >> 1][i & 1]; };
   auto transform_all = [&](int hoff, int voff) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -554,13 +569,13 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) td[i][j] = lds[rd + (i * HW + j) * 4];
+            for (int j = 0; j < 6; ++j) tp[i][j >> 1][j & 1] = lds[rd + (i * HW + j) * 4];
           t_burst();
           const int mrow = ((tid_d & 7) >> 1) * 4 + (tid_d >> 3) * 2 + (tid_d & 1);
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) lds[C::D_V64 + (i * 6 + j) * 16 + mrow] = td[i][j];
+            for (int j = 0; j < 6; ++j) lds[C::D_V64 + (i * 6 + j) * 16 + mrow] = tp[2 * (i >> 1) + (j & 1)][j >> 1][i & 1];
         }
         FPC_LDS_BARRIER();
         // ... and every wave adds its 16 output channels' share: ONE MFMA per position, K = 4 of which k = 0 is real (the
@@ -648,6 +663,47 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const float bias1 = b1h[16 * (wave * NB + nb) + n16];
+      if constexpr (NB == 1) {
+        // (measured: the pair form is 3 % faster on the 64-channel layers and 5 % SLOWER on the 128-channel ones, whose
+        // register file is full -- those keep the scalar form)
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {
+        __builtin_amdgcn_sched_barrier(0);          // one (block, tile pair) at a time: reading all 288 accumulators ahead spills
+        // rows r = 2 rp, 2 rp + 1 of the accumulators as register PAIRS (they are neighbours in every f32x4): the transform is
+        // element-wise in r, so every operation is one v_pk_* for both tiles
+        f32x2 tt[4][6];     // A^T M: rows 0..3, columns 0..5
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          auto pr = [&](int pos) { return f32x2{acc[pos][nb][2 * rp], acc[pos][nb][2 * rp + 1]}; };
+          const f32x2 m0 = pr(0 * 6 + j), m1 = pr(1 * 6 + j), m2 = pr(2 * 6 + j), m3 = pr(3 * 6 + j), m4 = pr(4 * 6 + j), m5 = pr(5 * 6 + j);
+          const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          tt[0][j] = m0 + s12 + s34;
+          tt[1][j] = __builtin_elementwise_fma(f32x2{2.f, 2.f}, d34, d12);
+          tt[2][j] = __builtin_elementwise_fma(f32x2{4.f, 4.f}, s34, s12);
+          tt[3][j] = __builtin_elementwise_fma(f32x2{8.f, 8.f}, d34, d12) + m5;
+        }
+        const f32x2 bias2 = {bias1, bias1}, zero2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 m0 = tt[i][0], m1 = tt[i][1], m2 = tt[i][2], m3 = tt[i][3], m4 = tt[i][4], m5 = tt[i][5];
+          const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          f32x2 yv[4];
+          yv[0] = m0 + s12 + s34 + bias2;
+          yv[1] = __builtin_elementwise_fma(f32x2{2.f, 2.f}, d34, d12) + bias2;
+          yv[2] = __builtin_elementwise_fma(f32x2{4.f, 4.f}, s34, s12) + bias2;
+          yv[3] = __builtin_elementwise_fma(f32x2{8.f, 8.f}, d34, d12) + m5 + bias2;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x2 v = __builtin_elementwise_max(yv[jj], zero2);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              if (rp == 0) lds[hw_base[e] + 16 * nb + (i * TW + jj) * RH] = v[e];
+              else yh1[nb][e][i * 4 + jj] = v[e];
+            }
+          }
+        }
+      }
+      } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         __builtin_amdgcn_sched_barrier(0);          // one (block, tile) at a time: reading all 288 accumulators ahead spills
@@ -678,6 +734,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
             else yh1[nb][r - 2][i * 4 + jj] = v;
           }
         }
+      }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
