@@ -884,8 +884,11 @@ def main():
             stats = symbol_stats(timed_timings, args.steps)
             key = "bytes" if mode.bound == "hbm" else "flops"
             sym = max((k for k in stats if stats[k][key] > 0), key=lambda k: stats[k]["total_ms"])
-            timed_src = ("HIP events on the launch streams inside the timed region (%d context%s: launches of different "
-                         "streams share the GPU, a launch's bracket includes that time)" % (args.contexts, "s" if args.contexts > 1 else ""))
+            if args.contexts == 1 and os.environ.get("FPC_STREAMS") == "1":
+                timed_src = "HIP events on the launch stream inside the timed region (one context, FPC_STREAMS=1: the kernel alone on the GPU)"
+            else:
+                timed_src = ("HIP events on the launch streams inside the timed region (%d context%s: launches of different "
+                             "streams share the GPU, a launch's bracket includes that time)" % (args.contexts, "s" if args.contexts > 1 else ""))
             timed_roof = roofline_entry(mode, sym, stats[sym], step_ms, table, None, timed_src)
             if serial is not None:
                 # `roofline` = the dominant kernel priced on ITS OWN duration (the one-stream pass: the kernel alone on the

@@ -1,5 +1,7 @@
 // demo.cpp -- the shape of the reference's cpp/src/main.cc:60,77 without camera / GUI:
-//   demo <checkpoint.pt> <frame.f32> <rows> <cols> [out.txt]
+//   demo <checkpoint.pt> <frame.f32> <rows> <cols> [out.txt [nms_dist]]
+// (a sixth argument runs the frame a second time after settings().nms_dist = nms_dist -- same object, same frame size --
+// and prints that count too: settings changed between frames take effect at the next frame)
 // frame.f32 = rows*cols raw float32 gray values in [0,1].  Prints the keypoint count and
 // writes "x y confidence d0 d1 d2 d3" per keypoint.  `demo --list <checkpoint.pt>` only
 // parses the checkpoint (no GPU needed) and prints name, dtype, shape, sum of every tensor.
@@ -42,6 +44,11 @@ int main(int argc, char** argv) {
       for (auto& p : pts)
         out << p.x << ' ' << p.y << ' ' << p.confidence << ' ' << p.descriptor[0] << ' ' << p.descriptor[1] << ' '
             << p.descriptor[2] << ' ' << p.descriptor[127] << ' ' << p.descriptor[255] << '\n';
+    }
+    if (argc > 6) {
+      net.settings().nms_dist = std::atoi(argv[6]);
+      auto again = net.ProcessFrame(frame.data(), rows, cols);
+      std::printf("%zu feature points with nms_dist %d\n", again.size(), net.settings().nms_dist);
     }
     return 0;
   } catch (const std::exception& e) {  // cpp/src/main.cc:146-149

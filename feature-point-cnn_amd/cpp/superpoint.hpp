@@ -67,7 +67,10 @@ class SuperPoint {
 
   int descriptor_len() const { return vgg_ ? 256 : 128; }
   bool is_cpp_network() const { return vgg_; }
-  Settings& settings() { return settings_; }   // changes take effect at the next frame-size change
+  // Changes take effect at the NEXT frame: ProcessFrame compares the settings it built its context with against these
+  // and rebuilds when nms_dist / confidence_thresh / border_remove differ (round 3 applied them only when the frame size
+  // changed and silently ignored them otherwise).
+  Settings& settings() { return settings_; }
 
   // frame: rows x cols floats (gray)
   std::vector<FeaturePoint> ProcessFrame(const float* frame, int rows, int cols) {
@@ -102,7 +105,9 @@ class SuperPoint {
     frame_dev_ = nullptr;
   }
   void ensure(int rows, int cols, int channels) {
-    if (ctx_ && rows == rows_ && cols == cols_ && channels == channels_) return;
+    if (ctx_ && rows == rows_ && cols == cols_ && channels == channels_ && settings_.nms_dist == applied_.nms_dist &&
+        settings_.confidence_thresh == applied_.confidence_thresh && settings_.border_remove == applied_.border_remove)
+      return;
     release();
     fpc_config cfg;
     chk(fpc_default_config(&cfg), "fpc_default_config");
@@ -132,6 +137,7 @@ class SuperPoint {
     rows_ = rows;
     cols_ = cols;
     channels_ = channels;
+    applied_ = settings_;
   }
   std::vector<FeaturePoint> run() {
     chk(fpc_detect(ctx_, frame_dev_, 1), "fpc_detect");
@@ -154,7 +160,7 @@ class SuperPoint {
     return feature_points_;  // by-value copy, as cpp/src/superpoint.cc:95
   }
 
-  Settings settings_;
+  Settings settings_, applied_;   // as the caller last set them / as the current context was built
   int device_ = 0, rows_ = 0, cols_ = 0, channels_ = 0;
   bool vgg_ = false;
   fpc_pt::Checkpoint ckpt_;

@@ -85,6 +85,15 @@ def test_config0_gray_vga_frame_through_the_cpp_entry_point(torch_gpu, golden_di
     np.testing.assert_allclose(desc.cpu().numpy().ravel()[::11], g["desc_map_probe"], rtol=0, atol=ATOL)
     np.testing.assert_allclose(prob.cpu().numpy().ravel()[::13], g["prob_probe"], rtol=0, atol=ATOL)
     e.close()
+    # settings() changed between two frames of the SAME size takes effect at the next frame (round 3 applied it only when
+    # the frame size changed): the demo's second pass with nms_dist = 8 reports what a context built with 8 reports
+    msg2 = subprocess.check_output([demo, ck, str(tmp_path / "frame.f32"), str(h), str(w), out, "8"]).decode().splitlines()
+    e8 = engine(h, w, in_channels=1, nms_dist=8)
+    e8.load_state_dict(sd)
+    k8 = len(e8.detect(np.ascontiguousarray(gray[..., :1].transpose(2, 0, 1)[None]))[0][1])
+    e8.close()
+    assert msg2[0].startswith("%d feature points" % len(gc)) and msg2[1] == "%d feature points with nms_dist 8" % k8
+    assert k8 < len(gc)
 
 
 def test_get_descriptors_on_its_own_against_reference_fixtures(torch_gpu, golden_dir):
