@@ -2245,7 +2245,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
           float* x0 = c->bf16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c->x0) + (size_t)f0 * (H / 4) * (W / 4) * 64)
                               : c->x0 + (size_t)f0 * (H / 4) * (W / 4) * 64;
           // (only the cells that tiles complete for each other with atomicMax need the zero: kernels_misc.h)
-          if (!c->bf16) stem_border_clear_kernel<<<n * (H / 4), 256, 0, sb.st>>>(reinterpret_cast<float4*>(x0), H / 4, W / 4);
+          if (!c->bf16) stem_border_clear_kernel<<<(n * (H / 4) + 7) / 8, 256, 0, sb.st>>>(reinterpret_cast<float4*>(x0), H / 4, W / 4, n * (H / 4));
           LaunchTimer t(c, (int)i, sb.st, n);
           StemPoolArgs a{};
           a.in = frames + (size_t)f0 * c->cin * H * W;

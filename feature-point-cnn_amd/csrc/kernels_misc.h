@@ -213,17 +213,19 @@ __device__ __forceinline__ void stem_pool_emit(const float* lds, float* out, int
 // multiples of 8 (window row / column 0 and 8 of a 16 x 16 conv tile) -- must hold +0 before the stem runs; every other
 // cell is written by a plain store of the one tile that holds its whole window.  Zeroing just those cells (23 % of the
 // map: whole rows y % 8 == 0, and every eighth pixel of the other rows) replaces the hipMemsetAsync of the whole map
-// (round 3: a 29 us fill launch per sub-batch at VGA x 32).  One workgroup per pooled row; out = [n, Hp, Wp, 64] floats.
-__global__ __launch_bounds__(256) void stem_border_clear_kernel(float4* out, int Hp, int Wp) {
-  const int row = blockIdx.x;                 // frame * Hp + y
-  const int y = row % Hp;
-  float4* p = out + (size_t)row * Wp * 16;
+// (round 3: a 29 us fill launch per sub-batch at VGA x 32).  out = [n, Hp, Wp, 64] floats.
+__global__ __launch_bounds__(256) void stem_border_clear_kernel(float4* out, int Hp, int Wp, int rows) {
+  // one workgroup per 8 pooled rows of a frame (row y0 whole, every eighth pixel of the other seven): `rows` = frames x Hp
+  const int y0 = blockIdx.x * 8;              // frame * Hp + y, Hp a multiple of 8 or not: rows are taken modulo Hp below
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((y & 7) == 0) {
-    for (int i = threadIdx.x; i < Wp * 16; i += 256) p[i] = z;
-  } else {
-    const int n = ((Wp + 7) / 8) * 16;        // pixels 0, 8, 16, ...: 16 float4 each
-    for (int i = threadIdx.x; i < n; i += 256) p[(i >> 4) * 128 + (i & 15)] = z;
+  const int nsparse = ((Wp + 7) / 8) * 16;    // pixels 0, 8, 16, ...: 16 float4 each
+  for (int r = 0; r < 8 && y0 + r < rows; ++r) {
+    float4* p = out + (size_t)(y0 + r) * Wp * 16;
+    if ((((y0 + r) % Hp) & 7) == 0) {
+      for (int i = threadIdx.x; i < Wp * 16; i += 256) p[i] = z;
+    } else {
+      for (int i = threadIdx.x; i < nsparse; i += 256) p[(i >> 4) * 128 + (i & 15)] = z;
+    }
   }
 }
 
