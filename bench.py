@@ -274,6 +274,9 @@ def cpu_baseline(state_dict, frames, budget_s=22.0, descriptor=True):
                       "post-processing (get_points + get_descriptors) by the C oracle; %.1f s of CPU work in all legs"
                       % (ka, w, h, all_threads, spent),
             "core_budget": ncap, "thread_probe_ms": {str(k): r3(v * 1e3) for k, v in sorted(probe.items())},
+            "note": "the GPU boxes give a container a CPU quota (16) out of 256 shared logical CPUs: the multi-thread figure "
+                    "moves 3-5 % inside a run (min / max) and 33-66 frames/s from box to box; `single_thread` is the stable "
+                    "one (10.3-10.5 frames/s on every box measured)",
             "forward_ms": r3(fa / ka * 1e3), "postproc_ms": r3(pa / ka * 1e3),
             "forward_only_frames_per_s": r3(ka / fa),
             "batch%d_forward_frames_per_s" % nb: r3(nb / fb),
