@@ -129,3 +129,29 @@ def test_blob_of_another_fragment_layout_revision_is_refused():
         assert ei.value.code == -1                      # FPC_E_INVALID
     e.close()
     e2.close()
+
+
+def test_homography_adaptation_on_the_batch_plan():
+    """fpc_homography_adaptation drives the path once per view; a pseudo-labelling batch (preprocess_coco.py: 16 frames x
+    16 passes) takes the BATCH plan's kernels -- F(4x4,3x3) blocks, the detector's 64 + 1-channel instance -- which calls of
+    a few frames do not.  Same flow as tests/test_gpu_parity.py::test_homography_adaptation_against_oracle_flow with the
+    batch plan forced (`no_latency_tiles`) and the canary zones on: against the oracle's restatement of the flow, and
+    bit-identical to the small-call plan's own result on the pixels both consider valid is NOT asked (two kernels, fp32
+    noise) -- the oracle bar is."""
+    from fpc_amd.inference import HomographyConfig, sample_homography
+    oracle = oracle_mod()
+    h, w, n = 64, 96, 2
+    sd = synth.make_state_dict(3, dustbin_bias=2.0)
+    frames = synth.make_batch(5, n, h, w)
+    rng = np.random.default_rng(11)
+    hs = np.stack([sample_homography((h, w), HomographyConfig(), rng) for _ in range(4)])
+    e = engine(h, w, n, plan_flags=["no_latency_tiles", "guard_zones"])
+    e.load_state_dict(sd)
+    fwd = lambda f: oracle.forward(f, sd, SPEC)[0]                       # noqa: E731
+    for agg, radius in (("sum", 4), ("max", 0)):
+        got = e.homography_adaptation(frames, hs, None, radius, agg).cpu().numpy()
+        want = oracle.homography_adaptation(frames, fwd, hs, None, radius, agg)
+        bad = np.abs(got - want) > 1e-4
+        assert bad.mean() < 5e-3, (agg, float(bad.mean()))
+    assert e.check_guards() == 0
+    e.close()
