@@ -2709,6 +2709,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     const unsigned pf = cfg->plan_flags;
     c->fuse_blocks = !(pf & FPC_PLAN_NO_FUSED_BLOCKS);
     c->guard_zones = (pf & FPC_PLAN_GUARD_ZONES) != 0;
+    if (const char* e = getenv("FPC_GUARD_ZONES")) c->guard_zones = atoi(e) != 0;      // (a whole test run under the canary zones)
     c->winograd_det_gen3 = !(pf & FPC_PLAN_DETECTOR_GEN1);
     if (const char* e = getenv("FPC_WINOGRAD_DET_GEN")) c->winograd_det_gen3 = atoi(e) >= 3;
     c->winograd = !(pf & FPC_PLAN_NO_WINOGRAD);

@@ -5,6 +5,7 @@ all arithmetic happens inside libfpc.so.  Tensors cross the boundary as raw
 device pointers (`tensor.data_ptr()`).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -84,8 +85,17 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
+            bad = 0
+            if os.environ.get("FPC_GUARD_ZONES") == "1":
+                # a whole run under the canary zones (FPC_GUARD_ZONES=1 python -m pytest tests -m gpu): every context is
+                # checked when it is closed, and a kernel that stored outside its tensors fails the test that closed it
+                b = ctypes.c_longlong(0)
+                if self._l.fpc_check_guards(self._ctx, ctypes.byref(b)) == 0:
+                    bad = int(b.value)
             self._l.fpc_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
+            if bad:
+                raise RuntimeError("fpc_check_guards: %d canary words were overwritten -- a kernel stored outside its tensors" % bad)
 
     def __del__(self):
         try:

@@ -8,6 +8,8 @@
   persistent grid, the 2 x 8 instance at layer1) against the oracle and against the library's default plan.
 * A packed blob whose tag names another fragment-layout revision / ABI version is refused.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -50,11 +52,12 @@ def test_maps_narrower_than_a_tile_store_nothing_outside_their_tensors(h, w):
     assert np.max(np.abs(prob.cpu().numpy() - o_prob)) < ATOL
     assert len(res) == 2
     e.close()
-    # the facility itself: a context without the flag refuses the call
-    e2 = engine(h, w, 1)
-    with pytest.raises(_lib.FpcError):
-        e2.check_guards()
-    e2.close()
+    # the facility itself: a context without the flag refuses the call (unless the whole run is under FPC_GUARD_ZONES=1)
+    if os.environ.get("FPC_GUARD_ZONES") != "1":
+        e2 = engine(h, w, 1)
+        with pytest.raises(_lib.FpcError):
+            e2.check_guards()
+        e2.close()
 
 
 def test_guard_zones_see_a_planted_store():
@@ -71,7 +74,11 @@ def test_guard_zones_see_a_planted_store():
     view[:16] = 0
     torch.cuda.synchronize()
     assert e.check_guards() == 4
-    e.close()
+    if os.environ.get("FPC_GUARD_ZONES") == "1":      # (a run under the canary zones checks every context at close: this one
+        with pytest.raises(RuntimeError):             # was damaged on purpose)
+            e.close()
+    else:
+        e.close()
 
 
 def test_headline_plan_one_sub_batch_on_one_stream_matches_oracle_and_default_plan():
