@@ -257,10 +257,24 @@ static double wkind_mfma_flops(const WKindInfo& k, int tiles, int nchunk, int k8
   if (k.gen == 3) return 2.0 * tiles * n * (36.0 * (px / 16) * nchunk * k.KC + px * k8_1x1 * 8.0);
   return 2.0 * tiles * n * (16.0 * (px / 4) * nchunk * k.KC + px * k8_1x1 * 8.0);
 }
-// Generation 3 addresses its tensors with signed 32-bit byte offsets below W36_MARKER (wblock36_mfma.h): a layer whose
-// input or output tensor is larger falls back to generation 2.
-static bool w36_fits(int B, int H, int W, int cs_in, int cs_out) {
-  return (unsigned long long)B * H * W * (unsigned long long)std::max(cs_in, cs_out) * sizeof(float) < (unsigned long long)W36_MARKER;
+// Generation 3 addresses its tensors with signed 32-bit byte offsets below W36_MARKER (wblock36_mfma.h).  A launch is
+// given pointers to ITS first frame (round 4; round 3 addressed from the batch's frame 0 and sent a layer whose whole
+// tensor did not fit -- the C++ network's full-resolution layers at 32 frames -- to generation 2) and is split into
+// several launches where even its own frames do not fit; only a layer whose single frame is too large falls back.
+static bool w36_fits(int /*B*/, int H, int W, int cs_in, int cs_out) {
+  return (unsigned long long)H * W * (unsigned long long)std::max(cs_in, cs_out) * sizeof(float) < (unsigned long long)W36_MARKER;
+}
+static int w36_frames_per_launch(int H, int W, int cs_in, int cs_out) {
+  const unsigned long long fb = (unsigned long long)H * W * (unsigned long long)std::max(cs_in, cs_out) * sizeof(float);
+  return (int)std::max<unsigned long long>(1, ((unsigned long long)W36_MARKER - 1) / fb);
+}
+// conv-only layers wider than one instance: two 128-channel parts or four 64-channel ones (NB = 1 tiles take 0.53 of an
+// NB = 2 tile's time) -- whichever needs fewer tile times on `cus` CUs for `tiles` tiles per part
+static int w36_conv_part(int cout, int tiles, int cus) {
+  if (cout < 128) return 64;
+  if (cout == 128) return 128;
+  const double t2 = std::ceil((double)tiles * (cout / 128) / cus) * 1.0, t1 = std::ceil((double)tiles * (cout / 64) / cus) * 0.53;
+  return t1 < t2 ? 64 : 128;
 }
 // Generation 3: the arrangement of the 16 Winograd tiles (4 x 4 or 2 x 8) that covers the map with fewer tiles
 static WKind w36_kind(int cout, int H, int W) {
@@ -1210,10 +1224,24 @@ static int build_vgg_plan(fpc_ctx* c) {
       return;
     }
     if (ksize == 3 && relu && c->winograd) {  // Winograd F(2x2,3x3), conv-only; 256 outputs = two 128-channel launches
-      // (the C++ network's layers stay on generation 2: no small-call variants exist on this path)
-      const WKind wk = c->winograd_gen >= 2 ? (cout == 64 ? WK_W16_C64 : WK_W16_C128) : (cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128);
-      for (int n0 = 0; n0 < cout; n0 += g_wkinds[wk].CMID)
-        add_wconv(c, prefix, false, wk, x, cin, cin, Hx, Wx, out, cso, cout, n0, desc, &bo);
+      const WKind wk2 = c->winograd_gen >= 2 ? (cout == 64 ? WK_W16_C64 : WK_W16_C128) : (cout == 64 ? WK_W816_K32_C64 : WK_W816_K32_C128);
+      auto add = [&](WKind wk, int when) {
+        const size_t i0 = c->ops.size();
+        for (int n0 = 0; n0 < cout; n0 += g_wkinds[wk].CMID)
+          add_wconv(c, prefix, false, wk, x, cin, cin, Hx, Wx, out, cso, cout, n0, desc, &bo);
+        for (size_t k = i0; k < c->ops.size(); ++k) c->ops[k].when = when;
+      };
+      if (c->winograd_gen == 3 && w36_fits(c->B, Hx, Wx, cin, cso) && cin % 32 == 0 && cin >= 64) {
+        // round 4: F(4x4,3x3) for the C++ network's 3x3 layers too (the conv-only form of wblock36_kernel; 256 outputs in
+        // parts), with generation 2 -- fragments of its own -- for calls of a few frames, as the Python network's blocks
+        // (priced for a 32-frame call whatever max_batch is: the packed layout must not depend on it -- contexts of
+        // different max_batch exchange blobs)
+        const int part = w36_conv_part(cout, ((Hx + 15) / 16) * ((Wx + 15) / 16) * 32, 256);
+        add(w36_kind(part, Hx, Wx), c->latency_tiles ? 2 : 0);
+        if (c->latency_tiles) add(wk2, 1);
+      } else {
+        add(wk2, 0);
+      }
       return;
     }
     ConvSpec s{};
@@ -2332,14 +2360,29 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         // amortise; otherwise one workgroup per tile
         int grid = (c->persist_min_tiles > 0 && a.total >= c->persist_min_tiles * c->num_cus) ? c->num_cus : a.total;
         if (g_wkinds[op.wkind].gen == 3) {
-          // One workgroup per CU (137 KB of LDS), so a launch lasts ceil(tiles / CUs) tile times whatever the grid: take
-          // the SMALLEST grid that still finishes in that many rounds (a multiple of 8: the tile walk is per XCD) and
-          // leave the other CUs to the launches of the other sub-batch's stream -- 640 tiles: 216 workgroups x 3 rounds
-          // instead of 256 of which 128 idle through the third; 320 tiles: 160 x 2.
-          // (a launch of gridDim.y parts shares the CUs between them: each part's tile walk gets CUs / parts)
-          const int cus8 = std::max(1, c->num_cus / 8 / std::max(1, op.grid_y)), per_xcd = (a.total + 7) / 8;
-          const int rounds = (per_xcd + cus8 - 1) / cus8;
-          grid = 8 * std::min(cus8, (per_xcd + rounds - 1) / rounds);
+          // Pointers to the launch's first frame, as many frames per launch as stay below W36_MARKER bytes (all of them,
+          // except at the C++ network's full-resolution layers: 78.6 MB per VGA frame and tensor).
+          const int fpl = w36_frames_per_launch(a.H, a.W, a.csx, a.cso);
+          const float* x0 = a.x;
+          float* o0 = a.out;
+          for (int g0 = 0; g0 < n; g0 += fpl) {
+            const int gn = std::min(fpl, n - g0);
+            a.frame0 = 0;
+            a.x = x0 + (size_t)(f0 + g0) * a.H * a.W * a.csx;
+            a.out = o0 + (size_t)(f0 + g0) * a.H * a.W * a.cso;
+            a.total = a.tiles_x * a.tiles_y * gn;
+            a.x_bytes = (unsigned)((unsigned long long)gn * a.H * a.W * a.csx * sizeof(float));
+            // One workgroup per CU (137 KB of LDS), so a launch lasts ceil(tiles / CUs) tile times whatever the grid: take
+            // the SMALLEST grid that still finishes in that many rounds (a multiple of 8: the tile walk is per XCD) and
+            // leave the other CUs to the launches of the other sub-batch's stream -- 640 tiles: 216 workgroups x 3 rounds
+            // instead of 256 of which 128 idle through the third; 320 tiles: 160 x 2.
+            // (a launch of gridDim.y parts shares the CUs between them: each part's tile walk gets CUs / parts)
+            const int cus8 = std::max(1, c->num_cus / 8 / std::max(1, op.grid_y)), per_xcd = (a.total + 7) / 8;
+            const int rounds = (per_xcd + cus8 - 1) / cus8;
+            const int grid3 = 8 * std::min(cus8, (per_xcd + rounds - 1) / rounds);
+            g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid3), op.grid_y), sb.st);
+          }
+          break;
         }
         g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid), op.grid_y), sb.st);
         break;

@@ -162,3 +162,26 @@ def test_homography_adaptation_on_the_batch_plan():
         assert bad.mean() < 5e-3, (agg, float(bad.mean()))
     assert e.check_guards() == 0
     e.close()
+
+
+def test_cpp_network_on_the_batch_plan_against_the_reference_binary():
+    """The C++ frontend's network (arch = "vgg") on the BATCH plan's kernels -- round 4: its 3x3 layers on the conv-only form
+    of wblock36_kernel (F(4x4,3x3); 256 outputs in parts; launches given pointers to their first frame) -- against fixture
+    F7, the outputs of the reference's own cpp/src/model.cc (oracle/_ref): dense maps at 1e-4, under the canary zones; and
+    against the oracle's restatement over the whole maps."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f7_vgg_qvga.npz"))
+    sd = synth.make_vgg_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    h, w = int(g["h"]), int(g["w"])
+    frame = synth.make_batch(int(g["seed_frame"]), 1, h, w, gray=True)[:, :1]
+    frames = np.ascontiguousarray(np.repeat(frame, 3, axis=0))
+    e = engine(h, w, 3, in_channels=1, arch="vgg", plan_flags=["no_latency_tiles", "guard_zones"])
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(frames)
+    for i in range(3):
+        np.testing.assert_allclose(logits[i].cpu().numpy().ravel()[::7], g["logits_probe"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(desc[i].cpu().numpy().ravel()[::11], g["desc_probe"], rtol=0, atol=ATOL)
+    o_prob, o_desc, o_logits = oracle_mod().vgg_forward(frames[:1], sd, arch.vgg_state_dict_spec())
+    assert np.max(np.abs(logits[2].cpu().numpy() - o_logits[0])) < ATOL
+    assert np.max(np.abs(desc[2].cpu().numpy() - o_desc[0])) < ATOL
+    assert e.check_guards() == 0
+    e.close()
