@@ -110,8 +110,12 @@ struct BlockBfCfg {
   static_assert(KC % 16 == 0 && CMIDP % 16 == 0 && CMIDP <= N, "bf16 MFMA consumes 16 channels per step");
 };
 
-template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
-__global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockBfArgs a) {
+// ONE: the block's input is ONE chunk (Cin_pad == KC; the host checks it) -- known at compile time, so that the second
+// accumulator set (the shortcut's, which conv2 continues) is born at the chunk's tenth "tap" instead of being carried
+// around the chunk loop, and no request for a "next chunk" holds the staging registers through the steps: 64 + 48 registers
+// fewer inside the unrolled steps, which is what lets a wave keep FOUR pixel blocks per weight fragment (MB = 4).
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP, bool ONE>
+__device__ __forceinline__ void block_bf16_body(const BlockBfArgs& a) {
   using C = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
   constexpr int NT = C::NT, HW = C::HW, HH = C::HH, HP = C::HP, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
   constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, ROWH16 = C::ROWH16, NBT = WN * NB;
@@ -173,36 +177,85 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   u32x4 stage[ITER];   // (vector values: an array of uint4 structs is not promoted to registers)
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  // Element e = tid + i NT of a halo chunk is 16 bytes: channels 8 c8 ..+7 of halo pixel e / KC8.  Where NT is a multiple
+  // of KC8 (every instance but the 80-channel one) c8 is the thread's own for every i and the pixel advances by
+  // PS = NT / KC8 per step, so (hy, hx), the global byte offset and the LDS slot are carried from element to element -- a
+  // compare and two selects -- instead of two divisions by constants, the frame's pitch and the pixel stride per element:
+  // round 4 counted 40 VALU instructions per requested element (18 per staged one) in the ISA, 1 230 per wave and
+  // 256-pixel tile of layer1 beside 176 MFMAs, and the VALU slots of the workgroup in its epilogue are the other
+  // workgroup's MFMA slots.
+  constexpr bool CARRY = NT % KC8 == 0;
+  constexpr int PS = CARRY ? NT / KC8 : 1, PQ = PS / HW, PR = PS % HW;
   auto load_chunk = [&](const TileP& p, int chunk) {
     const int wlim = (chunk < a.nchunk && p.live) ? a.W : 0;   // nothing is in range past the last chunk / tile
     int tl = tid;
     asm volatile("" : "+v"(tl));   // (recomputed per call: hoisted out of the tile loop, the per-element offsets spill)
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-      const int e = tl + i * NT;
-      const int pix = e / KC8, c8 = e - pix * KC8;
-      const int hy = pix / HW, hx = pix - hy * HW;
-      const int iy = p.iy0 + hy, ix = p.ix0 + hx;
-      const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)wlim) & (hy < HH);   // (& not &&: no branch)
+    if constexpr (CARRY) {
+      const int pix0 = tl / KC8, c8 = tl - pix0 * KC8;
+      int hy = pix0 / HW, hx = pix0 - hy * HW;
       unsigned off = p.xbase + (unsigned)(((hy * a.W + hx) * a.csx + chunk * KC + c8 * 8) * 2);
-      asm volatile("" : "+v"(off));   // computed for every lane: as a conditional the compiler branches around it
-      stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : 0xfffffff0u), 0, 0));
+      const unsigned dstep = (unsigned)(((PQ * a.W + PR) * a.csx) * 2), dwrap = (unsigned)(((a.W - HW) * a.csx) * 2);
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int iy = p.iy0 + hy, ix = p.ix0 + hx;
+        bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)wlim);
+        if ((i + 1) * NT > NV) ok = ok & (hy < HH);   // (only the last step can run past the halo)
+        stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : 0xfffffff0u), 0, 0));
+        if (i + 1 < ITER) {
+          hx += PR;
+          const bool wrap = hx >= HW;
+          hx -= wrap ? HW : 0;
+          hy += PQ + (wrap ? 1 : 0);
+          off += dstep + (wrap ? dwrap : 0u);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int e = tl + i * NT;
+        const int pix = e / KC8, c8 = e - pix * KC8;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = p.iy0 + hy, ix = p.ix0 + hx;
+        const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)wlim) & (hy < HH);   // (& not &&: no branch)
+        unsigned off = p.xbase + (unsigned)(((hy * a.W + hx) * a.csx + chunk * KC + c8 * 8) * 2);
+        asm volatile("" : "+v"(off));   // computed for every lane: as a conditional the compiler branches around it
+        stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : 0xfffffff0u), 0, 0));
+      }
     }
   };
   auto store_chunk = [&]() {
     int tl = tid;
     asm volatile("" : "+v"(tl));
+    if constexpr (CARRY) {
+      const int pix0 = tl / KC8, c8 = tl - pix0 * KC8;
+      int hy = pix0 / HW, hx = pix0 - hy * HW;
+      int slot = (hy * HP + hx) * ROW16 + c8;
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-      const int e = tl + i * NT;
-      int pix = e / KC8, c8 = e - pix * KC8;
-      if (NV % NT != 0) {   // elements past the halo go to the skew column of its last pixel (never read)
-        const bool in = e < NV;
-        pix = in ? pix : HH * HW - 1;
-        c8 = in ? c8 : KC8;
+      for (int i = 0; i < ITER; ++i) {
+        int sl = slot;
+        if ((i + 1) * NT > NV) sl = hy < HH ? sl : (HH * HW - 1 + (HH - 1) * (HP - HW)) * ROW16 + KC8;   // past the halo: the skew column of its last pixel (never read)
+        *reinterpret_cast<u32x4*>(&lds16[sl]) = stage[i];
+        if (i + 1 < ITER) {
+          hx += PR;
+          const bool wrap = hx >= HW;
+          hx -= wrap ? HW : 0;
+          hy += PQ + (wrap ? 1 : 0);
+          slot += (PQ * HP + PR) * ROW16 + (wrap ? (HP - HW) * ROW16 : 0);
+        }
       }
-      if constexpr (HP != HW) pix += (pix / HW) * (HP - HW);   // halo row pitch in LDS
-      *reinterpret_cast<u32x4*>(&lds16[pix * ROW16 + c8]) = stage[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int e = tl + i * NT;
+        int pix = e / KC8, c8 = e - pix * KC8;
+        if (NV % NT != 0) {   // elements past the halo go to the skew column of its last pixel (never read)
+          const bool in = e < NV;
+          pix = in ? pix : HH * HW - 1;
+          c8 = in ? c8 : KC8;
+        }
+        if constexpr (HP != HW) pix += (pix / HW) * (HP - HW);   // halo row pitch in LDS
+        *reinterpret_cast<u32x4*>(&lds16[pix * ROW16 + c8]) = stage[i];
+      }
     }
   };
 
@@ -211,7 +264,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   // conv1's (+ the shortcut's) fragment ring, see phase 1.  The stream is read CIRCULARLY: the last D steps of a tile
   // request steps 0 .. D - 1 again, which are the next tile's first -- no L2 round trip at the head of a tile.
   constexpr int NS = 10 * K16;          // steps of a chunk: 9 taps of conv1 and the shortcut, K16 each
-  constexpr int D = NS % 4 == 0 ? 4 : 5;   // fragment ring: D steps ahead
+  // (2 for detector.layer.1's 50 steps of three fragments: five steps ahead were 60 registers of a kernel that then spilled
+  // 22 -- every spill reload waits for ALL outstanding requests -- 0.40 -> 0.33 ms per 64 HD frames; for the others 4
+  // measured better than 2)
+  constexpr int D = NS % 4 == 0 ? 4 : 2;   // fragment ring: D steps ahead
   static_assert(NS % D == 0, "the ring position of a step must not depend on the chunk");
   u32x4 ring[D][NB];
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -219,7 +275,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   const unsigned wlane = (unsigned)((wn * NB) * 64 + lane) * 16u;
   const int wtotal = a.nchunk * NS * stepstride * 16;
   int wstep = 0;   // (scalar) byte offset of the next step to request
-  if (a.ntaps == 9) {
+  if (ONE || a.ntaps == 9) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -248,7 +304,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = acc2[mb][nb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[mb][nb][r] = 0.f;
+        if (!ONE) acc2[mb][nb][r] = 0.f;
+      }
 
   // ---------------------------------------------------------------- phase 1: KxK conv (+ the shortcut)
   FPC_STAMP(0)
@@ -260,18 +319,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   // pixel stride (32 cache lines per request): 23 k of layer_out.0's 85 k cycles per tile for 3 k cycles of MFMAs, and the
   // identity's loads stood at the head of the epilogue (in-kernel stamps).  Its fragments follow the chunk's conv1
   // fragments in the w1 stream ("tap 9").
-  if (a.ntaps == 9) {
+  if (ONE || a.ntaps == 9) {
     // Two steps of fragments ahead -- 256 MFMA cycles of this wave -- do not cover an L2 round trip, and the LDS read of a
     // step's pixels sat right in front of its MFMAs.  Here the chunk's steps are unrolled, fragments run D steps ahead
     // in a register ring whose slots are compile-time names (through a buffer descriptor too: the lane's offset in a
     // VGPR that never changes, the step in the scalar offset, and a request past the last step returns zeros), and a
     // step's pixels are read while the previous step's MFMAs run.
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    for (int chunk = 0; chunk < (ONE ? 1 : a.nchunk); ++chunk) {
       FPC_LDS_BARRIER();   // the previous chunk's pixels have been read
       store_chunk();
       FPC_LDS_BARRIER();
       if (chunk == 0) { FPC_STAMP(1) }
-      load_chunk(cur, chunk + 1);
+      if (!ONE) load_chunk(cur, chunk + 1);
       u32x4 av[MB], an[MB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + a.tapoff16[0]]);
@@ -296,6 +355,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[st % D][nb]),
                                                                     __builtin_bit_cast(bf16x8, av[mb]), acc[mb][nb], 0, 0, 0);
         } else {
+          if (ONE && st == 9 * K16) {   // the shortcut's accumulators start here
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = 0.f;
+          }
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -354,7 +421,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
   }
 
   FPC_STAMP(2)
-  if (!a.conv_only) {
+  if (ONE || !a.conv_only) {
     // -------------------------------------------------------------- h = relu(acc + b1) -> LDS (bf16)
     // phase 2's first D2 steps of fragments are requested before h is written and land behind that.
     constexpr int KH = CMIDP / 16, D2 = KH < 4 ? KH : 4;
@@ -594,19 +661,40 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
       FPC_LDS_BARRIER();
       constexpr int C8 = CMIDP / 8;
       constexpr int NE = TH * TW * C8, EIT = (NE + NT - 1) / NT;
+      // (element e = tid + i NT: 16 bytes = channels 8 c8 ..+7 of tile pixel m = e / C8.  With the blocked pixel order and
+      // NT / C8 = 8, 16 or 32 pixels per step, c8 and the pixel's place inside its 4 x 8 block are the thread's own and the
+      // step only adds compile-time rows / columns: one offset per thread + a scalar per step, as in load_chunk)
+      constexpr int MS = NT % C8 == 0 ? NT / C8 : 0;
+      constexpr bool OCARRY = bf_blocked(TH, TW, S) && NE % NT == 0 && (MS == 8 || MS == 16 || MS == 32);
       int tl = tid;
       asm volatile("" : "+v"(tl));
+      if constexpr (OCARRY) {
+        constexpr int BX = TW / 8;
+        const int m0 = tl / C8, c8 = tl - m0 * C8;
+        const int yb = oyb + (m0 >> 3), xb = oxb + (m0 & 7);
+        const unsigned obase = (unsigned)((b * a.OH + yb * a.oys + a.oy0) * a.OW + xb * a.oxs + a.ox0) * (unsigned)(a.cso * 2) + (unsigned)(c8 * 16);
+        const int lbase = m0 * ROWH16 + c8;
 #pragma unroll
-      for (int i = 0; i < EIT; ++i) {
-        const int e = tl + i * NT;
-        const int m = e / C8, c8 = e - m * C8;
-        int py, px;
-        bf_pixel<TH, TW, S>(m, py, px);
-        const int y = oyb + py, x = oxb + px;
-        const bool on = (NE % NT == 0 || e < NE) & (y < a.Ho) & (x < a.Wo);
-        const unsigned off = (unsigned)((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * (unsigned)(a.cso * 2) + (unsigned)(c8 * 16);
-        const int mm = (NE % NT == 0 || e < NE) ? m : 0;
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&lds16[mm * ROWH16 + c8]), orsrc, (int)(on ? off : 0xfffffff0u), 0, 0);
+        for (int i = 0; i < EIT; ++i) {
+          const int blk = (i * MS) >> 5, ci = (i * MS) & 31;
+          const int cy = (blk / BX) * 4 + (ci >> 3), cx = (blk % BX) * 8;
+          const bool on = (yb + cy < a.Ho) & (xb + cx < a.Wo);
+          const unsigned off = obase + (unsigned)(cy * a.oys * a.OW + cx * a.oxs) * (unsigned)(a.cso * 2);
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&lds16[lbase + i * MS * ROWH16]), orsrc, (int)(on ? off : 0xfffffff0u), 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+          const int e = tl + i * NT;
+          const int m = e / C8, c8 = e - m * C8;
+          int py, px;
+          bf_pixel<TH, TW, S>(m, py, px);
+          const int y = oyb + py, x = oxb + px;
+          const bool on = (NE % NT == 0 || e < NE) & (y < a.Ho) & (x < a.Wo);
+          const unsigned off = (unsigned)((b * a.OH + y * a.oys + a.oy0) * a.OW + x * a.oxs + a.ox0) * (unsigned)(a.cso * 2) + (unsigned)(c8 * 16);
+          const int mm = (NE % NT == 0 || e < NE) ? m : 0;
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&lds16[mm * ROWH16 + c8]), orsrc, (int)(on ? off : 0xfffffff0u), 0, 0);
+        }
       }
     }
   }
@@ -623,6 +711,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockB
 #endif
   cur = nxt;
   }
+}
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockBfArgs a) {
+  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, false>(a);
+}
+// the one-chunk form (3x3 blocks whose Cin_pad == KC: layer1, detector.layer.1)
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_one_kernel(const BlockBfArgs a) {
+  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, true>(a);
 }
 
 }  // namespace fpc

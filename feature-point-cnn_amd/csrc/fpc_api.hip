@@ -287,13 +287,13 @@ static WKind w36_kind(int cout, int H, int W) {
 // bf16 / split-operand instances.  FKIND(name, KERNEL, CFG, PLANES, TH,TW, S,EXT, KC, WM,WN, MB,NB, CMIDP)
 //   PLANES 1: block_bf16_kernel (dtype = FPC_BF16); 3: block_x3_kernel (dtype = FPC_F32_SPLIT)
 #define FPC_BF16_KINDS(X)                                                                   \
-  X(F816_s1_K64_C64, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)     \
-  X(F620_s2_K32_C128, block_bf16_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 32, 2, 2, 2, 2, 128)   \
+  X(F816_s1_K64_C64, block_bf16_one_kernel, BlockBfCfg, 1, 8, 32, 1, 3, 64, 2, 2, 4, 1, 64) \
   X(F816_s1_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 1, 4, 4, 1, 128)   \
-  X(F816_s1_K64_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 4, 1, 1, 3, 80)     \
-  X(F816_s1_K80_C80, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 80, 4, 1, 1, 3, 80)     \
-  X(F816_s1_K64_C80w, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 64, 1, 4, 4, 1, 80)   \
-  X(F320_s2_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 64, 1, 4, 2, 2, 256)   \
+  X(F816_s1_K80_C80, block_bf16_one_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 80, 4, 1, 1, 3, 80) \
+  X(F816_s1_K128_C128, block_bf16_one_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 128, 1, 4, 4, 1, 128) \
+  X(F816_s1_K128_C80w, block_bf16_one_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 128, 1, 4, 4, 1, 80) \
+  X(F620_s2_K64_C128, block_bf16_one_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 64, 2, 2, 2, 2, 128) \
+  X(F320_s2_K128_C256, block_bf16_one_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 128, 1, 4, 2, 2, 256) \
   X(F416_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 4, 16, 1, 3, 64, 1, 4, 2, 2, 256)   \
   X(F816_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 2, 64, 1, 4, 4, 1, 128)   \
   X(S816_s1_K64_C64, block_x3_kernel, BlockX3Cfg, 3, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)       \
@@ -941,6 +941,8 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   a.in_f32 = s.in_f32;
   a.x_bytes = (unsigned)std::min<size_t>((size_t)c->B * s.H * s.W * s.csx * 2, 0xffffff00u);
   a.nchunk = s.cin_pad / k.KC;
+  // block_bf16_one_kernel: the single chunk is a compile-time fact of the instance (block_bf16.h)
+  if (strstr(k.symbol, "block_bf16_one_kernel") && a.nchunk != 1) { c->plan_error = true; return; }
   a.H = s.H;
   a.W = s.W;
   a.ntaps = 9;
@@ -1055,12 +1057,12 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   // pull 64 B/clk of weight fragments from L2 and 64 B/clk of pixels from LDS for a 2 x 2 register blocking.)
   add_fblock(c, {"encoder.layer1.0", FK_F816_s1_K64_C64, c->x0, 64, 0, 64, 64, H4, W4, c->x1, 64, 0, 64, true, false}, bo);
   add_fblock(c, {"encoder.layer1.1", FK_F816_s1_K64_C64, c->x1, 64, 0, 64, 64, H4, W4, c->x2, 64, 0, 64, false, false}, bo);
-  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K32_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
-  add_fblock(c, {"encoder.layer2.1", FK_F816_s1_K64_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
+  add_fblock(c, {"encoder.layer2.0", FK_F620_s2_K64_C128, c->x2, 64, 0, 64, 64, H4, W4, c->x3, 128, 0, 128, true, false}, bo);
+  add_fblock(c, {"encoder.layer2.1", FK_F816_s1_K128_C128, c->x3, 128, 0, 128, 128, Hc, Wc, feat, 256, 0, 128, false, false}, bo);
   // detector.layer.0 on the 2 x 2 blocking of the 128-wide layers (N = 128 for 65 channels: a quarter of the MFMAs on
   // zeros, but four MFMAs per four operand fetches instead of three per four: 0.47 -> 0.40 ms per 64 HD frames);
   // layer.1 (K = 80) measured the same on both shapes and keeps the narrower one
-  add_fblock(c, {"detector.layer.0", FK_F816_s1_K64_C80w, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
+  add_fblock(c, {"detector.layer.0", FK_F816_s1_K128_C80w, feat, 256, 0, 128, 128, Hc, Wc, c->d0, 80, 0, 65, true, false}, bo);
   add_fblock(c, {"detector.layer.1", FK_F816_s1_K80_C80, c->d0, 80, 0, 65, 80, Hc, Wc, c->lg, 80, 1, 65, false, false}, bo);
   c->ops.back().fused_softmax_capable = c->fuse_softmax;
   {
@@ -1071,12 +1073,12 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
     c->convw.push_back({});
   }
   if (de) {
-    add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K64_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K128_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
     add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
     add_fconvT(c, FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
     add_fblock(c, {"descriptor.layer_out.0", FK_F816_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
     // (the descriptor map is bf16 as well -- round 3: descriptor16_kernel<8, true> reads it, fpc_forward / the tap convert it)
-    add_fblock(c, {"descriptor.layer_out.1", FK_F816_s1_K64_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 0, 128, false, true}, bo);
+    add_fblock(c, {"descriptor.layer_out.1", FK_F816_s1_K128_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 0, 128, false, true}, bo);
   }
 }
 
