@@ -23,4 +23,8 @@ for op in sys.argv[1:]:
     for i in range(5):
         print('  stamp %d->%d  mean %8.0f  median %8.0f' % (i, i + 1, d[:, i].mean(), np.median(d[:, i])))
     print('  tile total mean %.0f' % (s[:, 5] - s[:, 0]).mean())
+    rt = (s[:, 7] - s[:, 6]).astype(float)      # 100 MHz ticks between stamps 0 and 5 (wblock36_kernel records them)
+    ok = rt > 0
+    if ok.any():
+        print('  in-kernel clock (median over workgroups): %.2f GHz' % (np.median((s[ok, 5] - s[ok, 0]) / rt[ok]) * 0.1))
     eng.close()

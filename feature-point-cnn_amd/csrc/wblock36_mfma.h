@@ -406,7 +406,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
     const int b = pos_cur.b, ty = pos_cur.ty, tx = pos_cur.tx;
     const TilePos pos_next = tile_pos(wg + wg_step);
     const int base_next = halo_base(pos_next);
-    if (wg == wg_stamp) { FPC_STAMP(0) }
+    if (wg == wg_stamp) { FPC_STAMP(0) FPC_RSTAMP(6) }
 
     f32x4 acc[36][NB];
     {
@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
         const f32x4 v = {dhf ? 0.f : tot, 0.f, 0.f, 0.f};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), orsrc, voff, 0, 0);
       }
-      if (wg == wg_stamp && half == 0) { FPC_STAMP(5) }
+      if (wg == wg_stamp && half == 0) { FPC_STAMP(5) FPC_RSTAMP(7) }
       FPC_LDS_BARRIER();   // the region is reused by the second half / the next tile's pipeline
     }  // halves
     pos_cur = pos_next;
