@@ -244,3 +244,23 @@ def test_spills_are_what_design_md_says_and_outside_the_chunk_loop(code_object):
             assert len(inside) <= 12 and all(i.startswith("v_readlane") for i in inside), (key, inside[:5])
         else:
             assert not inside, (key, inside[:5])
+
+
+def test_one_chunk_bf16_block_instances_keep_their_registers(code_object):
+    """DESIGN.md 3.7 "Round 4": the one-chunk form of the bf16 block kernel exists to get the shortcut's accumulators and
+    the staging registers out of the unrolled steps -- every `block_bf16_one_kernel` instance fits its 256 registers with
+    NOTHING in scratch (detector.layer.1's 22 spilled registers were 0.40 -> 0.33 ms), and layer1's keeps four pixel
+    blocks per weight fragment (MB = 4) at that."""
+    funcs, meta = code_object
+    inst = {}
+    for name in funcs:
+        m = re.match(r"_ZN3fpc21block_bf16_one_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEEvNS_11BlockBfArgsE$", name)
+        if m:
+            inst[tuple(int(v) for v in m.groups())] = name
+    assert len(inst) >= 5, sorted(inst)
+    for key, name in inst.items():
+        m = meta[name]
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (key, m)
+        assert not any(i.startswith("scratch_") for _, i in funcs[name]), key
+    layer1 = [k for k in inst if k[4] == 64 and k[2] == 1]          # (TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP): KC = 64, stride 1
+    assert layer1 and all(k[7] == 4 for k in layer1), layer1
