@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -2693,6 +2695,74 @@ int fpc_default_config(fpc_config* cfg) {
   return FPC_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// Streams on distinct hardware queues
+// ------------------------------------------------------------------------------------
+// The runtime maps streams onto GPU_MAX_HW_QUEUES (4) hardware queues, a new stream onto the least-used one -- which one
+// that is depends on every stream the PROCESS has made and dropped before.  Two streams on one queue run their kernels
+// in a row: with the two sub-batch streams of a context on one queue the context is a one-stream context.  Measured
+// (round 4, 64 HD frames, bf16): the same engine gave 12 790 / 12 770 / 12 110 / 11 620 / 12 780 / 12 730 frames/s with
+// 0 .. 5 unrelated streams created in the process before it -- and the bounded pass of that workload inside the default
+// bench run (several engines made and closed before it) read 3 % under the workload's own run for that reason.
+// So fpc_create PROBES: a candidate stream is kept only if a 150 us one-wave kernel on it runs SIDE BY SIDE with the
+// same kernel on every stream it has to be concurrent with (this context's streams, and the main streams of the other
+// live contexts of the device); a candidate that shares a queue is set aside, and after a few candidates the best of
+// those set aside is taken (never worse than an unprobed stream).  FPC_QUEUE_PROBE=0 switches the probe off.
+static std::mutex g_queue_mu;
+static std::vector<std::pair<int, hipStream_t>> g_main_streams;   // (device, main / sub-batch stream) of the live contexts
+
+static bool streams_side_by_side(hipStream_t a, hipStream_t b) {
+  const unsigned ticks = 15000;   // 150 us
+  double best = 1e30;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipStreamSynchronize(a);
+    hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, a, ticks);
+    hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, b, ticks);
+    hipStreamSynchronize(a);
+    hipStreamSynchronize(b);
+    best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return best < 240.0;   // one probe: ~170 us with its launches; two in a row: ~320
+}
+
+// a new non-blocking stream that runs side by side with every stream of `with` (if the runtime has such a queue left)
+static hipStream_t acquire_stream(bool probe, const std::vector<hipStream_t>& with, const std::vector<hipStream_t>& prefer) {
+  hipStream_t st = nullptr;
+  if (!probe || (with.empty() && prefer.empty())) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return st;
+  }
+  std::vector<hipStream_t> aside;
+  hipStream_t second = nullptr;   // runs beside all of `with` but not beside all of `prefer`
+  for (int tries = 0; tries < 8; ++tries) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    bool ok = true;
+    for (hipStream_t o : with) ok = ok && streams_side_by_side(st, o);
+    if (ok) {
+      bool all = true;
+      for (hipStream_t o : prefer) all = all && streams_side_by_side(st, o);
+      if (all) {
+        if (second) aside.push_back(second);
+        second = nullptr;
+        break;
+      }
+      if (!second) { second = st; st = nullptr; continue; }
+    }
+    aside.push_back(st);
+    st = nullptr;
+  }
+  if (!st) st = second;
+  else if (second) aside.push_back(second);
+  if (!st && !aside.empty()) {   // every candidate shares a queue with something: an unprobed stream's luck, no worse
+    st = aside.back();
+    aside.pop_back();
+  }
+  for (hipStream_t o : aside) hipStreamDestroy(o);
+  return st;
+}
+
 int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   if (!out || !cfg) return FPC_E_INVALID;
   *out = nullptr;
@@ -2745,8 +2815,16 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->cap = cfg->max_keypoints > 0 ? cfg->max_keypoints : worst;
   c->sort_cap = 1;
   while (c->sort_cap < worst) c->sort_cap <<= 1;
-  HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // (streams: probed for hardware queues of their own -- "Streams on distinct hardware queues" above)
+  std::lock_guard<std::mutex> queue_lock(g_queue_mu);
+  const bool qprobe = !(getenv("FPC_QUEUE_PROBE") && atoi(getenv("FPC_QUEUE_PROBE")) == 0);
+  std::vector<hipStream_t> q_others, q_own, q_heavy;   // the other contexts' main / sub-batch streams on this device; this context's streams
+  for (const auto& ds : g_main_streams)
+    if (ds.first == cfg->device) q_others.push_back(ds.second);
+  c->stream = acquire_stream(qprobe, {}, q_others);
+  if (!c->stream) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
   c->own_stream = true;
+  q_own.push_back(c->stream);
   {
     // Launch-plan knobs: fpc_config fields (include/fpc.h, FPC_PLAN_*) first, then the FPC_* environment variables as
     // overrides for A/B runs of an unmodified caller.
@@ -2790,13 +2868,15 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (getenv("FPC_L1_T816")) c->layer1_t816 = true;
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < nsub; ++i) {
-      hipStream_t st;
+      hipStream_t st = acquire_stream(qprobe, q_own, q_others);
       hipEvent_t ev;
-      HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      if (!st) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
       HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       c->aux.push_back(st);
       c->ev_join.push_back(ev);
+      q_own.push_back(st);
     }
+    q_heavy = q_own;   // main + sub-batch streams: what other contexts keep clear of (registered once fpc_create has succeeded)
     // FPC_SPLIT_HEADS=1 (detector head + NMS of a sub-batch on a side stream next to its descriptor head) measures +1 %
     // frames/s for the Python network in the fp32-MFMA mode (8 200 vs 8 120, same box) and -2 % for the C++ network; it
     // stays off by default: with three kernels sharing the GPU every launch stretches (the dominant kernel's mean launch
@@ -2811,7 +2891,11 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     for (int i = 0; i < nsub; ++i) {
       hipStream_t st = nullptr;
       hipEvent_t e1, e2;
-      if (i < nside) HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      if (i < nside) {
+        st = acquire_stream(qprobe, q_own, q_others);
+        if (!st) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
+        q_own.push_back(st);
+      }
       HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
       c->side.push_back(st);
@@ -2868,6 +2952,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     fpc_destroy(c.release());  // streams, events and whatever build_plan had allocated
     return rc;
   }
+  for (hipStream_t st : q_heavy) g_main_streams.push_back({cfg->device, st});
   *out = c.release();
   return FPC_OK;
 }
@@ -2876,6 +2961,15 @@ void fpc_destroy(fpc_ctx* c) {
   if (!c) return;
   hipSetDevice(c->cfg.device);
   hipDeviceSynchronize();
+  {
+    std::lock_guard<std::mutex> queue_lock(g_queue_mu);
+    auto gone = [&](hipStream_t st) {
+      for (size_t i = 0; i < g_main_streams.size(); ++i)
+        if (g_main_streams[i].second == st) { g_main_streams.erase(g_main_streams.begin() + i); break; }
+    };
+    gone(c->stream);
+    for (auto st : c->aux) gone(st);
+  }
   for (auto e : c->event_pool) hipEventDestroy(e);
   for (auto e : c->ev_join) hipEventDestroy(e);
   for (auto st : c->aux) hipStreamDestroy(st);
@@ -3095,6 +3189,11 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
 
 int fpc_set_stream(fpc_ctx* c, void* s) {
   if (!c) return FPC_E_INVALID;
+  {
+    std::lock_guard<std::mutex> queue_lock(g_queue_mu);
+    for (auto& ds : g_main_streams)
+      if (ds.second == c->stream) ds.second = (hipStream_t)s;   // (the caller's stream: other contexts keep clear of it as well)
+  }
   if (c->own_stream && c->stream) {
     hipStreamSynchronize(c->stream);
     hipStreamDestroy(c->stream);
