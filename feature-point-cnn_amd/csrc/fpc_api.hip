@@ -2727,39 +2727,42 @@ static bool streams_side_by_side(hipStream_t a, hipStream_t b) {
   return best < 240.0;   // one probe: ~170 us with its launches; two in a row: ~320
 }
 
-// a new non-blocking stream that runs side by side with every stream of `with` (if the runtime has such a queue left)
+// a new non-blocking stream that runs side by side with every stream of `with` and, if the runtime has such a queue
+// left, of `prefer`
 static hipStream_t acquire_stream(bool probe, const std::vector<hipStream_t>& with, const std::vector<hipStream_t>& prefer) {
   hipStream_t st = nullptr;
   if (!probe || (with.empty() && prefer.empty())) {
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return st;
   }
-  std::vector<hipStream_t> aside;
-  hipStream_t second = nullptr;   // runs beside all of `with` but not beside all of `prefer`
-  for (int tries = 0; tries < 8; ++tries) {
+  // rank of a candidate: 2 = beside all of `with` and `prefer`, 1 = beside all of `with`, 0 = shares a queue with one of `with`.
+  // Candidates are kept alive until the choice is made: a dropped one would free its queue for the next candidate.
+  std::vector<std::pair<int, hipStream_t>> cand;
+  int best = -1;
+  for (int tries = 0; tries < 8 && best < 2; ++tries) {
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-    bool ok = true;
-    for (hipStream_t o : with) ok = ok && streams_side_by_side(st, o);
-    if (ok) {
-      bool all = true;
-      for (hipStream_t o : prefer) all = all && streams_side_by_side(st, o);
-      if (all) {
-        if (second) aside.push_back(second);
-        second = nullptr;
-        break;
-      }
-      if (!second) { second = st; st = nullptr; continue; }
+    int rank = 1;
+    for (hipStream_t o : with)
+      if (rank && !streams_side_by_side(st, o)) rank = 0;
+    if (rank == 1) {
+      rank = 2;
+      for (hipStream_t o : prefer)
+        if (rank == 2 && !streams_side_by_side(st, o)) rank = 1;
     }
-    aside.push_back(st);
-    st = nullptr;
+    cand.push_back({rank, st});
+    best = std::max(best, rank);
   }
-  if (!st) st = second;
-  else if (second) aside.push_back(second);
-  if (!st && !aside.empty()) {   // every candidate shares a queue with something: an unprobed stream's luck, no worse
-    st = aside.back();
-    aside.pop_back();
-  }
-  for (hipStream_t o : aside) hipStreamDestroy(o);
+  st = nullptr;
+  for (auto& rc : cand)
+    if (rc.first == best && !st) {
+      st = rc.second;
+      rc.second = nullptr;
+    }
+  for (auto& rc : cand)
+    if (rc.second) hipStreamDestroy(rc.second);
+  if (getenv("FPC_QUEUE_PROBE") && atoi(getenv("FPC_QUEUE_PROBE")) == 2)
+    fprintf(stderr, "[fpc] acquire_stream: %zu candidates for a stream beside %zu of this context / %zu of others: %s\n", cand.size(),
+            with.size(), prefer.size(), best == 2 ? "beside all" : best == 1 ? "beside this context's" : best == 0 ? "SHARES a queue" : "none");
   return st;
 }
 
