@@ -94,9 +94,10 @@ def _self_launch():
 
 if __name__ == "__main__":
     _self_launch()
-    # (HIP multiplexes streams onto 4 hardware queues by default, in creation order.  GPU_MAX_HW_QUEUES=8 was measured:
-    # the host-fed fp32 upload path gains -- 8 230 against 7 350 frames/s -- but the device-resident headline loses 2-3 %;
-    # the 8-bit host-fed path reaches 98-99 % of the device-resident rate either way.  Left at the default.)
+    # (HIP multiplexes streams onto 4 hardware queues by default, a new stream onto the least-used one.  More queues
+    # (GPU_MAX_HW_QUEUES=5, 6, 8) were measured again in round 4, with the streams probed: the device-resident headline loses
+    # 5 %, the host-fed legs 5-25 %.  Left at the default; what matters is WHICH streams share a queue -- fpc_create and
+    # stream_beside below see to that.)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -303,6 +304,44 @@ def cpu_baseline_vgg_reference(sd, frames):
                       "with libtorch CPU, %d runs of %.2f s); the rest of cpp/ needs TRTorch/OpenCV" % (n, W, H, reps, sec)}
 
 
+def stream_beside(others, dev, tries=8):
+    """A torch stream whose kernels run SIDE BY SIDE with those of every stream in `others`: the HIP runtime maps streams
+    onto 4 hardware queues, a new one onto the least-used queue, and two streams on one queue run in a row.
+    A candidate is kept if a ~100 us spin on it and the same spin on each of `others` take one spin's time together, not
+    two; the candidates set aside stay alive until the choice is made (torch pools its streams anyway)."""
+    def together(a, b):
+        best = 1e9
+        for _ in range(2):
+            a.synchronize(); b.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(spin)
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(spin)
+            a.synchronize(); b.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    if not others:
+        return torch.cuda.Stream(device=dev)
+    spin = 400000
+    probe = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(probe):
+        torch.cuda._sleep(spin)      # (first use: code object load)
+    probe.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(probe):
+        torch.cuda._sleep(spin)
+    probe.synchronize()
+    one = time.perf_counter() - t0
+    aside = [probe]
+    for _ in range(tries):
+        c = torch.cuda.Stream(device=dev)
+        if all(together(c, o) < 1.6 * one for o in others):
+            return c
+        aside.append(c)
+    return aside[-1]
+
+
 def host_fed_rates(sd, frames_np, local, dtype, steps=36):
     """H2D-inclusive rates (the second figure, never `value`): every step uploads its batch from pinned host
     memory and runs the path.  (a) the reference's input, fp32 RGB [n,3,H,W]; (b) 8-bit RGB HWC frames converted on
@@ -317,18 +356,23 @@ def host_fed_rates(sd, frames_np, local, dtype, steps=36):
     dev = torch.device("cuda", local)
     res = {}
     u8 = np.clip(np.rint(frames_np.transpose(0, 2, 3, 1) * 255.0), 0, 255).astype(np.uint8)
-    copy_stream = torch.cuda.Stream(device=dev)
     nbuf = 3
     for tag, host in (("f32_rgb_nchw", torch.from_numpy(frames_np).pin_memory()),
                       ("u8_rgb_hwc", torch.from_numpy(np.ascontiguousarray(u8)).pin_memory())):
-        ctxs = []
+        # (round 4: the three streams of the loop are PICKED so that they share no hardware queue -- stream_beside, the
+        # caller-side twin of fpc_create's probe.  With torch's pooled streams as they come, which stream shared a queue
+        # with which was the process's history: fp32 frames read 69 % of the device-resident rate and 8-bit ones 95 %, and
+        # after an unrelated change the other way round)
+        ctxs, taken = [], []
         for _ in range(2):
-            st = torch.cuda.Stream(device=dev)
+            st = stream_beside(taken, dev)
+            taken.append(st)
             e = Engine(H, W, max_batch=BATCH, device=local, dtype=dtype, num_streams=1)
             e.load_state_dict(sd)
             with torch.cuda.stream(st):
-                e.use_torch_stream()
+                e.use_torch_stream()      # (fpc_set_stream exchanges the context's side stream if it shares st's queue)
             ctxs.append((st, e))
+        copy_stream = stream_beside(taken, dev)
         bufs = [torch.empty_like(host, device=dev) for _ in range(nbuf)]
         uploaded = [torch.cuda.Event() for _ in range(nbuf)]
         consumed = [torch.cuda.Event() for _ in range(nbuf)]

@@ -22,7 +22,7 @@ CSRC = os.path.join(_DIR, "csrc")
 SYMBOLS = [
     "fpc_abi_version", "fpc_build_flags", "fpc_strerror", "fpc_last_hip_error", "fpc_default_config", "fpc_create",
     "fpc_destroy", "fpc_load_weights", "fpc_packed_size", "fpc_packed_device_ptr",
-    "fpc_export_packed", "fpc_import_packed", "fpc_mark_weights_loaded", "fpc_set_stream",
+    "fpc_export_packed", "fpc_import_packed", "fpc_mark_weights_loaded", "fpc_set_stream", "fpc_upload_stream",
     "fpc_get_stream", "fpc_sync", "fpc_forward", "fpc_detect", "fpc_get_points", "fpc_results",
     "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
     "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation", "fpc_detect_u8_resized",
@@ -111,6 +111,8 @@ def load():
     l.fpc_import_packed.argtypes = [vp, vp, ctypes.c_size_t]
     l.fpc_mark_weights_loaded.argtypes = [vp]
     l.fpc_set_stream.argtypes = [vp, vp]
+    l.fpc_upload_stream.argtypes = [vp]
+    l.fpc_upload_stream.restype = vp
     l.fpc_get_stream.argtypes = [vp]
     l.fpc_get_stream.restype = vp
     l.fpc_sync.argtypes = [vp]

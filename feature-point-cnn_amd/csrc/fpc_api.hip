@@ -414,6 +414,8 @@ struct fpc_ctx {
   int cap = 0, sort_cap = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t upload = nullptr;       // fpc_upload_stream: the caller's copy stream, on a hardware queue of its own
+  bool queue_probe = true;            // fpc_create probed the streams for hardware queues of their own (FPC_QUEUE_PROBE)
   std::vector<hipStream_t> aux;      // extra streams for sub-batches
   std::vector<hipEvent_t> ev_join;
   std::vector<hipStream_t> side;     // per sub-batch: detector head + NMS next to the descriptor head
@@ -2824,6 +2826,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   std::vector<hipStream_t> q_others, q_own, q_heavy;   // the other contexts' main / sub-batch streams on this device; this context's streams
   for (const auto& ds : g_main_streams)
     if (ds.first == cfg->device) q_others.push_back(ds.second);
+  c->queue_probe = qprobe;
   c->stream = acquire_stream(qprobe, {}, q_others);
   if (!c->stream) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
   c->own_stream = true;
@@ -2985,6 +2988,7 @@ void fpc_destroy(fpc_ctx* c) {
   if (c->blob) hipFree(c->blob);
   if (c->u8stage) hipFree(c->u8stage);
   if (c->ha_ws) hipFree(c->ha_ws);
+  if (c->upload) hipStreamDestroy(c->upload);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -3192,21 +3196,67 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
 
 int fpc_set_stream(fpc_ctx* c, void* s) {
   if (!c) return FPC_E_INVALID;
-  {
-    std::lock_guard<std::mutex> queue_lock(g_queue_mu);
-    for (auto& ds : g_main_streams)
-      if (ds.second == c->stream) ds.second = (hipStream_t)s;   // (the caller's stream: other contexts keep clear of it as well)
-  }
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  std::lock_guard<std::mutex> queue_lock(g_queue_mu);
+  for (auto& ds : g_main_streams)
+    if (ds.second == c->stream) ds.second = (hipStream_t)s;   // (the caller's stream: other contexts keep clear of it as well)
   if (c->own_stream && c->stream) {
     hipStreamSynchronize(c->stream);
     hipStreamDestroy(c->stream);
   }
   c->stream = (hipStream_t)s;
   c->own_stream = false;
+  // The sub-batch and side streams were chosen beside the stream this one replaces: any of them that shares a hardware
+  // queue with the caller's stream is exchanged ("Streams on distinct hardware queues").  (Not for the null stream.)
+  if (c->queue_probe && c->stream) {
+    std::vector<hipStream_t> own{c->stream}, others;
+    auto mine = [&](hipStream_t st) {
+      if (st == c->stream) return true;
+      for (hipStream_t a : c->aux) if (a == st) return true;
+      return false;
+    };
+    for (const auto& ds : g_main_streams)
+      if (ds.first == c->cfg.device && !mine(ds.second)) others.push_back(ds.second);
+    auto settle = [&](hipStream_t& st, bool heavy) {
+      bool ok = true;
+      for (hipStream_t o : own) ok = ok && streams_side_by_side(st, o);
+      if (!ok) {
+        hipStream_t fresh = acquire_stream(true, own, others);
+        if (fresh) {
+          hipStreamSynchronize(st);
+          if (heavy)
+            for (auto& ds : g_main_streams)
+              if (ds.second == st) ds.second = fresh;
+          hipStreamDestroy(st);
+          st = fresh;
+        }
+      }
+      own.push_back(st);
+    };
+    for (hipStream_t& st : c->aux) settle(st, true);
+    for (hipStream_t& st : c->side)
+      if (st) settle(st, false);
+  }
   return FPC_OK;
 }
 
 void* fpc_get_stream(fpc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+void* fpc_upload_stream(fpc_ctx* c) {
+  if (!c) return nullptr;
+  if (c->upload) return (void*)c->upload;
+  if (hipSetDevice(c->cfg.device) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> queue_lock(g_queue_mu);
+  std::vector<hipStream_t> own{c->stream}, others;
+  for (hipStream_t a : c->aux) own.push_back(a);
+  for (const auto& ds : g_main_streams) {
+    bool mine = false;
+    for (hipStream_t o : own) mine = mine || o == ds.second;
+    if (ds.first == c->cfg.device && !mine) others.push_back(ds.second);
+  }
+  c->upload = acquire_stream(c->queue_probe, own, others);
+  return (void*)c->upload;
+}
 
 int fpc_sync(fpc_ctx* c) {
   if (!c) return FPC_E_INVALID;

@@ -146,6 +146,17 @@ class Engine:
         s = torch.cuda.current_stream(self.torch_device).cuda_stream
         _lib.check(self._l.fpc_set_stream(self._ctx, ctypes.c_void_p(s)), "fpc_set_stream")
 
+    def torch_stream(self):
+        """The ctx's main stream as a torch stream (events recorded / awaited on it order torch work against fpc_detect)."""
+        return torch.cuda.ExternalStream(int(self._l.fpc_get_stream(self._ctx)), device=self.torch_device)
+
+    def upload_stream(self):
+        """fpc_upload_stream: a stream for the caller's uploads that shares no hardware queue with the ctx's compute streams."""
+        s = self._l.fpc_upload_stream(self._ctx)
+        if not s:
+            raise RuntimeError("fpc_upload_stream failed")
+        return torch.cuda.ExternalStream(int(s), device=self.torch_device)
+
     def _frames(self, frames):
         if not isinstance(frames, torch.Tensor):
             frames = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32))

@@ -197,6 +197,13 @@ int fpc_broadcast_weights(fpc_ctx* ctx, void* nccl_comm, int root);
 /* Work is enqueued on this hipStream_t (default: a stream the ctx owns). */
 int fpc_set_stream(fpc_ctx* ctx, void* hip_stream);
 void* fpc_get_stream(fpc_ctx* ctx);
+/* A hipStream_t for the CALLER's uploads (hipMemcpyAsync of the next batch while this one computes): non-blocking, owned
+ * by the ctx (destroyed with it), made at the first call.  It is chosen -- by the probe fpc_create uses for the ctx's own
+ * streams -- so that it does not share a hardware queue with the ctx's main / sub-batch streams nor, where a queue is
+ * left, with those of the device's other live ctxs: an upload on a stream that shares a queue with compute waits behind
+ * every launch in front of it.  Order it against fpc_detect with events, as any two streams.  NULL on failure.
+ * (The reference uploads on the default stream: python/src/superpoint.py:98-99 `.cuda()`.) */
+void* fpc_upload_stream(fpc_ctx* ctx);
 int fpc_sync(fpc_ctx* ctx);
 
 /* ~ SuperPoint.forward (python/src/superpoint.py:91-115): frames [n,3,H,W] ([n,1,H,W] with

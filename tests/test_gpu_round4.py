@@ -185,3 +185,39 @@ def test_cpp_network_on_the_batch_plan_against_the_reference_binary():
     assert np.max(np.abs(desc[2].cpu().numpy() - o_desc[0])) < ATOL
     assert e.check_guards() == 0
     e.close()
+
+
+def test_upload_stream_runs_beside_the_context_and_orders_by_events():
+    """fpc_upload_stream (round 4): a stream of the ctx's for the CALLER's uploads, probed -- like the ctx's own streams in
+    fpc_create -- to share no hardware queue with them.  A batch uploaded on it, an event, fpc_detect on the main stream
+    behind that event: the same keypoints, bit for bit, as the plain call; the handle is stable across calls and differs
+    from the main stream's; two contexts get different ones."""
+    import torch
+    h, w, n = 64, 96, 2
+    sd = synth.make_state_dict(5, dustbin_bias=4.0)
+    frames = synth.make_batch(21, n, h, w)
+    e = engine(h, w, n)
+    e.load_state_dict(sd)
+    want = e.detect(frames)
+    up, main = e.upload_stream(), e.torch_stream()
+    assert up.cuda_stream != 0 and up.cuda_stream != main.cuda_stream
+    assert e.upload_stream().cuda_stream == up.cuda_stream
+    host = torch.from_numpy(np.array(frames))      # (pageable: the copy below is staged by the runtime, still on `up`)
+    dev = torch.empty_like(host, device=e.torch_device)
+    done = torch.cuda.Event()
+    with torch.cuda.stream(up):
+        dev.copy_(host, non_blocking=True)
+        done.record(up)
+    main.wait_event(done)
+    e.detect_async(dev, n)
+    got = e.fetch(n)
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+    e2 = engine(h, w, n)
+    assert e2.upload_stream().cuda_stream not in (up.cuda_stream, main.cuda_stream)
+    torch.cuda.synchronize()
+    del dev          # (before the contexts go: torch's allocator records an event on every stream a freed block was used on)
+    e2.close()
+    e.close()
