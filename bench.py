@@ -757,9 +757,13 @@ def main():
         extra += 4 * len(engs)
     cnt, ncand = eng.counts(BATCH)
 
+    # events on ONE call in EVERY (round 4: two event records per launch on every call were 0.7 % of the frame rate --
+    # 11 300 against 11 390 frames/s, two runs each; sampled they still span the whole timed region)
     use_events = not args.no_timing_events
+    EVERY = 4
     for e_ in engs:
-        e_.set_timing(use_events)
+        e_.set_timing(EVERY if use_events else 0)
+    timed_calls = sum(len(range(0, len(range(j, args.steps, len(engs))), EVERY)) for j in range(len(engs)))
     fdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -935,14 +939,15 @@ def main():
             # timed region several streams run concurrently, so a launch's duration includes the time it shares the GPU;
             # `roofline_serial` repeats the measurement with one stream (kernels alone on the GPU).
             table = load_traffic_table(dtype) if (H, W) == (480, 640) or mode.bound == "hbm" else {}
-            stats = symbol_stats(timed_timings, args.steps)
+            stats = symbol_stats(timed_timings, timed_calls)
             key = "bytes" if mode.bound == "hbm" else "flops"
             sym = max((k for k in stats if stats[k][key] > 0), key=lambda k: stats[k]["total_ms"])
             if args.contexts == 1 and os.environ.get("FPC_STREAMS") == "1":
                 timed_src = "HIP events on the launch stream inside the timed region (one context, FPC_STREAMS=1: the kernel alone on the GPU)"
             else:
-                timed_src = ("HIP events on the launch streams inside the timed region (%d context%s: launches of different "
-                             "streams share the GPU, a launch's bracket includes that time)" % (args.contexts, "s" if args.contexts > 1 else ""))
+                timed_src = ("HIP events on the launch streams inside the timed region, on one call in %d (%d context%s: launches of "
+                             "different streams share the GPU, a launch's bracket includes that time)"
+                             % (EVERY, args.contexts, "s" if args.contexts > 1 else ""))
             timed_roof = roofline_entry(mode, sym, stats[sym], step_ms, table, None, timed_src)
             if serial is not None:
                 # `roofline` = the dominant kernel priced on ITS OWN duration (the one-stream pass: the kernel alone on the
@@ -960,8 +965,8 @@ def main():
             per_layer = {}
             for name, kern, ms, fl, mf, nb in timed_timings:
                 per_layer.setdefault(name, []).append((ms, mf, nb))
-            out["layer_ms_per_step_concurrent"] = {k: round(float(np.sum([m for m, _, _ in v])) / args.steps, 4) for k, v in per_layer.items()}
-            out["whole_path"] = whole_path_fractions(mode, timed_timings, args.steps, step_ms, BATCH, table)
+            out["layer_ms_per_step_concurrent"] = {k: round(float(np.sum([m for m, _, _ in v])) / timed_calls, 4) for k, v in per_layer.items()}
+            out["whole_path"] = whole_path_fractions(mode, timed_timings, timed_calls, step_ms, BATCH, table)
             if serial is not None:
                 sstats, sms, stim, ks = serial
                 lay = {}

@@ -481,7 +481,8 @@ struct fpc_ctx {
   };
   std::vector<ConvW> convw;  // parallel to ops (unused entries for non-conv ops)
 
-  bool timing = false;
+  bool timing = false;               // this call is timed (LaunchTimer)
+  int timing_every = 0, timing_calls = 0;   // fpc_set_timing(n): one fpc_detect call in n is timed (0 = off)
   std::vector<Timing> timings;
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
@@ -3356,6 +3357,7 @@ int fpc_detect(fpc_ctx* c, const float* frames, int n) {
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
+  if (c->timing_every > 1) c->timing = c->timing_calls++ % c->timing_every == 0;   // (sampled: every n-th call carries the events)
   if (c->split_f16) HIPCHECK(hipMemsetAsync(c->status + 1, 0, sizeof(int32_t), c->stream));
   return for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 1); });
 }
@@ -3596,6 +3598,8 @@ int fpc_get_keypoints(fpc_ctx* c, int frame, int cap, int32_t* xy, float* conf, 
 
 int fpc_set_timing(fpc_ctx* c, int enable) {
   if (!c) return FPC_E_INVALID;
+  c->timing_every = enable > 0 ? enable : 0;
+  c->timing_calls = 0;
   c->timing = enable != 0;
   c->timings.clear();   // records accumulate over calls from here on
   c->events_used = 0;

@@ -365,7 +365,8 @@ class Engine:
         return int(bad.value)
 
     def set_timing(self, on):
-        _lib.check(self._l.fpc_set_timing(self._ctx, int(bool(on))), "fpc_set_timing")
+        """on = True / False, or an int n > 1: only every n-th detect call (the first included) carries the events."""
+        _lib.check(self._l.fpc_set_timing(self._ctx, int(on) if on is not True else 1), "fpc_set_timing")
 
     def timings(self):
         """[(layer name, kernel symbol, ms, algorithmic FLOPs, MFMA-issued FLOPs, algorithmic HBM bytes)] of the
