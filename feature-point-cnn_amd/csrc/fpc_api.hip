@@ -2847,7 +2847,10 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->winograd_in1 = !(pf & FPC_PLAN_NO_WINOGRAD_LAYER_IN1);
     c->xcd_order = !(pf & FPC_PLAN_NO_XCD_ORDER);
     c->fuse_stem_pool = !(pf & FPC_PLAN_NO_FUSED_STEM_POOL);
-    c->split_heads = (pf & FPC_PLAN_SPLIT_HEADS) != 0;
+    // Round 4, with the streams on hardware queues of their own: one context, two sub-batches, Python network, fp32 MFMA:
+    // 10 740 -> 10 845 frames/s (steady 10 790 -> 10 930; two runs each); the C++ network loses 2 %, bf16 HD and the QVGA
+    // detector do not move, one-sub-batch contexts (the bench's two in turn) +0.1 %: the default where it was measured to pay.
+    c->split_heads = (pf & FPC_PLAN_SPLIT_HEADS) != 0;   // (and by default where it pays: below, once nsub is final)
     if (pf & FPC_PLAN_NO_PERSISTENT_GRID) c->persist_min_tiles = 0;
     c->layer1_t816 = (pf & FPC_PLAN_LAYER1_TILE_8x16) != 0;
     c->winograd_gen = (pf & FPC_PLAN_WINOGRAD_GEN1) ? 1 : (pf & FPC_PLAN_WINOGRAD_GEN2) ? 2 : 3;
@@ -2862,6 +2865,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (cfg->nms_round_launches > 0) c->nms_passes = std::min(64, cfg->nms_round_launches);
     else if (cfg->nms_round_launches < 0) c->nms_passes = 0;
     if (const char* e = getenv("FPC_STREAMS")) nsub = std::max(1, std::min(8, atoi(e)));
+    if (!(pf & FPC_PLAN_HEADS_IN_LINE) && nsub >= 2 && !c->vgg && !c->bf16 && !c->split) c->split_heads = true;
     if (const char* e = getenv("FPC_FUSE")) c->fuse_blocks = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD")) c->winograd = atoi(e) != 0;
     if (const char* e = getenv("FPC_XCD_ORDER")) c->xcd_order = atoi(e) != 0;

@@ -100,7 +100,8 @@ enum {
   FPC_PLAN_NO_WINOGRAD_LAYER_IN1 = 1 << 3, /* descriptor.layer_in.1 as the fused direct block           (FPC_WINOGRAD_IN1=0) */
   FPC_PLAN_NO_XCD_ORDER = 1 << 4,          /* plain tile order instead of the XCD-aware one             (FPC_XCD_ORDER=0)    */
   FPC_PLAN_NO_FUSED_STEM_POOL = 1 << 5,    /* stem convolution and max-pool as two launches             (FPC_FUSE_STEM=0)    */
-  FPC_PLAN_SPLIT_HEADS = 1 << 6,           /* detector head + NMS on a side stream next to the descriptor head (FPC_SPLIT_HEADS=1) */
+  FPC_PLAN_SPLIT_HEADS = 1 << 6,           /* detector head + NMS on a side stream next to the descriptor head (FPC_SPLIT_HEADS=1): the
+                                            * default, since round 4, of the Python network in FPC_F32 with two or more sub-batches */
   FPC_PLAN_NMS_IN_LINE = 1 << 7,           /* NMS on the sub-batch stream, not on a side stream         (FPC_NMS_ASIDE=0)    */
   FPC_PLAN_NO_PERSISTENT_GRID = 1 << 8,    /* one workgroup per tile in the Winograd kernels            (FPC_PERSIST_MIN=0)  */
   FPC_PLAN_LAYER1_TILE_8x16 = 1 << 9,      /* direct layer1 blocks on 8x16 instead of 16x16 tiles       (FPC_L1_T816=1)      */
@@ -109,6 +110,7 @@ enum {
   FPC_PLAN_NMS_ONE_WORKGROUP = 1 << 12,    /* survivors of a frame sorted by one workgroup, not in slices (FPC_NMS_CHUNKED=0)   */
   FPC_PLAN_NO_FUSED_SOFTMAX = 1 << 13,     /* FPC_BF16: exp-softmax as its own launch in fpc_detect too  (FPC_FUSE_SOFTMAX=0)   */
   FPC_PLAN_WINOGRAD_GEN2 = 1 << 14,        /* round-2 Winograd kernel, F(2x2,3x3), instead of F(4x4,3x3) (FPC_WINOGRAD_GEN=2)   */
+  FPC_PLAN_HEADS_IN_LINE = 1 << 17,        /* ... and its opt-out: the two heads of a sub-batch back to back on its stream  (FPC_SPLIT_HEADS=0) */
   FPC_PLAN_DETECTOR_GEN1 = 1 << 16,        /* the detector's 65-channel blocks on round 1's kernel in batch calls too       (FPC_WINOGRAD_DET_GEN=1) */
   FPC_PLAN_GUARD_ZONES = 1 << 15           /* TEST FACILITY: 64 KiB of a canary pattern behind every buffer of the workspace and
                                               2 GiB behind the last one (the workspace grows by that much); fpc_check_guards
