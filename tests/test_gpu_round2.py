@@ -242,7 +242,8 @@ def test_plan_fields_of_fpc_config(torch_gpu, golden_dir):
              dict(nms_round_launches=5), dict(plan_flags=["nms_one_workgroup"]), dict(plan_flags=["no_winograd"]), dict(plan_flags=["no_fused_blocks"]),
              dict(plan_flags=["no_winograd_detector", "no_winograd_layer_in1", "no_xcd_order"]),
              dict(plan_flags=["no_fused_stem_pool", "nms_in_line"]), dict(plan_flags=["split_heads", "no_persistent_grid"]),
-             dict(plan_flags=["no_winograd", "layer1_tile_8x16"]), dict(plan_flags=sum(_lib.PLAN_FLAGS.values()) & ~(1 << 6))]
+             dict(plan_flags=["no_winograd", "layer1_tile_8x16"]), dict(plan_flags=sum(_lib.PLAN_FLAGS.values()) & ~(1 << 6)),
+             dict(plan_flags=["heads_in_line"])]       # (round 4: the two heads side by side are this plan's default)
     for kw in plans:
         e = engine(h, w, n, **kw)
         e.load_state_dict(sd)
@@ -251,7 +252,7 @@ def test_plan_fields_of_fpc_config(torch_gpu, golden_dir):
         assert float((lg - lref).abs().max()) < ATOL, kw
         # a call below 2 * min_sub_batch frames takes the latency plan (layer_in.1 as the fused direct block instead of
         # the Winograd launches): min_sub_batch = 2 moves these 6 frames to the other side, i.e. to other arithmetic
-        same_arith = kw.get("plan_flags", []) in ([], ["nms_one_workgroup"]) and not kw.get("min_sub_batch")
+        same_arith = kw.get("plan_flags", []) in ([], ["nms_one_workgroup"], ["heads_in_line"]) and not kw.get("min_sub_batch")
         for (xy, conf, d, nc), (rxy, rconf, rd, rnc) in zip(got, ref):
             if same_arith:      # stream / NMS-launch plans do not touch the arithmetic: bit-equal
                 assert nc == rnc

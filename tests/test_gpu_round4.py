@@ -221,3 +221,31 @@ def test_upload_stream_runs_beside_the_context_and_orders_by_events():
     del dev          # (before the contexts go: torch's allocator records an event on every stream a freed block was used on)
     e2.close()
     e.close()
+
+
+def test_sampled_timing_records_every_nth_call():
+    """fpc_set_timing(ctx, n > 1): only every n-th fpc_detect call (the first included) carries the HIP events -- what
+    bench.py's timed region uses since the event records on every call measured 0.7 % of the frame rate.  Eight calls
+    with n = 4 leave exactly twice one call's records, with the same kernels and plausible durations."""
+    h, w, n = 64, 96, 2
+    e = engine(h, w, n, num_streams=1)
+    e.load_state_dict(synth.make_state_dict(5, dustbin_bias=4.0))
+    import torch
+    frames = torch.from_numpy(synth.make_batch(21, n, h, w)).to(e.torch_device)
+    e.set_timing(True)
+    e.detect_async(frames, n)
+    e.sync()
+    one = e.timings()
+    e.set_timing(4)
+    for _ in range(8):
+        e.detect_async(frames, n)
+    e.sync()
+    got = e.timings()
+    assert len(one) > 10 and len(got) == 2 * len(one)
+    assert [t[1] for t in got[:len(one)]] == [t[1] for t in one]
+    assert all(0.0 < t[2] < 50.0 for t in got)
+    e.set_timing(False)
+    e.detect_async(frames, n)
+    e.sync()
+    assert e.timings() == []
+    e.close()
