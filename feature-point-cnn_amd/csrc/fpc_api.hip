@@ -2742,7 +2742,7 @@ static hipStream_t acquire_stream(bool probe, const std::vector<hipStream_t>& wi
   // Candidates are kept alive until the choice is made: a dropped one would free its queue for the next candidate.
   std::vector<std::pair<int, hipStream_t>> cand;
   int best = -1;
-  for (int tries = 0; tries < 8 && best < 2; ++tries) {
+  for (int tries = 0; tries < 16 && best < 2; ++tries) {
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
     int rank = 1;
     for (hipStream_t o : with)
