@@ -323,39 +323,19 @@ def streams_together_ms(a, b, spin=400000):
 def stream_beside(others, dev, tries=8):
     """A torch stream whose kernels run SIDE BY SIDE with those of every stream in `others`: the HIP runtime maps streams
     onto 4 hardware queues, a new one onto the least-used queue, and two streams on one queue run in a row.
-    A candidate is kept if a ~100 us spin on it and the same spin on each of `others` take one spin's time together, not
-    two; the candidates set aside stay alive until the choice is made (torch pools its streams anyway)."""
-    def together(a, b):
-        best = 1e9
-        for _ in range(2):
-            a.synchronize(); b.synchronize()
-            t0 = time.perf_counter()
-            with torch.cuda.stream(a):
-                torch.cuda._sleep(spin)
-            with torch.cuda.stream(b):
-                torch.cuda._sleep(spin)
-            a.synchronize(); b.synchronize()
-            best = min(best, time.perf_counter() - t0)
-        return best
+    A candidate is kept if a ~170 us spin on it and the same spin on each of `others` take one spin's time together, not
+    two (the caller-side twin of fpc_create's probe; torch pools its streams, so candidates set aside stay alive)."""
     if not others:
         return torch.cuda.Stream(device=dev)
-    spin = 400000
     probe = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(probe):
-        torch.cuda._sleep(spin)      # (first use: code object load)
-    probe.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(probe):
-        torch.cuda._sleep(spin)
-    probe.synchronize()
-    one = time.perf_counter() - t0
-    aside = [probe]
+    streams_together_ms(probe, probe)            # (first use: code object load)
+    one = streams_together_ms(probe, probe) / 2  # two spins in a row on one stream
+    last = probe
     for _ in range(tries):
-        c = torch.cuda.Stream(device=dev)
-        if all(together(c, o) < 1.6 * one for o in others):
-            return c
-        aside.append(c)
-    return aside[-1]
+        last = torch.cuda.Stream(device=dev)
+        if all(streams_together_ms(last, o) < 1.6 * one for o in others):
+            break
+    return last
 
 
 def host_fed_rates(sd, frames_np, local, dtype, steps=36):
