@@ -2727,6 +2727,7 @@ static bool streams_side_by_side(hipStream_t a, hipStream_t b) {
     hipStreamSynchronize(b);
     best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
   }
+  (void)hipGetLastError();   // (a probe on a stream that has gone meanwhile must not leave its error for a later call to find)
   return best < 240.0;   // one probe: ~170 us with its launches; two in a row: ~320
 }
 
@@ -2826,7 +2827,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   const bool qprobe = !(getenv("FPC_QUEUE_PROBE") && atoi(getenv("FPC_QUEUE_PROBE")) == 0);
   std::vector<hipStream_t> q_others, q_own, q_heavy;   // the other contexts' main / sub-batch streams on this device; this context's streams
   for (const auto& ds : g_main_streams)
-    if (ds.first == cfg->device) q_others.push_back(ds.second);
+    if (ds.first == cfg->device && ds.second) q_others.push_back(ds.second);   // (not the null stream a caller may have set)
   c->queue_probe = qprobe;
   c->stream = acquire_stream(qprobe, {}, q_others);
   if (!c->stream) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
@@ -3221,7 +3222,7 @@ int fpc_set_stream(fpc_ctx* c, void* s) {
       return false;
     };
     for (const auto& ds : g_main_streams)
-      if (ds.first == c->cfg.device && !mine(ds.second)) others.push_back(ds.second);
+      if (ds.first == c->cfg.device && ds.second && !mine(ds.second)) others.push_back(ds.second);
     auto settle = [&](hipStream_t& st, bool heavy) {
       bool ok = true;
       for (hipStream_t o : own) ok = ok && streams_side_by_side(st, o);
@@ -3257,7 +3258,7 @@ void* fpc_upload_stream(fpc_ctx* c) {
   for (const auto& ds : g_main_streams) {
     bool mine = false;
     for (hipStream_t o : own) mine = mine || o == ds.second;
-    if (ds.first == c->cfg.device && !mine) others.push_back(ds.second);
+    if (ds.first == c->cfg.device && ds.second && !mine) others.push_back(ds.second);
   }
   c->upload = acquire_stream(c->queue_probe, own, others);
   return (void*)c->upload;

@@ -196,7 +196,8 @@ int fpc_check_guards(fpc_ctx* ctx, long long* bad_words);
  * differs from the root's still completes both collectives, then returns FPC_E_INVALID.  Synchronous. */
 int fpc_broadcast_weights(fpc_ctx* ctx, void* nccl_comm, int root);
 
-/* Work is enqueued on this hipStream_t (default: a stream the ctx owns). */
+/* Work is enqueued on this hipStream_t (default: a stream the ctx owns).  A stream handed in must stay valid until
+ * fpc_destroy or the next fpc_set_stream (other ctxs of the device probe their streams against it: fpc_upload_stream). */
 int fpc_set_stream(fpc_ctx* ctx, void* hip_stream);
 void* fpc_get_stream(fpc_ctx* ctx);
 /* A hipStream_t for the CALLER's uploads (hipMemcpyAsync of the next batch while this one computes): non-blocking, owned
