@@ -114,8 +114,15 @@ struct BlockBfCfg {
 // accumulator set (the shortcut's, which conv2 continues) is born at the chunk's tenth "tap" instead of being carried
 // around the chunk loop, and no request for a "next chunk" holds the staging registers through the steps: 64 + 48 registers
 // fewer inside the unrolled steps, which is what lets a wave keep FOUR pixel blocks per weight fragment (MB = 4).
-template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP, bool ONE>
+// NCH: the number of chunks as a compile-time fact (1: ONE above; 2: a 256-channel input in two 128-channel chunks -- the
+// second accumulator set is born at the FIRST chunk's tenth tap and the last chunk requests no successor); 0: a.nchunk.
+template <class T> struct bf_chunk_index { static constexpr int value = T::value; };
+template <> struct bf_chunk_index<int> { static constexpr int value = -1; };
+template <int V> struct bf_ic { static constexpr int value = V; constexpr operator int() const { return V; } };
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP, int NCH>
 __device__ __forceinline__ void block_bf16_body(const BlockBfArgs& a) {
+  constexpr bool ONE = NCH > 0;   // (the name of round 4's first form: "the trip count is known")
   using C = BlockBfCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP>;
   constexpr int NT = C::NT, HW = C::HW, HH = C::HH, HP = C::HP, ROW16 = C::ROW16, K16 = KC / 16, KC8 = KC / 8;
   constexpr int NV = HH * HW * KC8, ITER = (NV + NT - 1) / NT, ROWH16 = C::ROWH16, NBT = WN * NB;
@@ -325,12 +332,14 @@ __device__ __forceinline__ void block_bf16_body(const BlockBfArgs& a) {
     // in a register ring whose slots are compile-time names (through a buffer descriptor too: the lane's offset in a
     // VGPR that never changes, the step in the scalar offset, and a request past the last step returns zeros), and a
     // step's pixels are read while the previous step's MFMAs run.
-    for (int chunk = 0; chunk < (ONE ? 1 : a.nchunk); ++chunk) {
+    auto run_chunk = [&](auto chunk_c) {
+      const int chunk = chunk_c;
+      constexpr int CI = bf_chunk_index<decltype(chunk_c)>::value;   // the chunk's index where it is a compile-time fact, else -1
       FPC_LDS_BARRIER();   // the previous chunk's pixels have been read
       store_chunk();
       FPC_LDS_BARRIER();
       if (chunk == 0) { FPC_STAMP(1) }
-      if (!ONE) load_chunk(cur, chunk + 1);
+      if (!ONE || CI + 1 < NCH) load_chunk(cur, chunk + 1);
       u32x4 av[MB], an[MB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const u32x4*>(&lds16[abase[mb] + a.tapoff16[0]]);
@@ -355,7 +364,7 @@ __device__ __forceinline__ void block_bf16_body(const BlockBfArgs& a) {
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[st % D][nb]),
                                                                     __builtin_bit_cast(bf16x8, av[mb]), acc[mb][nb], 0, 0, 0);
         } else {
-          if (ONE && st == 9 * K16) {   // the shortcut's accumulators start here
+          if (ONE && CI == 0 && st == 9 * K16) {   // the shortcut's accumulators start here
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -379,6 +388,14 @@ __device__ __forceinline__ void block_bf16_body(const BlockBfArgs& a) {
         for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
         __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the ring's requests to just before their use)
       }
+    };
+    if constexpr (NCH == 1) {
+      run_chunk(bf_ic<0>{});
+    } else if constexpr (NCH == 2) {
+      run_chunk(bf_ic<0>{});
+      run_chunk(bf_ic<1>{});
+    } else {
+      for (int chunk = 0; chunk < a.nchunk; ++chunk) run_chunk(chunk);
     }
   } else {
 #pragma unroll
@@ -715,12 +732,17 @@ __device__ __forceinline__ void block_bf16_body(const BlockBfArgs& a) {
 
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
 __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_kernel(const BlockBfArgs a) {
-  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, false>(a);
+  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 0>(a);
 }
 // the one-chunk form (3x3 blocks whose Cin_pad == KC: layer1, detector.layer.1)
 template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
 __global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_one_kernel(const BlockBfArgs a) {
-  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, true>(a);
+  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 1>(a);
+}
+// the two-chunk form (Cin_pad == 2 KC: layer_out.0, layer_in.1 on 128-channel chunks)
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB, int CMIDP>
+__global__ __launch_bounds__(WM* WN * 64, 2) void block_bf16_two_kernel(const BlockBfArgs a) {
+  block_bf16_body<TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP, 2>(a);
 }
 
 }  // namespace fpc

@@ -296,7 +296,7 @@ static WKind w36_kind(int cout, int H, int W) {
   X(F816_s1_K128_C80w, block_bf16_one_kernel, BlockBfCfg, 1, 8, 16, 1, 3, 128, 1, 4, 4, 1, 80) \
   X(F620_s2_K64_C128, block_bf16_one_kernel, BlockBfCfg, 1, 6, 20, 2, 3, 64, 2, 2, 2, 2, 128) \
   X(F320_s2_K128_C256, block_bf16_one_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 128, 1, 4, 2, 2, 256) \
-  X(F416_s1_K64_C256, block_bf16_kernel, BlockBfCfg, 1, 4, 16, 1, 3, 64, 1, 4, 2, 2, 256)   \
+  X(F416_s1_K128_C256, block_bf16_two_kernel, BlockBfCfg, 1, 4, 16, 1, 3, 128, 1, 4, 2, 2, 256) \
   X(F816_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 2, 64, 1, 4, 4, 1, 128)   \
   X(S816_s1_K64_C64, block_x3_kernel, BlockX3Cfg, 3, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)       \
   X(S620_s2_K16_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)     \
@@ -948,6 +948,7 @@ static void add_fblock(fpc_ctx* c, const FBlockSpec& s, size_t* blob_off) {
   a.nchunk = s.cin_pad / k.KC;
   // block_bf16_one_kernel: the single chunk is a compile-time fact of the instance (block_bf16.h)
   if (strstr(k.symbol, "block_bf16_one_kernel") && a.nchunk != 1) { c->plan_error = true; return; }
+  if (strstr(k.symbol, "block_bf16_two_kernel") && a.nchunk != 2) { c->plan_error = true; return; }
   a.H = s.H;
   a.W = s.W;
   a.ntaps = 9;
@@ -1079,7 +1080,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   }
   if (de) {
     add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K128_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
-    add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K64_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
+    add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K128_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
     add_fconvT(c, FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
     add_fblock(c, {"descriptor.layer_out.0", FK_F816_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
     // (the descriptor map is bf16 as well -- round 3: descriptor16_kernel<8, true> reads it, fpc_forward / the tap convert it)
