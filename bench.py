@@ -97,7 +97,7 @@ if __name__ == "__main__":
     # (HIP multiplexes streams onto 4 hardware queues by default, a new stream onto the least-used one.  More queues
     # (GPU_MAX_HW_QUEUES=5, 6, 8) were measured again in round 4, with the streams probed: the device-resident headline loses
     # 5 %, the host-fed legs 5-25 %.  Left at the default; what matters is WHICH streams share a queue -- fpc_create and
-    # stream_beside below see to that.)
+    # fpc_upload_stream see to that: csrc/queue_map.h.)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -304,40 +304,6 @@ def cpu_baseline_vgg_reference(sd, frames):
                       "with libtorch CPU, %d runs of %.2f s); the rest of cpp/ needs TRTorch/OpenCV" % (n, W, H, reps, sec)}
 
 
-def streams_together_ms(a, b, spin=400000):
-    """wall time of one ~170 us spin on each of two streams, issued back to back (best of two): one spin's time if the
-    streams sit on different hardware queues, two if they share one."""
-    best = 1e9
-    for _ in range(2):
-        a.synchronize(); b.synchronize()
-        t0 = time.perf_counter()
-        with torch.cuda.stream(a):
-            torch.cuda._sleep(spin)
-        with torch.cuda.stream(b):
-            torch.cuda._sleep(spin)
-        a.synchronize(); b.synchronize()
-        best = min(best, time.perf_counter() - t0)
-    return best * 1e3
-
-
-def stream_beside(others, dev, tries=8):
-    """A torch stream whose kernels run SIDE BY SIDE with those of every stream in `others`: the HIP runtime maps streams
-    onto 4 hardware queues, a new one onto the least-used queue, and two streams on one queue run in a row.
-    A candidate is kept if a ~170 us spin on it and the same spin on each of `others` take one spin's time together, not
-    two (the caller-side twin of fpc_create's probe; torch pools its streams, so candidates set aside stay alive)."""
-    if not others:
-        return torch.cuda.Stream(device=dev)
-    probe = torch.cuda.Stream(device=dev)
-    streams_together_ms(probe, probe)            # (first use: code object load)
-    one = streams_together_ms(probe, probe) / 2  # two spins in a row on one stream
-    last = probe
-    for _ in range(tries):
-        last = torch.cuda.Stream(device=dev)
-        if all(streams_together_ms(last, o) < 1.6 * one for o in others):
-            break
-    return last
-
-
 def host_fed_rates(sd, frames_np, local, dtype, steps=36):
     """H2D-inclusive rates (the second figure, never `value`): every step uploads its batch from pinned host
     memory and runs the path.  (a) the reference's input, fp32 RGB [n,3,H,W]; (b) 8-bit RGB HWC frames converted on
@@ -355,27 +321,20 @@ def host_fed_rates(sd, frames_np, local, dtype, steps=36):
     nbuf = 3
     for tag, host in (("f32_rgb_nchw", torch.from_numpy(frames_np).pin_memory()),
                       ("u8_rgb_hwc", torch.from_numpy(np.ascontiguousarray(u8)).pin_memory())):
-        # (round 4: the three streams of the loop are PICKED so that they share no hardware queue -- stream_beside, the
-        # caller-side twin of fpc_create's probe.  With torch's pooled streams as they come, which stream shared a queue
-        # with which was the process's history: fp32 frames read 69 % of the device-resident rate and 8-bit ones 95 %, and
-        # after an unrelated change the other way round)
-        ctxs, taken = [], []
+        # The loop's three streams -- two contexts, one upload -- sit on three different hardware queues because the LIBRARY
+        # places them (csrc/queue_map.h): a context's main stream avoids the queues of the other live contexts' main
+        # streams, and fpc_upload_stream hands out a stream beside both.  (Round 4 picked torch streams here with a
+        # host-clock probe of its own; with torch's pooled streams as they come, which stream shared a queue with which
+        # was the process's history: fp32 frames read 69 % of the device-resident rate and 8-bit ones 95 %, and after an
+        # unrelated change the other way round.)  NMS in line: a context is ONE stream then, and nothing of it is left
+        # to land on the upload stream's queue.
+        ctxs = []
         for _ in range(2):
-            st = stream_beside(taken, dev)
-            taken.append(st)
-            # (NMS in line: a context is ONE stream then, and the loop's three streams -- two contexts, one upload -- fit the
-            # four hardware queues with nothing left to chance; a side stream for the NMS launches is +0.3 % device-resident and,
-            # one run in six, landed on the upload stream's queue: fp32 frames at 7 600 frames/s instead of 10 850)
             e = Engine(H, W, max_batch=BATCH, device=local, dtype=dtype, num_streams=1, plan_flags=["nms_in_line"])
             e.load_state_dict(sd)
-            with torch.cuda.stream(st):
-                e.use_torch_stream()
-            ctxs.append((st, e))
-        copy_stream = stream_beside(taken, dev)
-        if os.environ.get("FPC_BENCH_DEBUG_STREAMS"):
-            sys.stderr.write("[bench] %s: copy|ctx0 %.3f ms, copy|ctx1 %.3f ms, ctx0|ctx1 %.3f ms (one spin ~0.2)\n" % (
-                tag, streams_together_ms(copy_stream, taken[0]), streams_together_ms(copy_stream, taken[1]),
-                streams_together_ms(taken[0], taken[1])))
+            ctxs.append((e.torch_stream(), e))
+        copy_stream = ctxs[0][1].upload_stream()
+        placement = [e.stream_report()["streams"] for _, e in ctxs]
         bufs = [torch.empty_like(host, device=dev) for _ in range(nbuf)]
         uploaded = [torch.cuda.Event() for _ in range(nbuf)]
         consumed = [torch.cuda.Event() for _ in range(nbuf)]
@@ -421,14 +380,13 @@ def host_fed_rates(sd, frames_np, local, dtype, steps=36):
                     (e.detect_u8_async(bufs[i % nbuf], BATCH, "rgb_hwc") if tag == "u8_rgb_hwc" else e.detect_async(bufs[i % nbuf], BATCH))
             torch.cuda.synchronize(dev)
             dk = (time.perf_counter() - t1) / 8
-            # A step that costs compute + more than half an upload has its uploads in a row with a context's launches: one run in
-            # five of the full default run, cause not found (the three streams measure side by side beforehand).  Said, not
-            # hidden: another upload stream is picked, the leg repeated, `attempts` reported.
+            # A step that costs compute + more than half an upload has its uploads in a row with a context's launches (round 4:
+            # one run in five of the full default run).  Said, not hidden: the leg is repeated, `attempts` reported.
             if dt / steps < dk + 0.5 * dc or attempts >= 3:
                 break
-            copy_stream = stream_beside(taken, dev)
         nbytes = host.numel() * host.element_size()
         res[tag] = {"value": round(BATCH * steps / dt, 2), "unit": "frames/s", "steps": steps, "attempts": attempts,
+                    "stream_queues": placement,
                     "compute_alone_ms_per_batch": round(dk * 1e3, 3),
                     "h2d_bytes_per_frame": int(host[0].numel() * host.element_size()),
                     "h2d_gbytes_per_s": round(nbytes * steps / dt / 1e9, 2),
@@ -639,6 +597,11 @@ def aggregate_over_ranks(world, my_dt, dt, bcast_ms, steps, batch):
     return dt, value, per_rank
 
 
+def rank_frame_seed(rank, batch):
+    """First seed of a rank's synthetic frames: 100 + batch * rank (seeds 100..355 over 8 GPUs)."""
+    return 100 + batch * rank
+
+
 def bind_cpu_threads(world):
     """N ranks on one node share the host: each takes cores // N threads for its host-side work (frame synthesis, the
     host-fed legs, torch's intra-op pool), so 8 ranks do not oversubscribe the box.  Returns the thread count."""
@@ -714,8 +677,20 @@ def main():
         if world > 1:
             tdist.all_gather(allr, mine)
             fdist.barrier()
+        # what every rank of the real run derives from its rank: its frames' first seed (seeds
+        # 100 .. 355 over 8 GPUs = 100 + 32 * rank) and, for a caller that shards ONE batch of 32 * world frames instead
+        # (configs[2]: 256 frames on 8 GPUs), its contiguous shard -- gathered in rank order
+        lo, hi = fdist.shard_range(BATCH * world, world, rank)
+        facts = torch.tensor([rank, rank_frame_seed(rank, BATCH), lo, hi, host_threads], dtype=torch.int64)
+        allf = [torch.zeros_like(facts) for _ in range(world)]
+        if world > 1:
+            tdist.all_gather(allf, facts)
+        else:
+            allf = [facts]
         rec = {"rendezvous": "ok", "world": world, "ranks": [int(t.item()) for t in allr] if world > 1 else [0],
-               "backend": tdist.get_backend() if world > 1 else None, "host_threads_per_rank": host_threads}
+               "backend": tdist.get_backend() if world > 1 else None, "host_threads_per_rank": host_threads,
+               "frame_seed0": [int(f[1]) for f in allf], "shards": [[int(f[2]), int(f[3])] for f in allf],
+               "host_threads": [int(f[4]) for f in allf]}
         fake = os.environ.get("FPC_BENCH_FAKE_STEP_MS")
         if fake:
             ms = [float(v) for v in fake.split(",")]
@@ -742,20 +717,26 @@ def main():
     kw1 = dict(kw)                       # a context on its own: the library's default plan (two sub-batches on two streams)
     if args.contexts > 1 and "FPC_STREAMS" not in os.environ:
         kw["num_streams"] = 1            # contexts in turn: each runs its whole batch as one sub-batch
+    tc0 = time.perf_counter()
     eng = Engine(H, W, max_batch=BATCH, **kw)
+    first_create_ms = (time.perf_counter() - tc0) * 1e3   # the process's first fpc_create: code object load, anchor search, workspace
     fdist.barrier()
     tb0 = time.perf_counter()
     fdist.broadcast_packed_weights(eng, sd)
     torch.cuda.synchronize(dev)
     bcast_ms = (time.perf_counter() - tb0) * 1e3      # rank 0: parse + pack + broadcast; others: wait + receive + import
     engs = [eng]
+    create_ms = None
     for _ in range(1, max(1, args.contexts)):
+        tc0 = time.perf_counter()
         e2 = Engine(H, W, max_batch=BATCH, **kw)
-        e2.import_packed(eng.export_packed())
+        create_ms = (time.perf_counter() - tc0) * 1e3       # a later fpc_create: stream placement + workspace only
+        e2.import_packed_device(eng.packed_view())          # device to device
         engs.append(e2)
+    stream_reports = [e_.stream_report() for e_ in engs]
     # this rank's frames: seeds 100 + 32*rank ... (configs[2]: seeds 100..355 over 8 GPUs)
     nbase = BATCH if H * W <= 480 * 640 else 8      # HD: 8 distinct frames, shifted copies fill the batch
-    frames_np = synth.make_batch(100 + BATCH * rank, nbase, H, W, gray=args.gray)
+    frames_np = synth.make_batch(rank_frame_seed(rank, BATCH), nbase, H, W, gray=args.gray)
     if nbase < BATCH:
         frames_np = np.concatenate([np.roll(frames_np, 16 * k, axis=3) for k in range(BATCH // nbase)], 0)
     if args.gray:
@@ -943,6 +924,10 @@ def main():
             "candidates_per_frame": round(float(np.mean(ncand)), 1),
             "weights_broadcast_ms": round(bcast_ms, 2),
             "host_threads_per_rank": host_threads,
+            # what fpc_create costs (include/fpc.h: fpc_stream_report): the process's first one carries the code object's
+            # load and the search for one anchor stream per hardware queue; a later one only places its own streams
+            "create": {"first_create_ms": round(first_create_ms, 2), "create_ms": round(create_ms, 2) if create_ms is not None else None,
+                       "stream_placement": stream_reports},
         }
         out["config"]["contexts"] = args.contexts
         out["config"]["batches_in_flight"] = ("%d contexts in turn, each a whole 32-frame batch per call on one stream: batch k+1 starts while "

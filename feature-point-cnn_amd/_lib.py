@@ -22,15 +22,15 @@ CSRC = os.path.join(_DIR, "csrc")
 SYMBOLS = [
     "fpc_abi_version", "fpc_build_flags", "fpc_strerror", "fpc_last_hip_error", "fpc_default_config", "fpc_create",
     "fpc_destroy", "fpc_load_weights", "fpc_packed_size", "fpc_packed_device_ptr",
-    "fpc_export_packed", "fpc_import_packed", "fpc_mark_weights_loaded", "fpc_set_stream", "fpc_upload_stream",
+    "fpc_export_packed", "fpc_import_packed", "fpc_import_packed_device", "fpc_mark_weights_loaded", "fpc_set_stream", "fpc_upload_stream",
     "fpc_get_stream", "fpc_sync", "fpc_forward", "fpc_detect", "fpc_get_points", "fpc_results",
     "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
     "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation", "fpc_detect_u8_resized",
     "fpc_sample_descriptors", "fpc_plan_hash", "fpc_broadcast_weights", "fpc_read_activation",
-    "fpc_pack_layout_revision", "fpc_check_guards",
+    "fpc_pack_layout_revision", "fpc_check_guards", "fpc_stream_report",
 ]
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PACK_LAYOUT_REVISION = 3      # include/fpc.h FPC_PACK_LAYOUT_REVISION
 
 # fpc_config.plan_flags (include/fpc.h, FPC_PLAN_*)
@@ -61,6 +61,14 @@ class FpcDeviceResults(ctypes.Structure):
     _fields_ = [("count", ctypes.c_void_p), ("n_candidates", ctypes.c_void_p), ("xy", ctypes.c_void_p),
                 ("conf", ctypes.c_void_p), ("desc", ctypes.c_void_p), ("capacity", ctypes.c_int),
                 ("desc_dim", ctypes.c_int)]
+
+
+class FpcStreamReport(ctypes.Structure):
+    _fields_ = [("n_streams", ctypes.c_int), ("slot", ctypes.c_int * 16), ("queue", ctypes.c_int * 16),
+                ("probing", ctypes.c_int), ("hw_queues_found", ctypes.c_int), ("process_probe_rounds", ctypes.c_int),
+                ("process_probe_launches", ctypes.c_int), ("process_inconclusive_rounds", ctypes.c_int),
+                ("process_probe_ms", ctypes.c_float), ("create_probe_rounds", ctypes.c_int),
+                ("create_placement_ms", ctypes.c_float), ("process_registered_streams", ctypes.c_int)]
 
 
 class FpcError(RuntimeError):
@@ -109,6 +117,7 @@ def load():
     l.fpc_packed_device_ptr.restype = vp
     l.fpc_export_packed.argtypes = [vp, vp, ctypes.c_size_t]
     l.fpc_import_packed.argtypes = [vp, vp, ctypes.c_size_t]
+    l.fpc_import_packed_device.argtypes = [vp, vp, ctypes.c_size_t]
     l.fpc_mark_weights_loaded.argtypes = [vp]
     l.fpc_set_stream.argtypes = [vp, vp]
     l.fpc_upload_stream.argtypes = [vp]
@@ -136,6 +145,7 @@ def load():
     l.fpc_broadcast_weights.argtypes = [vp, vp, ci]
     l.fpc_pack_layout_revision.restype = ci
     l.fpc_check_guards.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
+    l.fpc_stream_report.argtypes = [vp, ctypes.POINTER(FpcStreamReport)]
     l.fpc_set_timing.argtypes = [vp, ci]
     l.fpc_get_timings.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double),

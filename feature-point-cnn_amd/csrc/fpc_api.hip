@@ -29,6 +29,7 @@
 #include "wblock36_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
+#include "queue_map.h"
 #include "match.h"
 #include "homography.h"
 #include "weights.h"
@@ -415,7 +416,10 @@ struct fpc_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t upload = nullptr;       // fpc_upload_stream: the caller's copy stream, on a hardware queue of its own
-  bool queue_probe = true;            // fpc_create probed the streams for hardware queues of their own (FPC_QUEUE_PROBE)
+  bool queue_probe = true;            // fpc_create placed the streams on hardware queues of their own (queue_map.h; FPC_QUEUE_PROBE)
+  int probe_rounds = 0;               // ... with this many probe rounds, in this much host time (fpc_stream_report)
+  double placement_ms = 0.0;
+  std::vector<std::pair<hipStream_t, int>> caller_stream_memo;   // fpc_set_stream: queue classes of the caller's streams seen before (at most 4)
   std::vector<hipStream_t> aux;      // extra streams for sub-batches
   std::vector<hipEvent_t> ev_join;
   std::vector<hipStream_t> side;     // per sub-batch: detector head + NMS next to the descriptor head
@@ -2564,6 +2568,9 @@ static void run_desc(fpc_ctx* c, const Sub& sb, const float* dmap_nhwc) {
 // Splits [0,n) over the ctx's streams; aux streams fork from / join into the main stream.
 template <typename F>
 static int for_each_sub(fpc_ctx* c, int n, F&& body) {
+  // fpc_set_timing(n > 1): every n-th pass over a batch carries the events -- decided HERE, for every entry point alike
+  // (fpc_detect, fpc_forward, fpc_detect_u8*, each network pass of fpc_homography_adaptation)
+  if (c->timing_every > 1) c->timing = c->timing_calls++ % c->timing_every == 0;
   int parts = std::min<int>((int)c->aux.size() + 1, std::max(1, n / c->min_sub));
   if (parts > 1) HIPCHECK(hipEventRecord(c->ev_fork, c->stream));
   int f0 = 0;
@@ -2700,75 +2707,53 @@ int fpc_default_config(fpc_config* cfg) {
 }
 
 // ------------------------------------------------------------------------------------
-// Streams on distinct hardware queues
+// Streams on distinct hardware queues: queue_map.h (anchors, device timestamps, a registry of the live contexts' streams)
 // ------------------------------------------------------------------------------------
-// The runtime maps streams onto GPU_MAX_HW_QUEUES (4) hardware queues, a new stream onto the least-used one -- which one
-// that is depends on every stream the PROCESS has made and dropped before.  Two streams on one queue run their kernels
-// in a row: with the two sub-batch streams of a context on one queue the context is a one-stream context.  Measured
-// (round 4, 64 HD frames, bf16): the same engine gave 12 790 / 12 770 / 12 110 / 11 620 / 12 780 / 12 730 frames/s with
-// 0 .. 5 unrelated streams created in the process before it -- and the bounded pass of that workload inside the default
-// bench run (several engines made and closed before it) read 3 % under the workload's own run for that reason.
-// So fpc_create PROBES: a candidate stream is kept only if a 150 us one-wave kernel on it runs SIDE BY SIDE with the
-// same kernel on every stream it has to be concurrent with (this context's streams, and the main streams of the other
-// live contexts of the device); a candidate that shares a queue is set aside, and after a few candidates the best of
-// those set aside is taken (never worse than an unprobed stream).  FPC_QUEUE_PROBE=0 switches the probe off.
-static std::mutex g_queue_mu;
-static std::vector<std::pair<int, hipStream_t>> g_main_streams;   // (device, main / sub-batch stream) of the live contexts
+enum { SLOT_MAIN = 0, SLOT_AUX = 1, SLOT_SIDE = 100, SLOT_UPLOAD = 200 };
 
-static bool streams_side_by_side(hipStream_t a, hipStream_t b) {
-  const unsigned ticks = 15000;   // 150 us
-  double best = 1e30;
-  for (int rep = 0; rep < 2; ++rep) {
-    hipStreamSynchronize(a);
-    hipStreamSynchronize(b);
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, a, ticks);
-    hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, b, ticks);
-    hipStreamSynchronize(a);
-    hipStreamSynchronize(b);
-    best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+// Dynamic-LDS limits of every kernel instance and the occupancy table of the bf16 / split-operand instances.
+static int prepare_kernels(fpc_ctx* c, const fpc_config* cfg) {
+  for (int k = 0; k < K_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
+  for (int k = 0; k < WK_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_wkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_wkinds[k].lds_bytes));
+  for (int k = 0; k < BK_COUNT; ++k)
+    HIPCHECK(hipFuncSetAttribute(g_bkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bkinds[k].lds_bytes));
+  static_assert(FK_COUNT <= 64, "fpc_ctx::fkind_blocks_per_cu");
+  for (int k = 0; k < FK_COUNT; ++k) {
+    HIPCHECK(hipFuncSetAttribute(g_fkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_fkinds[k].lds_bytes));
+    int nb = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_fkinds[k].fn, g_fkinds[k].WM * g_fkinds[k].WN * 64, g_fkinds[k].lds_bytes));
+    c->fkind_blocks_per_cu[k] = std::max(1, nb);
+#ifdef FPC_DIAG
+    hipFuncAttributes fa{};
+    hipFuncGetAttributes(&fa, g_fkinds[k].fn);
+    fprintf(stderr, "[diag] %s: lds %d B, regs %d, scratch %zu, occupancy %d blocks/CU\n", g_fkinds[k].name, g_fkinds[k].lds_bytes, fa.numRegs, fa.localSizeBytes, nb);
+#endif
   }
-  (void)hipGetLastError();   // (a probe on a stream that has gone meanwhile must not leave its error for a later call to find)
-  return best < 240.0;   // one probe: ~170 us with its launches; two in a row: ~320
-}
-
-// a new non-blocking stream that runs side by side with every stream of `with` and, if the runtime has such a queue
-// left, of `prefer`
-static hipStream_t acquire_stream(bool probe, const std::vector<hipStream_t>& with, const std::vector<hipStream_t>& prefer) {
-  hipStream_t st = nullptr;
-  if (!probe || (with.empty() && prefer.empty())) {
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    return st;
+  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               12 * cfg->width * (int)sizeof(float)));
+  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               12 * cfg->width * (int)sizeof(float)));
+  HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<1>::LDS_BYTES));
+  HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<3>::LDS_BYTES));
+  HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
+#ifdef FPC_DIAG
+  for (int k = 0; k < BK_COUNT; ++k) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_bkinds[k].fn, g_bkinds[k].WM * g_bkinds[k].WN * 64, g_bkinds[k].lds_bytes);
+    hipFuncAttributes fa{};
+    hipFuncGetAttributes(&fa, g_bkinds[k].fn);
+    fprintf(stderr, "[diag] %s: lds %d B, regs %d, static lds %zu, occupancy %d blocks/CU\n", g_bkinds[k].name, g_bkinds[k].lds_bytes, fa.numRegs, fa.sharedSizeBytes, nb);
   }
-  // rank of a candidate: 2 = beside all of `with` and `prefer`, 1 = beside all of `with`, 0 = shares a queue with one of `with`.
-  // Candidates are kept alive until the choice is made: a dropped one would free its queue for the next candidate.
-  std::vector<std::pair<int, hipStream_t>> cand;
-  int best = -1;
-  for (int tries = 0; tries < 16 && best < 2; ++tries) {
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-    int rank = 1;
-    for (hipStream_t o : with)
-      if (rank && !streams_side_by_side(st, o)) rank = 0;
-    if (rank == 1) {
-      rank = 2;
-      for (hipStream_t o : prefer)
-        if (rank == 2 && !streams_side_by_side(st, o)) rank = 1;
-    }
-    cand.push_back({rank, st});
-    best = std::max(best, rank);
+  for (int k = 0; k < K_COUNT; ++k) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_kinds[k].fn, g_kinds[k].threads, g_kinds[k].lds_bytes);
+    fprintf(stderr, "[diag] %s: lds %d B, occupancy %d blocks/CU\n", g_kinds[k].name, g_kinds[k].lds_bytes, nb);
   }
-  st = nullptr;
-  for (auto& rc : cand)
-    if (rc.first == best && !st) {
-      st = rc.second;
-      rc.second = nullptr;
-    }
-  for (auto& rc : cand)
-    if (rc.second) hipStreamDestroy(rc.second);
-  if (getenv("FPC_QUEUE_PROBE") && atoi(getenv("FPC_QUEUE_PROBE")) == 2)
-    fprintf(stderr, "[fpc] acquire_stream: %zu candidates for a stream beside %zu of this context / %zu of others: %s\n", cand.size(),
-            with.size(), prefer.size(), best == 2 ? "beside all" : best == 1 ? "beside this context's" : best == 0 ? "SHARES a queue" : "none");
-  return st;
+#endif
+  return FPC_OK;
 }
 
 int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
@@ -2823,17 +2808,17 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->cap = cfg->max_keypoints > 0 ? cfg->max_keypoints : worst;
   c->sort_cap = 1;
   while (c->sort_cap < worst) c->sort_cap <<= 1;
-  // (streams: probed for hardware queues of their own -- "Streams on distinct hardware queues" above)
-  std::lock_guard<std::mutex> queue_lock(g_queue_mu);
-  const bool qprobe = !(getenv("FPC_QUEUE_PROBE") && atoi(getenv("FPC_QUEUE_PROBE")) == 0);
-  std::vector<hipStream_t> q_others, q_own, q_heavy;   // the other contexts' main / sub-batch streams on this device; this context's streams
-  for (const auto& ds : g_main_streams)
-    if (ds.first == cfg->device && ds.second) q_others.push_back(ds.second);   // (not the null stream a caller may have set)
+  // Streams: placed on hardware queues of their own (queue_map.h).  The registry's lock is held while this context's
+  // streams are chosen and registered, and RELEASED before anything that can fail and call fpc_destroy (round 4 held it
+  // to the end of the function: a failing build_plan then deadlocked on fpc_destroy's own lock).
+  const bool qprobe = qmap::probe_mode() != 0;
   c->queue_probe = qprobe;
-  c->stream = acquire_stream(qprobe, {}, q_others);
-  if (!c->stream) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
+  const auto create_t0 = std::chrono::steady_clock::now();
+  std::unique_lock<std::mutex> queue_lock(qmap::state().mu);
+  const int probe_rounds0 = qmap::state().dev[cfg->device].rounds;
+  c->stream = qmap::acquire(cfg->device, c.get(), SLOT_MAIN, true, qprobe, true);
+  if (!c->stream) { qmap::release_owner(c.get()); g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
   c->own_stream = true;
-  q_own.push_back(c->stream);
   {
     // Launch-plan knobs: fpc_config fields (include/fpc.h, FPC_PLAN_*) first, then the FPC_* environment variables as
     // overrides for A/B runs of an unmodified caller.
@@ -2879,21 +2864,25 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     if (const char* e = getenv("FPC_NMS_PASSES")) c->nms_passes = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("FPC_NMS_G")) c->nms_g = std::max(0, std::min(64, atoi(e)));
     if (getenv("FPC_L1_T816")) c->layer1_t816 = true;
-    HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    // (from here to the end of the stream block: a failure leaves through `fail`, which drops the lock first)
+    auto fail = [&](const char* what) {
+      g_hip_err = what;
+      queue_lock.unlock();
+      fpc_destroy(c.release());
+      return FPC_E_HIP;
+    };
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreateWithFlags");
     for (int i = 1; i < nsub; ++i) {
-      hipStream_t st = acquire_stream(qprobe, q_own, q_others);
+      hipStream_t st = qmap::acquire(cfg->device, c.get(), SLOT_AUX + (i - 1), true, qprobe, true);
       hipEvent_t ev;
-      if (!st) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
-      HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      if (!st) return fail("hipStreamCreateWithFlags");
       c->aux.push_back(st);
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreateWithFlags");
       c->ev_join.push_back(ev);
-      q_own.push_back(st);
     }
-    q_heavy = q_own;   // main + sub-batch streams: what other contexts keep clear of (registered once fpc_create has succeeded)
-    // FPC_SPLIT_HEADS=1 (detector head + NMS of a sub-batch on a side stream next to its descriptor head) measures +1 %
-    // frames/s for the Python network in the fp32-MFMA mode (8 200 vs 8 120, same box) and -2 % for the C++ network; it
-    // stays off by default: with three kernels sharing the GPU every launch stretches (the dominant kernel's mean launch
-    // 0.26 -> 0.30 ms), which is all a per-kernel roofline measured inside the timed region would show of it.
+    // FPC_SPLIT_HEADS (detector head + NMS of a sub-batch on a side stream next to its descriptor head): the default of
+    // the Python network in FPC_F32 with two or more sub-batches since round 4 (above: +1 % with the streams on queues of
+    // their own; the C++ network loses 2 % with it); the variable overrides either way.
     if (const char* e = getenv("FPC_SPLIT_HEADS")) c->split_heads = atoi(e) != 0;
     c->nms_aside = !c->split;  // measured: +1.5 % with two sub-batches (fp32-MFMA kernels), nothing with three (split modes)
     if (pf & FPC_PLAN_NMS_IN_LINE) c->nms_aside = false;
@@ -2905,58 +2894,27 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
       hipStream_t st = nullptr;
       hipEvent_t e1, e2;
       if (i < nside) {
-        st = acquire_stream(qprobe, q_own, q_others);
-        if (!st) { g_hip_err = "hipStreamCreateWithFlags"; return FPC_E_HIP; }
-        q_own.push_back(st);
+        st = qmap::acquire(cfg->device, c.get(), SLOT_SIDE + i, false, qprobe, true);
+        if (!st) return fail("hipStreamCreateWithFlags");
       }
-      HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-      HIPCHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
       c->side.push_back(st);
+      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreateWithFlags");
       c->ev_enc.push_back(e1);
+      if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreateWithFlags");
       c->ev_det.push_back(e2);
     }
+    c->probe_rounds = qmap::state().dev[cfg->device].rounds - probe_rounds0;
+    c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - create_t0).count();
+    queue_lock.unlock();
   }
-  for (int k = 0; k < K_COUNT; ++k)
-    HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
-  for (int k = 0; k < WK_COUNT; ++k)
-    HIPCHECK(hipFuncSetAttribute(g_wkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_wkinds[k].lds_bytes));
-  for (int k = 0; k < BK_COUNT; ++k)
-    HIPCHECK(hipFuncSetAttribute(g_bkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bkinds[k].lds_bytes));
-  static_assert(FK_COUNT <= 64, "fpc_ctx::fkind_blocks_per_cu");
-  for (int k = 0; k < FK_COUNT; ++k) {
-    HIPCHECK(hipFuncSetAttribute(g_fkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_fkinds[k].lds_bytes));
-    int nb = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_fkinds[k].fn, g_fkinds[k].WM * g_fkinds[k].WN * 64, g_fkinds[k].lds_bytes));
-    c->fkind_blocks_per_cu[k] = std::max(1, nb);
-#ifdef FPC_DIAG
-    hipFuncAttributes fa{};
-    hipFuncGetAttributes(&fa, g_fkinds[k].fn);
-    fprintf(stderr, "[diag] %s: lds %d B, regs %d, scratch %zu, occupancy %d blocks/CU\n", g_fkinds[k].name, g_fkinds[k].lds_bytes, fa.numRegs, fa.localSizeBytes, nb);
-#endif
+  int rc = prepare_kernels(c.get(), cfg);
+  // (test hook: the failure path below -- streams, events, registry entries and whatever build_plan had allocated given
+  // back, the error code returned -- cannot be reached on this pool's 288 GB otherwise)
+  if (rc == FPC_OK && getenv("FPC_TEST_FAIL_CREATE")) {
+    g_hip_err = "FPC_TEST_FAIL_CREATE is set: fpc_create's failure path was asked for";
+    rc = FPC_E_HIP;
   }
-  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               12 * cfg->width * (int)sizeof(float)));
-  HIPCHECK(hipFuncSetAttribute((const void*)softmax_d2s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               12 * cfg->width * (int)sizeof(float)));
-  HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<1>::LDS_BYTES));
-  HIPCHECK(hipFuncSetAttribute((const void*)stem_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, StemB2Cfg<3>::LDS_BYTES));
-  HIPCHECK(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               NMS_LDS_KEYS * (int)sizeof(unsigned long long)));
-#ifdef FPC_DIAG
-  for (int k = 0; k < BK_COUNT; ++k) {
-    int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_bkinds[k].fn, g_bkinds[k].WM * g_bkinds[k].WN * 64, g_bkinds[k].lds_bytes);
-    hipFuncAttributes fa{};
-    hipFuncGetAttributes(&fa, g_bkinds[k].fn);
-    fprintf(stderr, "[diag] %s: lds %d B, regs %d, static lds %zu, occupancy %d blocks/CU\n", g_bkinds[k].name, g_bkinds[k].lds_bytes, fa.numRegs, fa.sharedSizeBytes, nb);
-  }
-  for (int k = 0; k < K_COUNT; ++k) {
-    int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_kinds[k].fn, g_kinds[k].threads, g_kinds[k].lds_bytes);
-    fprintf(stderr, "[diag] %s: lds %d B, occupancy %d blocks/CU\n", g_kinds[k].name, g_kinds[k].lds_bytes, nb);
-  }
-#endif
-  int rc = build_plan(c.get());
+  if (rc == FPC_OK) rc = build_plan(c.get());
   if (rc == FPC_OK && c->plan_error) {
     g_hip_err = "no kernel instance for a layer of this dtype / arch combination";
     rc = FPC_E_INVALID;
@@ -2965,7 +2923,6 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     fpc_destroy(c.release());  // streams, events and whatever build_plan had allocated
     return rc;
   }
-  for (hipStream_t st : q_heavy) g_main_streams.push_back({cfg->device, st});
   *out = c.release();
   return FPC_OK;
 }
@@ -2974,29 +2931,31 @@ void fpc_destroy(fpc_ctx* c) {
   if (!c) return;
   hipSetDevice(c->cfg.device);
   hipDeviceSynchronize();
-  {
-    std::lock_guard<std::mutex> queue_lock(g_queue_mu);
-    auto gone = [&](hipStream_t st) {
-      for (size_t i = 0; i < g_main_streams.size(); ++i)
-        if (g_main_streams[i].second == st) { g_main_streams.erase(g_main_streams.begin() + i); break; }
-    };
-    gone(c->stream);
-    for (auto st : c->aux) gone(st);
-  }
   for (auto e : c->event_pool) hipEventDestroy(e);
   for (auto e : c->ev_join) hipEventDestroy(e);
-  for (auto st : c->aux) hipStreamDestroy(st);
-  for (auto st : c->side)
-    if (st) hipStreamDestroy(st);
   for (auto e : c->ev_enc) hipEventDestroy(e);
   for (auto e : c->ev_det) hipEventDestroy(e);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  {
+    // the ctx's own streams (idle: the device was waited for above) go back to the device's spare list with the queue
+    // they were found on -- the next fpc_create takes them from there (queue_map.h); a caller's stream is not ours
+    std::lock_guard<std::mutex> queue_lock(qmap::state().mu);
+    qmap::DeviceQueues& q = qmap::state().dev[c->cfg.device];
+    auto give_back = [&](hipStream_t st, int slot) {
+      if (!st) return;
+      const qmap::Placed* p = qmap::find(c, slot);
+      qmap::retire(q, st, p && p->st == st ? p->qclass : qmap::Q_UNKNOWN);
+    };
+    for (size_t i = 0; i < c->aux.size(); ++i) give_back(c->aux[i], SLOT_AUX + (int)i);
+    for (size_t i = 0; i < c->side.size(); ++i) give_back(c->side[i], SLOT_SIDE + (int)i);
+    give_back(c->upload, SLOT_UPLOAD);
+    if (c->own_stream) give_back(c->stream, SLOT_MAIN);
+    qmap::release_owner(c);
+  }
   if (c->slab) hipFree(c->slab);
   if (c->blob) hipFree(c->blob);
   if (c->u8stage) hipFree(c->u8stage);
   if (c->ha_ws) hipFree(c->ha_ws);
-  if (c->upload) hipStreamDestroy(c->upload);
-  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -3047,6 +3006,26 @@ int fpc_import_packed(fpc_ctx* c, const void* src, size_t n) {
   return FPC_OK;
 }
 
+int fpc_import_packed_device(fpc_ctx* c, const void* src_dev, size_t n) {
+  if (!c || !src_dev) return FPC_E_INVALID;
+  if (n != c->blob_floats * sizeof(float)) {
+    g_hip_err = "packed weights: " + std::to_string(n) + " bytes, this context's plan packs " + std::to_string(c->blob_floats * sizeof(float));
+    return FPC_E_INVALID;
+  }
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  // the 64-byte tag is checked on the host BEFORE the blob is touched; the bytes themselves never leave the device
+  uint32_t h[BLOB_HEADER_FLOATS];
+  HIPCHECK(hipMemcpy(h, src_dev, sizeof(h), hipMemcpyDeviceToHost));
+  if (!check_blob_header(c, h, &g_hip_err)) return FPC_E_INVALID;
+  if (src_dev != (const void*)c->blob) {
+    c->weights_loaded = false;
+    HIPCHECK(hipMemcpy(c->blob, src_dev, n, hipMemcpyDeviceToDevice));
+    HIPCHECK(hipDeviceSynchronize());
+  }
+  c->weights_loaded = true;
+  return FPC_OK;
+}
+
 int fpc_mark_weights_loaded(fpc_ctx* c) {
   if (!c) return FPC_E_INVALID;
   // the blob was written in place (a collective into fpc_packed_device_ptr): it must carry this context's tag
@@ -3071,7 +3050,11 @@ int fpc_check_guards(fpc_ctx* c, long long* bad_words) {
   HIPCHECK(hipDeviceSynchronize());
   unsigned long long* d = nullptr;
   HIPCHECK(hipMalloc((void**)&d, sizeof(*d)));
-  HIPCHECK(hipMemset(d, 0, sizeof(*d)));
+  {
+    const hipError_t e0 = hipMemset(d, 0, sizeof(*d));
+    if (e0 != hipSuccess) hipFree(d);
+    HIPCHECK(e0);
+  }
   for (const auto& z : c->guards) {
     const size_t n = z.second / 4;
     guard_count_kernel<<<(unsigned)std::min<size_t>(4096, (n + 255) / 256), 256, 0, c->stream>>>(reinterpret_cast<const uint32_t*>(c->slab + z.first), n, GUARD_PATTERN, d);
@@ -3203,46 +3186,61 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
 
 int fpc_set_stream(fpc_ctx* c, void* s) {
   if (!c) return FPC_E_INVALID;
+  // the stream the ctx already runs on: nothing to do (a caller may hand its stream over before every call)
+  if ((hipStream_t)s == c->stream && !c->own_stream) return FPC_OK;
   HIPCHECK(hipSetDevice(c->cfg.device));
-  std::lock_guard<std::mutex> queue_lock(g_queue_mu);
-  for (auto& ds : g_main_streams)
-    if (ds.second == c->stream) ds.second = (hipStream_t)s;   // (the caller's stream: other contexts keep clear of it as well)
+  std::lock_guard<std::mutex> queue_lock(qmap::state().mu);
   if (c->own_stream && c->stream) {
     hipStreamSynchronize(c->stream);
     hipStreamDestroy(c->stream);
   }
   c->stream = (hipStream_t)s;
   c->own_stream = false;
-  // The sub-batch and side streams were chosen beside the stream this one replaces: any of them that shares a hardware
-  // queue with the caller's stream is exchanged ("Streams on distinct hardware queues").  (Not for the null stream.)
-  if (c->queue_probe && c->stream) {
-    std::vector<hipStream_t> own{c->stream}, others;
-    auto mine = [&](hipStream_t st) {
-      if (st == c->stream) return true;
-      for (hipStream_t a : c->aux) if (a == st) return true;
-      return false;
-    };
-    for (const auto& ds : g_main_streams)
-      if (ds.first == c->cfg.device && ds.second && !mine(ds.second)) others.push_back(ds.second);
-    auto settle = [&](hipStream_t& st, bool heavy) {
-      bool ok = true;
-      for (hipStream_t o : own) ok = ok && streams_side_by_side(st, o);
-      if (!ok) {
-        hipStream_t fresh = acquire_stream(true, own, others);
-        if (fresh) {
-          hipStreamSynchronize(st);
-          if (heavy)
-            for (auto& ds : g_main_streams)
-              if (ds.second == st) ds.second = fresh;
-          hipStreamDestroy(st);
-          st = fresh;
-        }
+  // The registry's entry is THIS context's main slot -- never another context's that happens to name the same caller
+  // stream.  The caller's stream is a foreign object: its queue class is looked up in a small per-context memo of handles
+  // seen before, and otherwise found with ONE probe round (a one-thread kernel of ~40 us on it) only if that is safe --
+  // probing on, not the null stream, not being captured into a graph, and idle.  Anything else: class unknown, the
+  // context's other streams stay as they are.
+  qmap::Placed* mainp = qmap::find(c, SLOT_MAIN);
+  int k = qmap::Q_UNKNOWN;
+  qmap::DeviceQueues& q = qmap::state().dev[c->cfg.device];
+  bool memo_hit = false;
+  for (const auto& m : c->caller_stream_memo)
+    if (m.first == c->stream) { k = m.second; memo_hit = true; }
+  if (!memo_hit && c->queue_probe && c->stream && !q.futile && q.anchor.size() >= 2) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (!capturing && hipStreamQuery(c->stream) == hipSuccess) {
+      k = qmap::classify(q, c->stream);
+      if (k == qmap::Q_INCONCLUSIVE) k = qmap::Q_UNKNOWN;
+      if (c->caller_stream_memo.size() >= 4) c->caller_stream_memo.erase(c->caller_stream_memo.begin());
+      c->caller_stream_memo.push_back({c->stream, k});
+    }
+    (void)hipGetLastError();
+  }
+  if (mainp) {
+    mainp->st = c->stream;
+    mainp->qclass = k;
+  }
+  // a sub-batch or side stream of this context on the caller's queue would run in a row with it: exchanged
+  if (k >= 0) {
+    auto settle = [&](hipStream_t& st, int slot, bool heavy) {
+      qmap::Placed* p = qmap::find(c, slot);
+      if (!st || !p || p->qclass != k) return;
+      const qmap::Placed old = *p;
+      for (size_t i = 0; i < qmap::state().placed.size(); ++i)      // (out of the table while its replacement is chosen)
+        if (&qmap::state().placed[i] == p) { qmap::state().placed.erase(qmap::state().placed.begin() + i); break; }
+      hipStream_t fresh = qmap::acquire(c->cfg.device, c, slot, heavy, true, true);
+      if (fresh) {
+        hipStreamSynchronize(st);
+        hipStreamDestroy(st);
+        st = fresh;
+      } else {
+        qmap::state().placed.push_back(old);
       }
-      own.push_back(st);
     };
-    for (hipStream_t& st : c->aux) settle(st, true);
-    for (hipStream_t& st : c->side)
-      if (st) settle(st, false);
+    for (size_t i = 0; i < c->aux.size(); ++i) settle(c->aux[i], SLOT_AUX + (int)i, true);
+    for (size_t i = 0; i < c->side.size(); ++i) settle(c->side[i], SLOT_SIDE + (int)i, false);
   }
   return FPC_OK;
 }
@@ -3253,16 +3251,34 @@ void* fpc_upload_stream(fpc_ctx* c) {
   if (!c) return nullptr;
   if (c->upload) return (void*)c->upload;
   if (hipSetDevice(c->cfg.device) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> queue_lock(g_queue_mu);
-  std::vector<hipStream_t> own{c->stream}, others;
-  for (hipStream_t a : c->aux) own.push_back(a);
-  for (const auto& ds : g_main_streams) {
-    bool mine = false;
-    for (hipStream_t o : own) mine = mine || o == ds.second;
-    if (ds.first == c->cfg.device && ds.second && !mine) others.push_back(ds.second);
-  }
-  c->upload = acquire_stream(c->queue_probe, own, others);
+  std::lock_guard<std::mutex> queue_lock(qmap::state().mu);
+  // beside this context's main / sub-batch streams (its side streams carry the few-CU NMS launches: sharing a queue with
+  // one of them is the lesser evil when all four queues are taken) and, where a queue is left, other contexts' too
+  c->upload = qmap::acquire(c->cfg.device, c, SLOT_UPLOAD, false, c->queue_probe, false);
   return (void*)c->upload;
+}
+
+int fpc_stream_report(fpc_ctx* c, fpc_stream_report_t* out) {
+  if (!c || !out) return FPC_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  std::lock_guard<std::mutex> queue_lock(qmap::state().mu);
+  const qmap::DeviceQueues& q = qmap::state().dev[c->cfg.device];
+  out->probing = c->queue_probe && !q.futile ? 1 : 0;
+  out->hw_queues_found = (int)q.anchor.size();
+  out->process_probe_rounds = q.rounds;
+  out->process_probe_launches = q.launches;
+  out->process_probe_ms = (float)q.ms;
+  out->process_inconclusive_rounds = q.inconclusive;
+  out->create_probe_rounds = c->probe_rounds;
+  out->create_placement_ms = (float)c->placement_ms;
+  out->process_registered_streams = (int)qmap::state().placed.size();
+  for (const qmap::Placed& p : qmap::state().placed) {
+    if (p.owner != c || out->n_streams >= 16) continue;
+    out->slot[out->n_streams] = p.slot;
+    out->queue[out->n_streams] = p.qclass;
+    out->n_streams += 1;
+  }
+  return FPC_OK;
 }
 
 int fpc_sync(fpc_ctx* c) {
@@ -3363,7 +3379,6 @@ int fpc_detect(fpc_ctx* c, const float* frames, int n) {
   if (n < 1 || n > c->B || !frames) return FPC_E_INVALID;
   HIPCHECK(hipSetDevice(c->cfg.device));
   const bool de = c->cfg.descriptor_enabled != 0;
-  if (c->timing_every > 1) c->timing = c->timing_calls++ % c->timing_every == 0;   // (sampled: every n-th call carries the events)
   if (c->split_f16) HIPCHECK(hipMemsetAsync(c->status + 1, 0, sizeof(int32_t), c->stream));
   return for_each_sub(c, n, [&](const Sub& sb) { run_path(c, frames, sb, de, 1); });
 }

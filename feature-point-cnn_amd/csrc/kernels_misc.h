@@ -209,18 +209,6 @@ __device__ __forceinline__ void stem_pool_emit(const float* lds, float* out, int
   }
 }
 
-// fpc_create's probe for streams that share a hardware queue (fpc_api.hip: acquire_stream): one wave that leaves after
-// `ticks` of the constant 100 MHz clock (s_memrealtime: independent of the shader clock; the loop has no other exit
-// condition and needs none).  Two of these on two streams take one such time side by side, two in a row on one queue.
-__global__ __launch_bounds__(64) void queue_probe_kernel(unsigned ticks) {
-  unsigned long long t0, t;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-  do {
-    __builtin_amdgcn_s_sleep(16);
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  } while (t - t0 < ticks);
-}
-
 // The pooled map's cells that stem_pool_emit completes ACROSS tiles with atomicMax -- pooled rows / columns that are
 // multiples of 8 (window row / column 0 and 8 of a 16 x 16 conv tile) -- must hold +0 before the stem runs; every other
 // cell is written by a plain store of the one tile that holds its whole window.  Zeroing just those cells (23 % of the

@@ -93,27 +93,41 @@ def broadcast_packed_weights(engine, state_dict, src=0):
             % (rank, "differs from" if mine_differs else "matches, but another rank's differs from", src, n, ph, src_n,
                src_lo | (src_hi << 32)))
     if dist.get_backend() == "nccl":
-        # RCCL broadcast over xGMI, device to device, of a torch-owned buffer (16 MB, start-up only), then one copy
-        # into the library.  FPC_DIST_ZERO_COPY=1 broadcasts straight into the library's blob instead (a tensor view
-        # of memory the library allocated): it saves that copy; every rank must set it.
-        if os.environ.get("FPC_DIST_ZERO_COPY") == "1":
-            view = engine.packed_view()
-            dist.broadcast(view, src=src)
-            torch.cuda.synchronize()
-            if rank != src:
-                engine.mark_weights_loaded()      # verifies the tag that arrived
-        else:
-            buf = (torch.from_numpy(engine.export_packed()).to(dev) if rank == src
-                   else torch.empty(n, dtype=torch.uint8, device=dev))
-            dist.broadcast(buf, src=src)
-            torch.cuda.synchronize()
-            if rank != src:
-                engine.import_packed(buf.cpu().numpy())
+        target, finish = nccl_receive_target(engine, rank == src, n, dev)
+        dist.broadcast(target, src=src)        # RCCL over xGMI, device to device (16 MB, start-up only)
+        torch.cuda.synchronize()
+        finish()
     else:
         buf = torch.from_numpy(engine.export_packed()) if rank == src else torch.empty(n, dtype=torch.uint8)
         dist.broadcast(buf, src=src)
         if rank != src:
             engine.import_packed(buf.numpy())
+
+
+def nccl_receive_target(engine, is_src, n, dev):
+    """(tensor, finish) for the blob collective of a device backend.  The tensor every rank hands to dist.broadcast is a
+    VIEW OF THE LIBRARY'S OWN device blob (fpc_packed_device_ptr): the source sends from where fpc_load_weights packed,
+    a receiver's bytes land where the kernels read them -- no staging buffer, no host round trip; `finish` then has the
+    library verify the tag that arrived (fpc_mark_weights_loaded).  The three collectives in front of this one have
+    already made every rank agree on the size and the plan hash, so every rank enters the same collective with the
+    same byte count whichever target it uses.  If the view cannot be made on some rank (or FPC_DIST_ZERO_COPY=0), that
+    rank receives into a torch-owned device buffer and hands it over with fpc_import_packed_device -- one device-to-
+    device copy, still no host hop.  (Round 4's default went device -> host -> device on every receiver.)"""
+    view = None
+    if os.environ.get("FPC_DIST_ZERO_COPY", "1") != "0":
+        try:
+            view = engine.packed_view()
+            if view.numel() != n or view.dtype != torch.uint8:
+                view = None
+        except Exception:
+            view = None
+    if view is not None:
+        return view, (lambda: None) if is_src else engine.mark_weights_loaded
+    buf = torch.empty(n, dtype=torch.uint8, device=dev)
+    if is_src:
+        buf.copy_(torch.from_numpy(engine.export_packed()))      # (the source's fallback only: its view could not be made)
+        return buf, (lambda: None)
+    return buf, (lambda: engine.import_packed_device(buf))
 
 
 def max_over_ranks(value):

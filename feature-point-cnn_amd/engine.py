@@ -130,6 +130,14 @@ class Engine:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         _lib.check(self._l.fpc_import_packed(self._ctx, buf.ctypes.data, buf.nbytes), "fpc_import_packed")
 
+    def import_packed_device(self, buf):
+        """fpc_import_packed_device: a packed blob that is already in device memory (a uint8 CUDA tensor -- the receive
+        buffer of a broadcast, another engine's packed_view()): tag checked, copied device to device."""
+        if buf.dtype != torch.uint8 or not buf.is_cuda or not buf.is_contiguous():
+            raise ValueError("import_packed_device takes a contiguous uint8 CUDA tensor")
+        torch.cuda.synchronize(buf.device)
+        _lib.check(self._l.fpc_import_packed_device(self._ctx, buf.data_ptr(), buf.numel()), "fpc_import_packed_device")
+
     def mark_weights_loaded(self):
         _lib.check(self._l.fpc_mark_weights_loaded(self._ctx), "fpc_mark_weights_loaded")
 
@@ -156,6 +164,23 @@ class Engine:
         if not s:
             raise RuntimeError("fpc_upload_stream failed")
         return torch.cuda.ExternalStream(int(s), device=self.torch_device)
+
+    def stream_report(self):
+        """fpc_stream_report: which hardware queue each of the ctx's streams sits on, and what finding that out cost."""
+        r = _lib.FpcStreamReport()
+        _lib.check(self._l.fpc_stream_report(self._ctx, ctypes.byref(r)), "fpc_stream_report")
+        names = {0: "main", 200: "upload"}
+        streams = {}
+        for i in range(r.n_streams):
+            sl = r.slot[i]
+            name = names.get(sl) or ("sub%d" % sl if sl < 100 else "side%d" % (sl - 100))
+            streams[name] = r.queue[i]
+        return {"streams": streams, "probing": bool(r.probing), "hw_queues_found": r.hw_queues_found,
+                "create_probe_rounds": r.create_probe_rounds, "create_placement_ms": round(r.create_placement_ms, 3),
+                "process_probe_rounds": r.process_probe_rounds, "process_probe_launches": r.process_probe_launches,
+                "process_probe_ms": round(r.process_probe_ms, 3),
+                "process_inconclusive_rounds": r.process_inconclusive_rounds,
+                "process_registered_streams": r.process_registered_streams}
 
     def _frames(self, frames):
         if not isinstance(frames, torch.Tensor):

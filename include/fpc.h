@@ -29,13 +29,13 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 3
+#define FPC_ABI_VERSION 4
 /* Revision of the packed-weight FRAGMENT LAYOUTS (what the packing routines of this build write at the offsets the launch
  * plan names).  It is part of the blob's tag and of fpc_plan_hash: bump it whenever a packing routine changes the order
  * of values inside a layer's fragments -- offsets and sizes, which the plan hash covers anyway, do not change then, and
  * a blob of the older build would otherwise be accepted and multiplied with the wrong weights.
  *   1: rounds 1-2.   2: round 3 (fp32 stem fragments in the column / row tap-pair K order, stem_pair).
- *   3: round 4. */
+ *   3: round 4.  (ABI 4, round 5: fpc_stream_report added, fpc_set_stream's contract narrowed; layouts unchanged.) */
 #define FPC_PACK_LAYOUT_REVISION 3
 
 enum {
@@ -172,6 +172,9 @@ size_t fpc_packed_size(const fpc_ctx* ctx);
 void* fpc_packed_device_ptr(fpc_ctx* ctx);              /* in-place collective target */
 int fpc_export_packed(fpc_ctx* ctx, void* host_dst, size_t cap);
 int fpc_import_packed(fpc_ctx* ctx, const void* host_src, size_t n);
+/* The same from DEVICE memory (the receive buffer of a broadcast, another ctx's fpc_packed_device_ptr): the tag is read
+ * back and checked, the blob is copied device to device.  Synchronous. */
+int fpc_import_packed_device(fpc_ctx* ctx, const void* dev_src, size_t n);
 /* Declares the blob at fpc_packed_device_ptr valid (after a broadcast into it).  The blob starts with a 64-byte tag
  * (magic, ABI version, dtype, arch, launch-plan hash, size); fpc_import_packed and this call refuse a blob whose tag
  * does not match the context (FPC_E_INVALID; fpc_last_hip_error says which field). */
@@ -197,7 +200,11 @@ int fpc_check_guards(fpc_ctx* ctx, long long* bad_words);
 int fpc_broadcast_weights(fpc_ctx* ctx, void* nccl_comm, int root);
 
 /* Work is enqueued on this hipStream_t (default: a stream the ctx owns).  A stream handed in must stay valid until
- * fpc_destroy or the next fpc_set_stream (other ctxs of the device probe their streams against it: fpc_upload_stream). */
+ * fpc_destroy or the next fpc_set_stream.  Handing over the stream the ctx already runs on returns at once (cheap enough
+ * to do before every call).  A NEW caller stream is looked at once: if it is idle and not being captured into a graph,
+ * one ~40 us one-thread kernel is launched on it to learn which hardware queue it sits on (so that the ctx's sub-batch
+ * streams can keep clear of that queue); a busy or capturing stream, the null stream, or FPC_QUEUE_PROBE=0: nothing is
+ * launched and the ctx's other streams stay as they are.  Never synchronises the caller's stream. */
 int fpc_set_stream(fpc_ctx* ctx, void* hip_stream);
 void* fpc_get_stream(fpc_ctx* ctx);
 /* A hipStream_t for the CALLER's uploads (hipMemcpyAsync of the next batch while this one computes): non-blocking, owned
@@ -207,6 +214,24 @@ void* fpc_get_stream(fpc_ctx* ctx);
  * every launch in front of it.  Order it against fpc_detect with events, as any two streams.  NULL on failure.
  * (The reference uploads on the default stream: python/src/superpoint.py:98-99 `.cuda()`.) */
 void* fpc_upload_stream(fpc_ctx* ctx);
+/* How the ctx's streams were placed on the GPU's hardware queues, and what that cost (csrc/queue_map.h).  The HIP runtime
+ * maps streams onto GPU_MAX_HW_QUEUES (4) queues and two streams on one queue run their kernels in a row, so fpc_create
+ * picks streams that sit on queues of their own.  queue[i] of stream slot[i] (0 = main, 1.. = sub-batch streams, 100.. =
+ * side streams, 200 = upload stream): index of the hardware queue, -1 = a queue outside the map, -3 = not probed
+ * (FPC_QUEUE_PROBE=0, a caller stream that was busy, or probing switched off after inconclusive rounds: `probing` 0).
+ * process_* count every probe round of the process on this device; create_* what THIS ctx's fpc_create spent. */
+typedef struct fpc_stream_report_t {
+  int n_streams;
+  int slot[16], queue[16];
+  int probing;
+  int hw_queues_found;
+  int process_probe_rounds, process_probe_launches, process_inconclusive_rounds;
+  float process_probe_ms;
+  int create_probe_rounds;
+  float create_placement_ms;
+  int process_registered_streams;   /* streams of ALL live ctxs of the process in the registry (0 once every ctx is gone) */
+} fpc_stream_report_t;
+int fpc_stream_report(fpc_ctx* ctx, fpc_stream_report_t* out);
 int fpc_sync(fpc_ctx* ctx);
 
 /* ~ SuperPoint.forward (python/src/superpoint.py:91-115): frames [n,3,H,W] ([n,1,H,W] with
@@ -314,8 +339,9 @@ int fpc_get_keypoints(fpc_ctx* ctx, int frame, int cap, int32_t* xy, float* conf
 
 /* Optional per-launch timing for the bench: with `enable`, every kernel launch of
  * fpc_detect / fpc_forward is bracketed by HIP events on the launch stream; records
- * accumulate over calls until the next fpc_set_timing.  enable = n > 1: only every n-th fpc_detect call (the first one
- * included) carries the events -- two event records per launch cost 0.7 % of the frame rate at 32 VGA frames per call. */
+ * accumulate over calls until the next fpc_set_timing.  enable = n > 1: only every n-th pass over a batch (the first one
+ * included; one pass per fpc_detect / fpc_forward / fpc_detect_u8* call, 1 + num per fpc_homography_adaptation) carries
+ * the events -- two event records per launch cost 0.7 % of the frame rate at 32 VGA frames per call. */
 int fpc_set_timing(fpc_ctx* ctx, int enable);
 /* After fpc_sync: number of launches recorded since fpc_set_timing; names[i] (layer) and
  * kernels[i] (kernel symbol, as rocprofv3 prints it) point into ctx-owned storage;

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     # the header, the library as built and the binding agree on the ABI and on the fragment-layout revision -- the
     # latter is part of the packed blob's tag and of fpc_plan_hash (advisor, round 3: round 3 changed the stem's
     # fragment order under an unchanged ABI version and plan hash, so a round-2 blob would have been accepted)
-    assert int(re.search(r"#define FPC_ABI_VERSION (\d+)", hdr).group(1)) == lib.fpc_abi_version() == _lib.ABI_VERSION == 3
+    assert int(re.search(r"#define FPC_ABI_VERSION (\d+)", hdr).group(1)) == lib.fpc_abi_version() == _lib.ABI_VERSION == 4
     assert int(re.search(r"#define FPC_PACK_LAYOUT_REVISION (\d+)", hdr).group(1)) == lib.fpc_pack_layout_revision() == _lib.PACK_LAYOUT_REVISION
     api = open(os.path.join(ROOT, "feature-point-cnn_amd", "csrc", "fpc_api.hip")).read()
     assert "mix(FPC_PACK_LAYOUT_REVISION)" in api and "h[9] = FPC_PACK_LAYOUT_REVISION" in api
@@ -65,6 +65,7 @@ def test_library_contains_gfx950_code_object():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.FpcConfig) == 17 * 4
     assert ctypes.sizeof(_lib.FpcTensor) == 8 + 8 + 8 + 32
+    assert ctypes.sizeof(_lib.FpcStreamReport) == (1 + 16 + 16 + 9) * 4      # fpc_stream_report_t: ints and floats only
     cfg = _lib.FpcConfig()
     assert _lib.load().fpc_default_config(ctypes.byref(cfg)) == 0
     # python/src/settings.py:2-8
@@ -210,7 +211,8 @@ def test_inference_wrapper_exports(tmp_path):
 def test_public_header_is_plain_c(tmp_path):
     """include/fpc.h is the drop-in boundary: it must compile as C99 (cgo / JNI / ctypes-style consumers) and as C++."""
     src = tmp_path / "hdr.c"
-    src.write_text('#include "fpc.h"\nint main(void) { fpc_config c; return (int)sizeof(c) * 0; }\n')
+    src.write_text('#include "fpc.h"\nint main(void) { fpc_config c; fpc_stream_report_t r; '
+                   'typedef char report_is_42_words[sizeof(r) == 42 * 4 ? 1 : -1]; return (int)(sizeof(c) + sizeof(report_is_42_words)) * 0; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])

@@ -147,6 +147,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert len(lines) == 1
     out = json.loads(lines[0])
     threads = out.pop("host_threads_per_rank")
+    assert out.pop("frame_seed0") == [100, 132] and out.pop("shards") == [[0, 32], [32, 64]] and out.pop("host_threads") == [threads] * 2
     assert out == {"rendezvous": "ok", "world": 2, "ranks": [0, 1], "backend": "gloo"}
     assert 1 <= threads <= max(1, len(os.sched_getaffinity(0)) // 2)      # each rank binds cores // N host threads
 
@@ -169,6 +170,37 @@ def test_bench_timing_reduction_with_four_ranks():
     want = [32 / 3.0e-3, 32 / 3.2e-3, 32 / 4.0e-3, 32 / 2.5e-3]
     assert all(abs(a - b) < 0.5 for a, b in zip(out["per_rank"]["frames_per_s"], want))
     assert out["per_rank"]["weights_start_up_ms"] == [10.0, 11.0, 12.0, 13.0]
+
+
+def test_bench_gpus_8_rehearsed_over_gloo():
+    """`python bench.py --gpus 8` as the driver's first 8-GPU lease will start it, rehearsed with 8 gloo ranks on the CPU:
+    the parent starts its ranks, they rendezvous, and every piece of per-rank bookkeeping of configs[2] (256 VGA frames
+    sharded over 8 GPUs) comes out as SURVEY 8(d) config 3 states it -- frame seeds 100 + 32 * rank (100 .. 355 over the
+    job), contiguous shards of 32 frames with no gap or overlap, cores // 8 host threads per rank -- and
+    aggregate_over_ranks (the function the real run calls) prices the job on the slowest rank.  No scaling curve exists:
+    this is bookkeeping, not a measurement."""
+    import json
+    ms = "2.8,2.9,2.85,3.1,2.8,2.8,2.95,2.8"
+    r = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5"], FPC_BENCH_RENDEZVOUS_ONLY="1", FPC_DIST_BACKEND="gloo",
+               FPC_BENCH_FAKE_STEP_MS=ms)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                                  # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["world"] == 8 and out["ranks"] == list(range(8)) and out["n_gpus"] == 8 and out["backend"] == "gloo"
+    assert out["frame_seed0"] == [100 + 32 * r_ for r_ in range(8)] and out["frame_seed0"][-1] + 31 == 355
+    assert out["shards"] == [[32 * r_, 32 * r_ + 32] for r_ in range(8)]
+    cores = len(os.sched_getaffinity(0))
+    assert out["host_threads"] == [out["host_threads_per_rank"]] * 8 and 1 <= out["host_threads_per_rank"] <= max(1, cores // 8)
+    assert abs(out["ms_per_step"] - 3.1) < 1e-6
+    assert abs(out["value"] - 8 * 32 * 20 / (3.1e-3 * 20)) < 0.5            # 82 580 frames/s for the whole job
+    want = [32 / (float(v) * 1e-3) for v in ms.split(",")]
+    assert all(abs(a - b) < 0.5 for a, b in zip(out["per_rank"]["frames_per_s"], want))
+    # ragged shards (a caller's batch that does not divide): remainders to the low ranks, still contiguous
+    from fpc_amd.dist import shard_range
+    got = [shard_range(250, 8, r_) for r_ in range(8)]
+    assert got[0] == (0, 32) and got[1] == (32, 64) and got[2] == (64, 95) and got[-1] == (219, 250)
+    assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
 
 
 def test_bench_parent_reports_a_failing_rank():

@@ -1,0 +1,222 @@
+"""Round-5 robustness tests (pytest -m gpu), all through the C-ABI.
+
+* fpc_create's failure path returns its error code (round 4 deadlocked there: the advisor's finding).
+* Stream placement (csrc/queue_map.h): cheap, bounded, observable (fpc_stream_report), keyed by context, and without any
+  influence on results (FPC_QUEUE_PROBE=0 gives the same bits).
+* Sampled timing covers every entry point.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import fpc_amd  # noqa: F401
+from fpc_amd import _lib, arch, synth
+
+pytestmark = pytest.mark.gpu
+
+SPEC = arch.state_dict_spec()
+ATOL = 1e-4
+
+
+def engine(h, w, b=1, **kw):
+    from fpc_amd.engine import Engine
+    return Engine(h, w, max_batch=b, **kw)
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_create_returns_its_error_code_and_the_next_one_works():
+    """FPC_TEST_FAIL_CREATE makes fpc_create take its failure path after the streams are placed and registered (what a
+    failed workspace allocation does).  Round 4 called fpc_destroy there with the registry's mutex held: a hung process
+    instead of FPC_E_HIP.  The code comes back, nothing of the dead context stays registered, and the next create works."""
+    e0 = engine(64, 96, 1)
+    before = e0.stream_report()["process_registered_streams"]
+    os.environ["FPC_TEST_FAIL_CREATE"] = "1"
+    try:
+        with pytest.raises(_lib.FpcError) as ei:
+            engine(64, 96, 1)
+        assert ei.value.code == -3 and "FPC_TEST_FAIL_CREATE" in str(ei.value)
+    finally:
+        del os.environ["FPC_TEST_FAIL_CREATE"]
+    assert e0.stream_report()["process_registered_streams"] == before
+    e = engine(64, 96, 1)
+    e.load_state_dict(synth.make_state_dict(3, dustbin_bias=4.0))
+    assert len(e.detect(synth.make_batch(5, 1, 64, 96))) == 1
+    e.close()
+    e0.close()
+
+
+@pytest.mark.timeout(600)
+def test_stream_placement_is_cheap_bounded_and_changes_no_result():
+    """The default VGA context (32 frames, two sub-batches, heads side by side: four streams) lands on four different
+    hardware queues; what fpc_create spends on that is reported and small -- at most 6 probe rounds per stream, < 20 ms
+    for the FIRST context of a process (anchor discovery included), < 5 ms for a later one, and fpc_create as a whole
+    (2.4 GB of workspace carved and zeroed) < 1.5 s.  FPC_QUEUE_PROBE=0: no probe round, same results bit for bit."""
+    h, w, n = 480, 640, 32
+    sd = synth.make_state_dict(3, dustbin_bias=4.0)
+    frames = synth.make_batch(5, 4, h, w)
+    t0 = time.perf_counter()
+    e1 = engine(h, w, n)
+    first_create_s = time.perf_counter() - t0
+    r1 = e1.stream_report()
+    assert r1["probing"] and r1["hw_queues_found"] >= 2, r1
+    qs = r1["streams"]
+    assert set(qs) == {"main", "sub1", "side0", "side1"}, r1
+    heavy = [qs["main"], qs["sub1"]]
+    assert all(q >= 0 for q in heavy) and heavy[0] != heavy[1], r1
+    if r1["hw_queues_found"] >= 4:
+        assert len(set(qs.values())) == 4, r1
+    assert r1["create_probe_rounds"] <= 6 * 4 + 12, r1            # (+ the anchor search when this is the process's first context)
+    assert r1["create_placement_ms"] < 20.0, r1
+    assert r1["process_inconclusive_rounds"] == 0, r1
+    t0 = time.perf_counter()
+    e2 = engine(h, w, n)
+    create_s = time.perf_counter() - t0
+    r2 = e2.stream_report()
+    assert r2["create_probe_rounds"] <= 6 * 4 and r2["create_placement_ms"] < 8.0, r2
+    assert r2["streams"]["main"] != r2["streams"]["sub1"], r2
+    assert create_s < 1.5, (first_create_s, create_s)
+    e1.load_state_dict(sd)
+    want = e1.detect(frames)
+    rounds = e2.stream_report()["process_probe_rounds"]
+    os.environ["FPC_QUEUE_PROBE"] = "0"
+    try:
+        e3 = engine(h, w, n)
+    finally:
+        del os.environ["FPC_QUEUE_PROBE"]
+    r3 = e3.stream_report()
+    assert not r3["probing"] and r3["create_probe_rounds"] == 0 and r3["process_probe_rounds"] == rounds, r3
+    assert all(q == -3 for q in r3["streams"].values()), r3
+    e3.load_state_dict(sd)
+    got = e3.detect(frames)
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+    for e in (e1, e2, e3):
+        e.close()
+
+
+def test_set_stream_is_cheap_idempotent_and_keyed_by_context():
+    """Two contexts on ONE caller stream, then one of them moved: the other's registry entry still names the stream it
+    runs on (round 4 rewrote every entry that matched the stream's value), handing the same stream over again costs no
+    probe round, and when both contexts are gone nothing of them stays registered."""
+    import torch
+    e0 = engine(64, 96, 2)
+    base = e0.stream_report()["process_registered_streams"]
+    a, b = engine(64, 96, 2), engine(64, 96, 2)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        a.use_torch_stream()
+        b.use_torch_stream()
+    assert a.torch_stream().cuda_stream == s1.cuda_stream == b.torch_stream().cuda_stream
+    qa, qb = a.stream_report()["streams"], b.stream_report()["streams"]
+    assert qa["main"] == qb["main"]                       # one stream, one queue (or both unprobed)
+    for q in (qa, qb):                                    # ... and each context's other streams keep clear of it
+        assert q["main"] < 0 or q["main"] not in [v for k, v in q.items() if k != "main"], q
+    rounds = a.stream_report()["process_probe_rounds"]
+    with torch.cuda.stream(s1):
+        for _ in range(5):
+            a.use_torch_stream()
+    assert a.stream_report()["process_probe_rounds"] == rounds
+    with torch.cuda.stream(s2):
+        a.use_torch_stream()
+    assert a.torch_stream().cuda_stream == s2.cuda_stream and b.torch_stream().cuda_stream == s1.cuda_stream
+    assert b.stream_report()["streams"]["main"] == qb["main"]
+    sd = synth.make_state_dict(3, dustbin_bias=4.0)
+    frames = synth.make_batch(5, 2, 64, 96)
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    ra, rb = a.detect(frames), b.detect(frames)
+    for x, y in zip(ra, rb):
+        np.testing.assert_array_equal(x[0], y[0])
+        np.testing.assert_array_equal(x[1], y[1])
+    torch.cuda.synchronize()
+    a.close()
+    b.close()
+    assert e0.stream_report()["process_registered_streams"] == base
+    e0.close()
+
+
+def test_a_busy_or_capturing_caller_stream_is_left_alone():
+    """fpc_set_stream never launches on a caller stream that has work in flight (no verdict: queue -3)."""
+    import torch
+    e = engine(64, 96, 1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        torch.cuda._sleep(200_000_000)                    # ~0.1 s of spinning on the stream
+        rounds = e.stream_report()["process_probe_rounds"]
+        e.use_torch_stream()
+    r = e.stream_report()
+    assert r["streams"]["main"] == -3 and r["process_probe_rounds"] == rounds, r
+    torch.cuda.synchronize()
+    e.close()
+
+
+def test_sampled_timing_covers_forward_as_well():
+    """fpc_set_timing(n): the n-th-pass decision is taken where the batch is split into sub-batches, so fpc_forward and
+    fpc_detect_u8 are sampled like fpc_detect (round 4 re-evaluated it in fpc_detect only: the other entry points
+    inherited whatever the last detect had left)."""
+    import torch
+    h, w, n = 64, 96, 2
+    e = engine(h, w, n, num_streams=1)
+    e.load_state_dict(synth.make_state_dict(5, dustbin_bias=4.0))
+    frames = torch.from_numpy(synth.make_batch(21, n, h, w)).to(e.torch_device)
+    e.set_timing(True)
+    e.forward(frames)
+    e.sync()
+    one = len(e.timings())
+    assert one > 8
+    e.set_timing(3)
+    for _ in range(6):
+        e.forward(frames)
+    e.sync()
+    assert len(e.timings()) == 2 * one
+    e.set_timing(False)
+    e.close()
+
+
+def test_the_device_backend_blob_target_is_the_librarys_own_buffer():
+    """dist.nccl_receive_target, the receive half of the one collective of the system, without a second GPU: the tensor a
+    rank hands to dist.broadcast IS the library's device blob (same address as fpc_packed_device_ptr), the bytes that
+    arrive there are verified by the library (`finish`), and the resulting engine computes what the source computes,
+    bit for bit.  FPC_DIST_ZERO_COPY=0: a torch-owned device buffer + fpc_import_packed_device, still no host hop; a
+    blob with a foreign tag is refused there.  (The collective call itself needs two GPUs: never run -- DESIGN section 6.)"""
+    import torch
+    from fpc_amd import dist as fdist
+    h, w = 64, 96
+    sd = synth.make_state_dict(3, dustbin_bias=4.0)
+    frames = synth.make_batch(5, 2, h, w)
+    src = engine(h, w, 2)
+    src.load_state_dict(sd)
+    want = src.detect(frames)
+    n = src.packed_size()
+    dev = src.torch_device
+    s_target, s_finish = fdist.nccl_receive_target(src, True, n, dev)
+    assert s_target.data_ptr() == src.packed_view().data_ptr() and s_target.numel() == n
+    for zero_copy in ("1", "0"):
+        os.environ["FPC_DIST_ZERO_COPY"] = zero_copy
+        try:
+            dst = engine(h, w, 2)
+            target, finish = fdist.nccl_receive_target(dst, False, n, dev)
+            assert (target.data_ptr() == dst.packed_view().data_ptr()) == (zero_copy == "1")
+            with pytest.raises(_lib.FpcError):
+                dst.detect(frames)                                      # no weights yet
+            target.copy_(s_target)                                      # what the broadcast does
+            torch.cuda.synchronize()
+            finish()
+            got = dst.detect(frames)
+            for a, b in zip(want, got):
+                np.testing.assert_array_equal(a[0], b[0])
+                np.testing.assert_array_equal(a[1], b[1])
+                np.testing.assert_array_equal(a[2], b[2])
+            bad = s_target.clone()
+            bad[4] ^= 0xFF                                              # the tag's ABI word
+            with pytest.raises(_lib.FpcError):
+                dst.import_packed_device(bad)
+            dst.close()
+        finally:
+            del os.environ["FPC_DIST_ZERO_COPY"]
+    s_finish()
+    src.close()
