@@ -27,7 +27,7 @@ SYMBOLS = [
     "fpc_get_counts", "fpc_get_keypoints", "fpc_set_timing", "fpc_get_timings", "fpc_match", "fpc_first_within",
     "fpc_detect_u8", "fpc_u8_staging", "fpc_homography_adaptation", "fpc_detect_u8_resized",
     "fpc_sample_descriptors", "fpc_plan_hash", "fpc_broadcast_weights", "fpc_read_activation",
-    "fpc_pack_layout_revision", "fpc_check_guards", "fpc_stream_report",
+    "fpc_pack_layout_revision", "fpc_check_guards", "fpc_stream_report", "fpc_output_range",
 ]
 
 ABI_VERSION = 4
@@ -136,6 +136,7 @@ def load():
     l.fpc_results.argtypes = [vp, ctypes.POINTER(FpcDeviceResults)]
     l.fpc_get_counts.argtypes = [vp, ci, vp, vp]
     l.fpc_get_keypoints.argtypes = [vp, ci, ci, vp, vp, vp]
+    l.fpc_output_range.argtypes = [vp, ci, vp, vp, vp]
     l.fpc_match.argtypes = [vp, vp, ci, vp, ci, ci, ctypes.c_float, vp, vp]
     l.fpc_first_within.argtypes = [vp, vp, ci, vp, ci, ctypes.c_float, vp]
     l.fpc_sample_descriptors.argtypes = [vp, vp, vp, ci, vp]

@@ -463,6 +463,7 @@ struct fpc_ctx {
   float* prob;
   uint32_t *nmsmap, *cand;
   int32_t *ncand, *count, *xy, *status;
+  uint32_t* range = nullptr;        // [B][FPC_RANGE_WORDS]: largest logit / descriptor-map value, non-finite input flag, per frame
   float *conf, *desc_out;
   unsigned long long* sort_scratch;
   int32_t* nms_aux = nullptr;  // [B][NMS_AUX_INTS] (kernels_misc.h: nms_chunk_sort_kernel)
@@ -1194,6 +1195,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   const size_t o_prob = cv.take<float>((size_t)B * H * W);
   const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
   const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4 + BLOB_HEADER_FLOATS);   // + the 64-byte tag of fpc_broadcast_weights
+  const size_t o_range = cv.take<uint32_t>((size_t)B * FPC_RANGE_WORDS);   // per-frame range words (kernels_misc.h)
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>((size_t)B * c->cap * 256);
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
@@ -1215,6 +1217,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   c->count = reinterpret_cast<int32_t*>(c->slab + o_count);
   c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
   c->bcast_tag = reinterpret_cast<uint32_t*>(c->status + 4);
+  c->range = reinterpret_cast<uint32_t*>(c->slab + o_range);
   c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
@@ -1402,6 +1405,7 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_prob = cv.take<float>((size_t)B * H * W);
   const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
   const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4 + BLOB_HEADER_FLOATS);   // + the 64-byte tag of fpc_broadcast_weights
+  const size_t o_range = cv.take<uint32_t>((size_t)B * FPC_RANGE_WORDS);   // per-frame range words (kernels_misc.h)
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>(de ? (size_t)B * c->cap * 128 : 64);
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
@@ -1427,6 +1431,7 @@ static int build_plan(fpc_ctx* c) {
   c->count = reinterpret_cast<int32_t*>(c->slab + o_count);
   c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
   c->bcast_tag = reinterpret_cast<uint32_t*>(c->status + 4);
+  c->range = reinterpret_cast<uint32_t*>(c->slab + o_range);
   c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
@@ -2294,6 +2299,7 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
           a.out = x0;
           a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Hp = H / 4; a.Wp = W / 4;
           a.tiles_x = c->stem.tiles_x; a.tiles_y = c->stem.tiles_y;
+          a.range = c->range + (size_t)f0 * FPC_RANGE_WORDS;
           if (c->split || c->bf16) {
             StemX3Args x{};
             x.in = a.in; x.wfrag = reinterpret_cast<const uint4*>(a.wfrag); x.bias = a.bias; x.out = a.out;
@@ -2501,7 +2507,8 @@ static void run_softmax(fpc_ctx* c, const Sub& sb, bool dense_map = true) {
   const auto kern = c->bf16 ? softmax_d2s_kernel<true> : softmax_d2s_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(sb.n * c->Hc), dim3(256), (size_t)12 * c->W * sizeof(float), sb.st,
                      c->lg + (size_t)sb.f0 * c->Hc * c->Wc * c->lgcs, c->lgcs, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
-                     dense_map ? c->prob + sb.f0 * HW : nullptr, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0);
+                     dense_map ? c->prob + sb.f0 * HW : nullptr, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0,
+                     c->range + (size_t)sb.f0 * FPC_RANGE_WORDS);
 }
 
 static void run_nms(fpc_ctx* c, const Sub& sb) {
@@ -2610,6 +2617,7 @@ static void run_path(fpc_ctx* c, const float* frames, const Sub& sb0, bool de, i
   Sub sb = sb0;
   for (const Op& op : c->ops) sb.fuse_softmax |= upto && op.fused_softmax_capable;
   c->logits_valid = !sb.fuse_softmax;
+  hipMemsetAsync(c->range + (size_t)sb.f0 * FPC_RANGE_WORDS, 0, sizeof(uint32_t) * FPC_RANGE_WORDS * sb.n, sb.st);
   run_network(c, frames, sb, 0, sb.st);
   if (de && upto && c->nms_aside && !sb.small && sb.side) {
     // detector head and softmax in line; the (latency-bound, few-CU) NMS on the side stream next to the descriptor head
@@ -2684,6 +2692,7 @@ const char* fpc_strerror(int code) {
     case FPC_E_CAPACITY: return "caller buffer too small";
     case FPC_E_NOT_CONVERGED: return "NMS round limit hit";
     case FPC_E_RANGE: return "value outside fp16's range in FPC_F32_SPLIT_F16 mode (use FPC_F32_SPLIT or FPC_F32)";
+    case FPC_E_NONFINITE: return "a frame of the call holds a NaN or Inf pixel (see fpc_last_hip_error for which)";
     default: return "unknown error";
   }
 }
@@ -3309,7 +3318,7 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
   if (logits) {
     const size_t tot = (size_t)n * 65 * HWc;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->lg, c->lgcs, 65,
-                       HWc, n, logits);
+                       HWc, n, logits, (uint32_t*)nullptr, 0);
   }
   if (desc) {
     const size_t tot = (size_t)n * c->D * HWc;
@@ -3318,7 +3327,7 @@ int fpc_forward(fpc_ctx* c, const float* frames, int n, float* prob, float* desc
                          reinterpret_cast<const unsigned short*>(c->desc_map), c->D, c->D, HWc, n, desc);
     else if (de)
       hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                         c->desc_map, c->D, c->D, HWc, n, desc);
+                         c->desc_map, c->D, c->D, HWc, n, desc, c->range, (int)RANGE_MAX_DESC);
     else  // superpoint.py:106-109: zeros when the descriptor head is disabled
       HIPCHECK(hipMemsetAsync(desc, 0, tot * sizeof(float), c->stream));
   }
@@ -3365,7 +3374,7 @@ int fpc_read_activation(fpc_ctx* c, const char* name, int frame0, int n, float* 
       hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, grid, dim3(256), 0, c->stream, src, t.cs, t.C, HW, n, out);
     } else {
       const float* src = static_cast<const float*>(t.p) + t.off + (size_t)frame0 * HW * t.cs;
-      hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, c->stream, src, t.cs, t.C, HW, n, out);
+      hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, c->stream, src, t.cs, t.C, HW, n, out, (uint32_t*)nullptr, 0);
     }
     HIPCHECK(hipGetLastError());
     return FPC_OK;
@@ -3597,6 +3606,31 @@ int fpc_get_counts(fpc_ctx* c, int n, int32_t* count, int32_t* ncand) {
   if (st[1]) return FPC_E_RANGE;
   if (count) HIPCHECK(hipMemcpy(count, c->count, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   if (ncand) HIPCHECK(hipMemcpy(ncand, c->ncand, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  // a frame with a NaN / Inf pixel (FPC_F32's stem looks at every pixel it stages): the counts above are delivered, the
+  // call is flagged -- include/fpc.h, FPC_E_NONFINITE
+  std::vector<uint32_t> rw((size_t)n * FPC_RANGE_WORDS);
+  HIPCHECK(hipMemcpy(rw.data(), c->range, rw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (int b = 0; b < n; ++b)
+    if (rw[(size_t)b * FPC_RANGE_WORDS + RANGE_BAD_INPUT]) {
+      g_hip_err = "frame " + std::to_string(b) + " of the last call holds a NaN or Inf pixel";
+      return FPC_E_NONFINITE;
+    }
+  return FPC_OK;
+}
+
+int fpc_output_range(fpc_ctx* c, int n, float* max_logit, float* max_desc, int32_t* nonfinite_input) {
+  if (!c || n < 1 || n > c->B) return FPC_E_INVALID;
+  HIPCHECK(hipSetDevice(c->cfg.device));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> rw((size_t)n * FPC_RANGE_WORDS);
+  HIPCHECK(hipMemcpy(rw.data(), c->range, rw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (int b = 0; b < n; ++b) {
+    const uint32_t* w = rw.data() + (size_t)b * FPC_RANGE_WORDS;
+    float f;
+    if (max_logit) { memcpy(&f, w + RANGE_MAX_LOGIT, 4); max_logit[b] = f; }
+    if (max_desc) { memcpy(&f, w + RANGE_MAX_DESC, 4); max_desc[b] = f; }
+    if (nonfinite_input) nonfinite_input[b] = (int32_t)w[RANGE_BAD_INPUT];
+  }
   return FPC_OK;
 }
 

@@ -147,7 +147,19 @@ struct StemPoolArgs {
   const float* bias;    // [64]
   float* out;           // [B,Hp,Wp,64], zero-filled
   int H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y;
+  uint32_t* range;      // [B][FPC_RANGE_WORDS] per-frame range words (nullable): word RANGE_BAD_INPUT is set to 1 when a pixel of the
+                        // frame is NaN or +-Inf (include/fpc.h: FPC_E_NONFINITE)
 };
+
+// Per-frame range words the path keeps for its caller (fpc_get_counts, fpc_output_range).
+constexpr int FPC_RANGE_WORDS = 4;
+enum { RANGE_MAX_LOGIT = 0, RANGE_BAD_INPUT = 1, RANGE_MAX_DESC = 2, RANGE_SPARE = 3 };
+
+// Non-finite pixels, found while the stem stages its window: 0 * (x + y + z + w) is NaN iff one of the four is NaN or
+// +-Inf (or their sum overflows: |pixel| > 8e37, no image).  Three VALU instructions per 16-byte load, outside the K loop.
+__device__ __forceinline__ float nonfinite_probe(float chk, const float4& x) {
+  return fmaf((x.x + x.y) + (x.z + x.w), 0.f, chk);
+}
 
 constexpr int STEM_TROW = 33;  // floats per pixel of the epilogue tile (32 channels + 1 skew)
 constexpr int STEM_POOL_LDS_FLOATS =
@@ -274,11 +286,14 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
       const float4 x = *reinterpret_cast<const float4*>(a.in + (ok ? ((size_t)(b * CIN + c) * a.H + iy) * a.W + ix : 0));
       v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float chk = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * 256;
       if (e < NE) *reinterpret_cast<float4*>(lds + e * 4) = v[i];  // e * 4 == row * STEM_LW + 4 * q
+      chk = nonfinite_probe(chk, v[i]);
     }
+    if (chk != chk && a.range) a.range[b * FPC_RANGE_WORDS + RANGE_BAD_INPUT] = 1u;   // (rare; any number of writers, one value)
   }
   __syncthreads();
 
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* 
 template <bool FAST = false>
 __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
                                                           float thresh, float* prob, uint32_t* nmsmap,
-                                                          uint32_t* cand, int32_t* ncand) {
+                                                          uint32_t* cand, int32_t* ncand, uint32_t* range) {
   // one workgroup per ROW of cells: the 8 x W strip of probabilities is assembled in LDS so
   // that the dense maps are written as whole rows, and the strip's candidates are appended
   // with ONE global atomic (per-wave atomics on one counter serialise at ~11 ns each).
@@ -405,6 +420,7 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
   // 6 cross-lane steps, 2 exps and 4 one-word LDS writes per lane and CELL.  Four such loads per wave are in flight.
   const float* lrow = logits + (size_t)(b * Hc + i) * Wc * cs;
   const int q = lane & 15, gidx = lane >> 4;
+  float lmax = 0.f;       // the largest logit of this row of cells (logits are post-ReLU: >= 0; NaN never wins a max)
   for (int j0 = wave * 16; j0 < Wc; j0 += 64) {
     float4 lv[4];
     float ld[4];
@@ -419,6 +435,7 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
       const int j = j0 + 4 * u + gidx;
       const float e0 = sm_exp<FAST>(lv[u].x), e1 = sm_exp<FAST>(lv[u].y), e2 = sm_exp<FAST>(lv[u].z), e3 = sm_exp<FAST>(lv[u].w);
       const float ed = sm_exp<FAST>(ld[u]);
+      lmax = fmaxf(fmaxf(fmaxf(lmax, fabsf(ld[u])), fmaxf(fabsf(lv[u].x), fabsf(lv[u].y))), fmaxf(fabsf(lv[u].z), fabsf(lv[u].w)));
       float s = (e0 + e1) + (e2 + e3);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -427,6 +444,15 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
         *reinterpret_cast<float4*>(strip + (q >> 1) * W + j * 8 + 4 * (q & 1)) =
             make_float4(sm_prob<FAST>(e0, den), sm_prob<FAST>(e1, den), sm_prob<FAST>(e2, den), sm_prob<FAST>(e3, den));
     }
+  }
+  if (range) {
+    // the frame's largest |logit| (include/fpc.h: fpc_output_range): a wave's maximum, one atomic per wave and only when
+    // it raises the word (after a frame's first rows almost never)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    uint32_t* word = range + b * FPC_RANGE_WORDS + RANGE_MAX_LOGIT;
+    if (lane == 0 && __float_as_uint(lmax) > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(word, __float_as_uint(lmax));
   }
   __syncthreads();
   // write-out, four pixels per thread and trip (16-byte LDS reads and stores: as single floats this loop was 80 store
@@ -1244,13 +1270,28 @@ __global__ __launch_bounds__(256) void descriptor_at_points_kernel(const float* 
 }
 
 // NHWC (pixel stride cs, first C channels) -> NCHW, for the reference-layout dense outputs.
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, int cs, int C, int HW, int B, float* out) {
+// `range` (nullable): the frame's largest |value| goes to its word `word` (fpc_forward's descriptor map: fpc_output_range)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, int cs, int C, int HW, int B, float* out,
+                                                           uint32_t* range = nullptr, int word = 0) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)B * C * HW) return;
+  const bool in_range = i < (size_t)B * C * HW;
   const int p = i % HW;
   const int c = (i / HW) % C;
-  const int b = i / ((size_t)HW * C);
-  out[i] = in[((size_t)b * HW + p) * cs + c];
+  const int b = in_range ? (int)(i / ((size_t)HW * C)) : B - 1;
+  float v = 0.f;
+  if (in_range) out[i] = v = in[((size_t)b * HW + p) * cs + c];
+  if (range) {
+    // (a wave may straddle two frames: the maximum goes to the frame of its first lane's element and of its last one's --
+    // a frame's word may then carry its neighbour's maximum: the words bound the tensor, which is all they are for)
+    float m = fabsf(v);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 || lane == 63) {
+      uint32_t* w = range + b * FPC_RANGE_WORDS + word;
+      if (__float_as_uint(m) > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, __float_as_uint(m));
+    }
+  }
 }
 
 // the same from a bf16 NHWC tensor (FPC_BF16 mode; fpc_read_activation)

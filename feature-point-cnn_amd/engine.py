@@ -325,17 +325,27 @@ class Engine:
     def sync(self):
         _lib.check(self._l.fpc_sync(self._ctx), "fpc_sync")
 
-    def counts(self, n):
+    def counts(self, n, allow_nonfinite=False):
+        """fpc_get_counts.  A frame with a NaN / Inf pixel raises FpcError (code -9, FPC_E_NONFINITE) unless
+        `allow_nonfinite`: the counts are delivered either way, and output_range() names the frame."""
         cnt = np.zeros(n, np.int32)
         ncand = np.zeros(n, np.int32)
-        _lib.check(self._l.fpc_get_counts(self._ctx, n, cnt.ctypes.data, ncand.ctypes.data), "fpc_get_counts")
+        rc = self._l.fpc_get_counts(self._ctx, n, cnt.ctypes.data, ncand.ctypes.data)
+        if not (allow_nonfinite and rc == -9):
+            _lib.check(rc, "fpc_get_counts")
         return cnt, ncand
 
-    def fetch(self, n, with_desc=None):
+    def output_range(self, n):
+        """fpc_output_range: per frame of the last call (max logit, max |descriptor map| (forward only), non-finite pixel?)."""
+        ml, md, bad = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        _lib.check(self._l.fpc_output_range(self._ctx, n, ml.ctypes.data, md.ctypes.data, bad.ctypes.data), "fpc_output_range")
+        return ml, md, bad.astype(bool)
+
+    def fetch(self, n, with_desc=None, allow_nonfinite=False):
         """-> list of (xy int32[K,2], conf float32[K], desc float32[K,128] | None, n_candidates)."""
         if with_desc is None:
             with_desc = self.descriptor_enabled
-        cnt, ncand = self.counts(n)
+        cnt, ncand = self.counts(n, allow_nonfinite)
         out = []
         for f in range(n):
             k = int(cnt[f])

@@ -120,3 +120,21 @@ def make_batch(first_seed, n, h=480, w=640, gray=False):
     for i in range(n):
         out[i] = make_frame(first_seed + i, h, w, gray).transpose(2, 0, 1)
     return out
+
+
+def scale_activations(sd, s):
+    """A checkpoint whose EVERY activation is `s` times that of `sd` on the same frames (exactly, in exact arithmetic):
+    the stem's BatchNorm gets weight and bias times s, every later BatchNorm running_mean and bias times s (bn(s y) with
+    mean s mu and bias s beta is s bn(y); ReLU, max-pool, the shortcut sums and the concat are positively homogeneous),
+    and so does the transposed convolution's bias.  Logits and descriptor map come out times s: what a trained network
+    with a larger dynamic range than the He-scaled synthetic ones looks like to the arithmetic."""
+    out = {k: np.array(v, copy=True) for k, v in sd.items()}
+    f = np.float32(s)
+    for name in out:
+        leaf = name.rsplit(".", 1)[1]
+        if name.startswith("encoder.bn1."):
+            if leaf in ("weight", "bias"):
+                out[name] = (out[name] * f).astype(np.float32)
+        elif leaf in ("running_mean",) or (leaf == "bias" and out[name].ndim == 1):
+            out[name] = (out[name] * f).astype(np.float32)
+    return out

@@ -47,10 +47,31 @@ enum {
   FPC_E_MISSING_KEY = -5, /* checkpoint entry missing or of the wrong shape       */
   FPC_E_CAPACITY = -6,    /* caller buffer too small (needed size is reported)    */
   FPC_E_NOT_CONVERGED = -7, /* NMS round limit hit (never seen)    */
-  FPC_E_RANGE = -8        /* FPC_F32_SPLIT_F16 only: a folded weight (at load) or an */
+  FPC_E_RANGE = -8,       /* FPC_F32_SPLIT_F16 only: a folded weight (at load) or an */
                           /* activation (reported by fpc_get_counts) left fp16's     */
                           /* range |x| <= 65504; use FPC_F32_SPLIT or FPC_F32        */
+  FPC_E_NONFINITE = -9    /* fpc_get_counts: a frame of the call held a NaN or +-Inf */
+                          /* pixel (see "Numerical contract" below)                  */
 };
+
+/* Numerical contract of FPC_F32 (the default), measured against a double-accumulating restatement of the reference on
+ * checkpoints whose every activation was scaled x1 .. x100 (tests/test_gpu_round5.py):
+ *  - the PRODUCTS of the path -- probability map, keypoint coordinates and confidences, unit-norm descriptors -- are
+ *    within 1e-4 (measured <= 1.7e-5) / identical sets at every magnitude the reference itself survives: its softmax has
+ *    no max-subtraction (python/src/superpoint.py:111-112), so logits above 88.7 overflow exp() there and here alike
+ *    (NaN probabilities, no keypoint in such a cell);
+ *  - the dense fp32 tensors fpc_forward returns (logits, descriptor map) carry fp32's RELATIVE error:
+ *    |delta| <= 2.5e-6 * max|tensor| (measured 1.5e-6; the 3x3 layers run as Winograd F(4x4,3x3), whose F(2x2,3x3) and
+ *    direct alternatives measure 1.0-1.7x smaller, i.e. the bound is fp32 accumulation over 12 layers, not the
+ *    transform).  An ABSOLUTE 1e-4 therefore holds while max|tensor| <= 40 (13 ulp of fp32 at 64): fpc_output_range
+ *    reports the magnitudes of the last call so that a caller who needs the absolute bar can check it;
+ *  - frames must be finite.  FPC_F32's stem looks at every pixel it stages: a NaN or +-Inf pixel makes fpc_get_counts
+ *    return FPC_E_NONFINITE for the call (after delivering the counts) and fpc_output_range name the frame.  The other
+ *    frames of the batch are unaffected (frames are independent), and the call is memory-safe; the flagged frame's own
+ *    results are UNDEFINED -- the reference propagates the NaN through the receptive field of the pixel (a region of
+ *    NaN logits, no keypoints there), this library's ReLU (v_max_f32 returns the non-NaN operand) does not, and its
+ *    Winograd tiles spread whatever survives further than a direct convolution would.  fpc_detect_u8* inputs are 8-bit
+ *    and cannot be non-finite.  The other dtype modes do not check. */
 
 enum { FPC_F32 = 0, FPC_BF16 = 1, FPC_F32_SPLIT = 2, FPC_F32_SPLIT_F16 = 3 };
 enum { FPC_ARCH_RESNET = 0, FPC_ARCH_VGG = 1 };
@@ -330,8 +351,14 @@ int fpc_first_within(fpc_ctx* ctx, const float* key_dev, int nk, const float* cu
                      float tolerance, int32_t* first_dev);
 
 int fpc_results(fpc_ctx* ctx, fpc_device_results* out);
-/* Synchronises, then copies the per-frame counts to the host. */
+/* Synchronises, then copies the per-frame counts to the host.  FPC_E_NONFINITE (counts delivered all the same) when a
+ * frame of the call held a NaN / Inf pixel: "Numerical contract" at the top of this header. */
 int fpc_get_counts(fpc_ctx* ctx, int n, int32_t* count_host, int32_t* n_candidates_host);
+/* Synchronises; per frame of the last call: the largest logit (fpc_detect and fpc_forward; logits are post-ReLU, >= 0),
+ * the largest |value| of the descriptor map (fpc_forward with a desc output only, else 0; a frame's figure may include
+ * its neighbour's -- it bounds the tensor), and whether the frame held a non-finite pixel (FPC_F32 only).  Host arrays of
+ * n entries, any may be NULL.  What the "Numerical contract" above is checked against. */
+int fpc_output_range(fpc_ctx* ctx, int n, float* max_logit_host, float* max_desc_host, int32_t* nonfinite_input_host);
 /* Synchronises, then copies frame `frame`'s keypoints: xy [K][2], conf [K],
  * desc [K][128] (desc may be NULL).  Returns K, or FPC_E_CAPACITY if K > cap
  * (nothing is written then; fpc_get_counts gives the size). */

@@ -220,3 +220,93 @@ def test_the_device_backend_blob_target_is_the_librarys_own_buffer():
             del os.environ["FPC_DIST_ZERO_COPY"]
     s_finish()
     src.close()
+
+
+def oracle_mod():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("scale", [1, 4, 8, 30, 100])
+def test_dynamic_range_of_the_fp32_winograd_plan(scale):
+    """include/fpc.h "Numerical contract", held on the device.  Every activation of the network scaled by `scale`
+    (synth.scale_activations: exact in exact arithmetic) -- at x8 the logits reach 71 and the descriptor map 85, at x100
+    886 / 1060 -- through the BATCH plan (16 frames: the F(4x4,3x3) kernels) against the double-accumulating oracle:
+      * dense logits and descriptor map within 2.5e-6 of the tensor's magnitude (measured 1.5e-6), and within the absolute
+        1e-4 while that magnitude is <= 40;
+      * the products: probability map within 1e-4 (measured <= 1.7e-5 at every scale), keypoint sets identical, sampled
+        unit descriptors within 1e-4 -- up to x8; from x10 on the reference's own exp() overflows (no max-subtraction:
+        superpoint.py:111-112): NaN probabilities there, no keypoints there and none here;
+      * fpc_output_range reports the magnitudes the bound is stated in."""
+    h, w, n = 240, 320, 16
+    sd = synth.scale_activations(synth.make_state_dict(3, dustbin_bias=4.0), scale)
+    frames = synth.make_batch(11, n, h, w)
+    o_prob, o_desc, o_logits = oracle_mod().forward(frames[:2], sd, SPEC)
+    e = engine(h, w, n)
+    e.load_state_dict(sd)
+    prob, desc, logits = e.forward(frames)
+    ml, md, bad = e.output_range(n)
+    assert not bad.any()
+    mag_l, mag_d = float(np.max(np.abs(o_logits))), float(np.max(np.abs(o_desc)))
+    assert abs(float(ml[:2].max()) - mag_l) < 1e-3 * mag_l and float(md.max()) >= 0.999 * mag_d
+    dl = float(np.max(np.abs(logits[:2].cpu().numpy() - o_logits)))
+    dd = float(np.max(np.abs(desc[:2].cpu().numpy() - o_desc)))
+    assert dl <= 2.5e-6 * max(mag_l, 40.0) and dd <= 2.5e-6 * max(mag_d, 40.0), (scale, mag_l, dl, mag_d, dd)
+    if max(mag_l, mag_d) <= 40.0:
+        assert dl < ATOL and dd < ATOL
+    res = e.detect(frames)
+    for b in range(2):
+        oxs, oys, oconf, _ = oracle_mod().get_points(o_prob[b])
+        xy, conf, d, _ = res[b]
+        if scale <= 8:
+            assert np.nanmax(np.abs(prob[b].cpu().numpy() - o_prob[b])) < ATOL
+            assert len(oxs) > 300
+            assert set(map(tuple, xy.tolist())) == set(zip(oxs.tolist(), oys.tolist()))
+            od = oracle_mod().get_descriptors(o_desc[b], xy[:, 0], xy[:, 1], h, w)
+            assert float(np.max(np.abs(d - od))) < ATOL
+        else:
+            assert len(oxs) == 0 and len(xy) == 0          # exp(logit > 88.7) = inf in the reference as well
+    e.close()
+
+
+def test_a_non_finite_pixel_is_reported_and_stays_in_its_frame():
+    """Frames must be finite ("Numerical contract", include/fpc.h).  A batch of three VGA-quarter frames whose middle one
+    holds a NaN and an Inf pixel: fpc_get_counts delivers the counts and returns FPC_E_NONFINITE, fpc_output_range names
+    frame 1 and only frame 1, the other two frames' keypoints and descriptors are bit for bit those of the clean batch
+    (frames are independent), nothing is stored outside the tensors (canary zones), and the next clean call is clean."""
+    import torch
+    h, w, n = 240, 320, 3
+    sd = synth.make_state_dict(3, dustbin_bias=4.0)
+    frames = synth.make_batch(11, n, h, w)
+    e = engine(h, w, n, plan_flags=["guard_zones"])
+    e.load_state_dict(sd)
+    clean = e.detect(frames)
+    dirty = np.array(frames)
+    dirty[1, 0, 17, 23] = np.nan
+    dirty[1, 2, 200, 301] = np.inf
+    dev = torch.from_numpy(dirty).to(e.torch_device)
+    e.detect_async(dev, n)
+    with pytest.raises(_lib.FpcError) as ei:
+        e.counts(n)
+    assert ei.value.code == -9 and "frame 1" in str(ei.value)
+    _, _, bad = e.output_range(n)
+    assert bad.tolist() == [False, True, False]
+    got = e.fetch(n, allow_nonfinite=True)
+    for b in (0, 2):
+        np.testing.assert_array_equal(clean[b][0], got[b][0])
+        np.testing.assert_array_equal(clean[b][1], got[b][1])
+        np.testing.assert_array_equal(clean[b][2], got[b][2])
+    assert e.check_guards() == 0
+    again = e.detect(frames)
+    assert not e.output_range(n)[2].any()
+    for b in range(n):
+        np.testing.assert_array_equal(clean[b][0], again[b][0])
+    # gray frames go through the same stem
+    g = engine(h, w, 1, in_channels=1)
+    g.load_state_dict(sd)
+    gf = np.array(frames[:1, :1])
+    gf[0, 0, 100, 100] = -np.inf
+    g.detect_async(torch.from_numpy(gf).to(g.torch_device), 1)
+    assert g.output_range(1)[2].tolist() == [True]
+    g.close()
+    e.close()
