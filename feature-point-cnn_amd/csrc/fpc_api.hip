@@ -27,6 +27,7 @@
 #include "wblock_mfma.h"
 #include "wblock16_mfma.h"
 #include "wblock36_mfma.h"
+#include "wblock36p_mfma.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "queue_map.h"
@@ -167,6 +168,12 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
   X(W36_C128_4x4, 2, 4, 4) \
   X(W36_C128_2x8, 2, 2, 8)
 
+// W36PKIND(name, TYT, TXT): wblock36p_kernel (round 5: the 64-channel instance at TWO waves per SIMD -- 512 threads, the 36
+// positions split between the two waves of a SIMD; same packed weights as W36_C64_*)
+#define FPC_W36P_KINDS(X) \
+  X(W36P_C64_4x4, 4, 4)   \
+  X(W36P_C64_2x8, 2, 8)
+
 // W36DKIND(name, TYT, TXT): wblock36_dust_kernel -- the 64-channel instance + the detector's 65th channel on the VALU
 #define FPC_W36D_KINDS(X) \
   X(W36_C65_4x4, 4, 4)    \
@@ -178,6 +185,7 @@ enum WKind {
   FPC_W16_KINDS(X)
   FPC_W36_KINDS(X)
   FPC_W36D_KINDS(X)
+  FPC_W36P_KINDS(X)
 #undef X
       WK_COUNT
 };
@@ -224,6 +232,13 @@ FPC_W36_KINDS(X)
   }
 FPC_W36D_KINDS(X)
 #undef X
+#define X(name, TYT, TXT)                                                                                  \
+  static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
+    constexpr int lds = W36PCfg<TYT, TXT>::LDS_BYTES;                                                     \
+    hipLaunchKernelGGL((wblock36p_kernel<TYT, TXT>), grid, dim3(512), lds, st, a);                        \
+  }
+FPC_W36P_KINDS(X)
+#undef X
 
 static const WKindInfo g_wkinds[WK_COUNT] = {
 #define X(name, KC, NBT, CMID)                                                                            \
@@ -245,6 +260,11 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
   {#name, "wblock36_dust_kernel<" #TYT ", " #TXT ">", 3, 16, 2, 64,                                        \
    W36Cfg<1, TYT, TXT, true>::LDS_BYTES, 4, 4 * TYT, 4 * TXT, 256, (const void*)wblock36_dust_kernel<TYT, TXT>, launchw_##name, true},
     FPC_W36D_KINDS(X)
+#undef X
+#define X(name, TYT, TXT)                                                                                 \
+  {#name, "wblock36p_kernel<" #TYT ", " #TXT ">", 3, 16, 2, 64,                                            \
+   W36PCfg<TYT, TXT>::LDS_BYTES, 4, 4 * TYT, 4 * TXT, 512, (const void*)wblock36p_kernel<TYT, TXT>, launchw_##name},
+    FPC_W36P_KINDS(X)
 #undef X
 };
 
@@ -280,9 +300,12 @@ static int w36_conv_part(int cout, int tiles, int cus) {
   return t1 < t2 ? 64 : 128;
 }
 // Generation 3: the arrangement of the 16 Winograd tiles (4 x 4 or 2 x 8) that covers the map with fewer tiles
-static WKind w36_kind(int cout, int H, int W) {
+// (cout == 64, `paired`: the two-waves-per-SIMD instance, wblock36p_mfma.h -- the default since round 5; a block's
+// projection must then be a multiple of 64 channels wide, which every 64-channel layer of both networks is)
+static WKind w36_kind(int cout, int H, int W, bool paired = false) {
   const int t44 = ((H + 15) / 16) * ((W + 15) / 16), t28 = ((H + 7) / 8) * ((W + 31) / 32);
   if (cout == 65) return t28 < t44 ? WK_W36_C65_2x8 : WK_W36_C65_4x4;
+  if (cout == 64 && paired) return t28 < t44 ? WK_W36P_C64_2x8 : WK_W36P_C64_4x4;
   if (cout == 64) return t28 < t44 ? WK_W36_C64_2x8 : WK_W36_C64_4x4;
   return t28 < t44 ? WK_W36_C128_2x8 : WK_W36_C128_4x4;
 }
@@ -445,6 +468,7 @@ struct fpc_ctx {
 #endif
   bool winograd_in1 = true;          // descriptor.layer_in.1 (256 ch): conv-only Winograd x2 + 1x1 (FPC_WINOGRAD_IN1=0: fused direct block)
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
+  bool w36_paired = true;            // the 64-channel F(4x4,3x3) layers on wblock36p_kernel, two waves per SIMD (FPC_PLAN_W36_ONE_WAVE / FPC_W36_PAIRED=0: wblock36_kernel<1, ..>)
   bool winograd_det_gen3 = true;     // ... on wblock36_dust_kernel in batch calls (FPC_PLAN_DETECTOR_GEN1 / FPC_WINOGRAD_DET_GEN=1: round 1's kernel)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
   bool latency_tiles = true;         // calls of a few frames run the 128-channel Winograd blocks on 4 x 16 tiles (FPC_LATENCY_TILES=0: 8 x 16)
@@ -463,6 +487,7 @@ struct fpc_ctx {
   float* prob;
   uint32_t *nmsmap, *cand;
   int32_t *ncand, *count, *xy, *status;
+  float* rowmax = nullptr;          // [B][H / 8]: the largest logit of every row of cells of the last call
   uint32_t* range = nullptr;        // [B][FPC_RANGE_WORDS]: largest logit / descriptor-map value, non-finite input flag, per frame
   float *conf, *desc_out;
   unsigned long long* sort_scratch;
@@ -1196,6 +1221,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
   const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4 + BLOB_HEADER_FLOATS);   // + the 64-byte tag of fpc_broadcast_weights
   const size_t o_range = cv.take<uint32_t>((size_t)B * FPC_RANGE_WORDS);   // per-frame range words (kernels_misc.h)
+  const size_t o_rowmax = cv.take<float>((size_t)B * (H / 8));             // largest logit per row of cells (softmax_d2s_kernel)
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>((size_t)B * c->cap * 256);
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
@@ -1218,6 +1244,7 @@ static int build_vgg_plan(fpc_ctx* c) {
   c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
   c->bcast_tag = reinterpret_cast<uint32_t*>(c->status + 4);
   c->range = reinterpret_cast<uint32_t*>(c->slab + o_range);
+  c->rowmax = reinterpret_cast<float*>(c->slab + o_rowmax);
   c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
@@ -1252,7 +1279,7 @@ static int build_vgg_plan(fpc_ctx* c) {
         // (priced for a 32-frame call whatever max_batch is: the packed layout must not depend on it -- contexts of
         // different max_batch exchange blobs)
         const int part = w36_conv_part(cout, ((Hx + 15) / 16) * ((Wx + 15) / 16) * 32, 256);
-        add(w36_kind(part, Hx, Wx), c->latency_tiles ? 2 : 0);
+        add(w36_kind(part, Hx, Wx, c->w36_paired), c->latency_tiles ? 2 : 0);
         if (c->latency_tiles) add(wk2, 1);
       } else {
         add(wk2, 0);
@@ -1406,6 +1433,7 @@ static int build_plan(fpc_ctx* c) {
   const size_t o_map = cv.take<uint32_t>((size_t)B * H * W), o_cand = cv.take<uint32_t>((size_t)B * H * W);
   const size_t o_ncand = cv.take<int32_t>(B), o_count = cv.take<int32_t>(B), o_status = cv.take<int32_t>(4 + BLOB_HEADER_FLOATS);   // + the 64-byte tag of fpc_broadcast_weights
   const size_t o_range = cv.take<uint32_t>((size_t)B * FPC_RANGE_WORDS);   // per-frame range words (kernels_misc.h)
+  const size_t o_rowmax = cv.take<float>((size_t)B * (H / 8));             // largest logit per row of cells (softmax_d2s_kernel)
   const size_t o_xy = cv.take<int32_t>((size_t)B * c->cap * 2), o_conf = cv.take<float>((size_t)B * c->cap);
   const size_t o_dout = cv.take<float>(de ? (size_t)B * c->cap * 128 : 64);
   const size_t o_sort = cv.take<unsigned long long>((size_t)B * c->sort_cap);
@@ -1432,6 +1460,7 @@ static int build_plan(fpc_ctx* c) {
   c->status = reinterpret_cast<int32_t*>(c->slab + o_status);
   c->bcast_tag = reinterpret_cast<uint32_t*>(c->status + 4);
   c->range = reinterpret_cast<uint32_t*>(c->slab + o_range);
+  c->rowmax = reinterpret_cast<float*>(c->slab + o_rowmax);
   c->xy = reinterpret_cast<int32_t*>(c->slab + o_xy);
   c->conf = F(o_conf);
   c->desc_out = F(o_dout);
@@ -1479,7 +1508,7 @@ static int build_plan(fpc_ctx* c) {
         // by 4): k8_x = cinp / 8 must be a multiple of 8, i.e. cinp of 64 -- true of every layer of both networks; a
         // layer that is not falls back to generation 2 instead of running extra K steps over stale staging rows
         const int gen = c->winograd_gen == 3 && (!w36_fits(c->B, Hx, Wx, csx, csy) || (proj && cinp % 64 != 0)) ? 2 : c->winograd_gen;
-        if (cinp % 32 == 0 && cout == 64) wk = gen == 3 ? w36_kind(64, Hx, Wx) : gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
+        if (cinp % 32 == 0 && cout == 64) wk = gen == 3 ? w36_kind(64, Hx, Wx, c->w36_paired) : gen == 2 ? WK_W16_C64 : WK_W816_K32_C64;
         else if (cinp % 32 == 0 && cout == 128) wk = gen == 3 ? w36_kind(128, Hx, Wx) : gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
         else if (c->winograd_det && cout == 65 && c->winograd_det_gen3 && c->winograd_gen == 3 && w36_fits(c->B, Hx, Wx, csx, csy) &&
                  (cin == 65 ? !proj : (cin == cinp && cinp % 64 == 0 && cinp <= 256)))
@@ -1581,7 +1610,7 @@ static int build_plan(fpc_ctx* c) {
       const bool g3 = c->winograd_gen == 3 && w36_fits(c->B, H16, W16, 256, 256);
       const int in1_parts = g3 ? 4 : 2;
       for (int n0 = 0; n0 < 256; n0 += 256 / in1_parts)
-        add_wconv(c, p, true, g3 ? w36_kind(64, H16, W16) : c->winograd_gen >= 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
+        add_wconv(c, p, true, g3 ? w36_kind(64, H16, W16, c->w36_paired) : c->winograd_gen >= 2 ? WK_W16_C128 : WK_W816_K32_C128, c->y16a, 256, 256, H16, W16, c->h16, 256, 256, n0, true, &bo);
       const size_t in1_ops = in1_parts + 1;      // [the launch, its shadows, the 1x1 below]
       ConvSpec t{};
       t.name = p + ".conv2+bn2+identity+relu";
@@ -2508,7 +2537,7 @@ static void run_softmax(fpc_ctx* c, const Sub& sb, bool dense_map = true) {
   hipLaunchKernelGGL(kern, dim3(sb.n * c->Hc), dim3(256), (size_t)12 * c->W * sizeof(float), sb.st,
                      c->lg + (size_t)sb.f0 * c->Hc * c->Wc * c->lgcs, c->lgcs, sb.n, c->Hc, c->Wc, c->cfg.conf_thresh,
                      dense_map ? c->prob + sb.f0 * HW : nullptr, c->nmsmap + sb.f0 * HW, c->cand + sb.f0 * HW, c->ncand + sb.f0,
-                     c->range + (size_t)sb.f0 * FPC_RANGE_WORDS);
+                     c->rowmax + (size_t)sb.f0 * c->Hc);
 }
 
 static void run_nms(fpc_ctx* c, const Sub& sb) {
@@ -2837,6 +2866,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->guard_zones = (pf & FPC_PLAN_GUARD_ZONES) != 0;
     if (const char* e = getenv("FPC_GUARD_ZONES")) c->guard_zones = atoi(e) != 0;      // (a whole test run under the canary zones)
     c->winograd_det_gen3 = !(pf & FPC_PLAN_DETECTOR_GEN1);
+    c->w36_paired = !(pf & FPC_PLAN_W36_ONE_WAVE);
+    if (const char* e = getenv("FPC_W36_PAIRED")) c->w36_paired = atoi(e) != 0;
     if (const char* e = getenv("FPC_WINOGRAD_DET_GEN")) c->winograd_det_gen3 = atoi(e) >= 3;
     c->winograd = !(pf & FPC_PLAN_NO_WINOGRAD);
     c->winograd_det = !(pf & FPC_PLAN_NO_WINOGRAD_DETECTOR);
@@ -3624,10 +3655,16 @@ int fpc_output_range(fpc_ctx* c, int n, float* max_logit, float* max_desc, int32
   HIPCHECK(hipStreamSynchronize(c->stream));
   std::vector<uint32_t> rw((size_t)n * FPC_RANGE_WORDS);
   HIPCHECK(hipMemcpy(rw.data(), c->range, rw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<float> rm((size_t)n * c->Hc);
+  if (max_logit) HIPCHECK(hipMemcpy(rm.data(), c->rowmax, rm.size() * sizeof(float), hipMemcpyDeviceToHost));
   for (int b = 0; b < n; ++b) {
     const uint32_t* w = rw.data() + (size_t)b * FPC_RANGE_WORDS;
     float f;
-    if (max_logit) { memcpy(&f, w + RANGE_MAX_LOGIT, 4); max_logit[b] = f; }
+    if (max_logit) {
+      f = 0.f;
+      for (int i = 0; i < c->Hc; ++i) f = std::max(f, rm[(size_t)b * c->Hc + i]);
+      max_logit[b] = f;
+    }
     if (max_desc) { memcpy(&f, w + RANGE_MAX_DESC, 4); max_desc[b] = f; }
     if (nonfinite_input) nonfinite_input[b] = (int32_t)w[RANGE_BAD_INPUT];
   }

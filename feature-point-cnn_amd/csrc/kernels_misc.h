@@ -403,12 +403,13 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* 
 template <bool FAST = false>
 __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, int cs, int B, int Hc, int Wc,
                                                           float thresh, float* prob, uint32_t* nmsmap,
-                                                          uint32_t* cand, int32_t* ncand, uint32_t* range) {
+                                                          uint32_t* cand, int32_t* ncand, float* rowmax) {
   // one workgroup per ROW of cells: the 8 x W strip of probabilities is assembled in LDS so
   // that the dense maps are written as whole rows, and the strip's candidates are appended
   // with ONE global atomic (per-wave atomics on one counter serialise at ~11 ns each).
   extern __shared__ float strip[];                 // [8][W] floats, then [8*W] 16-bit candidate slots (8 W < 65536)
   __shared__ int s_cnt, s_base;
+  __shared__ float s_max[4];
   const int W = Wc * 8, H = Hc * 8;
   unsigned short* s_list = reinterpret_cast<unsigned short*>(strip + 8 * W);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -445,19 +446,17 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* logits, i
             make_float4(sm_prob<FAST>(e0, den), sm_prob<FAST>(e1, den), sm_prob<FAST>(e2, den), sm_prob<FAST>(e3, den));
     }
   }
-  if (range) {
-    // the frame's largest |logit| (include/fpc.h: fpc_output_range): a wave's maximum, one atomic per wave and only when
-    // it raises the word (after a frame's first rows almost never)
+  // the largest logit of this row of cells -> rowmax[frame][row] (include/fpc.h: fpc_output_range reduces the rows): a wave's
+  // maximum to LDS in front of the barrier that is there anyway, one plain store per workgroup behind it.  (Round 5's first
+  // form -- an atomicMax per wave on the frame's word -- doubled this kernel's time: 240 atomics per word.)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-    uint32_t* word = range + b * FPC_RANGE_WORDS + RANGE_MAX_LOGIT;
-    if (lane == 0 && __float_as_uint(lmax) > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(word, __float_as_uint(lmax));
-  }
+  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  if (lane == 0) s_max[wave] = lmax;
   __syncthreads();
   // write-out, four pixels per thread and trip (16-byte LDS reads and stores: as single floats this loop was 80 store
   // instructions per thread at HD); `prob` is NULL in fpc_detect, whose callers never see the dense map (a third of the
   // kernel's bytes)
+  if (rowmax && tid == 0) rowmax[b * Hc + i] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
   const size_t fbase = (size_t)b * H * W + (size_t)i * 8 * W;
   for (int k4 = tid; k4 < 2 * W; k4 += 256) {      // 8 W / 4 groups; 2 W is a multiple of 16, not always of 64
     const float4 p4 = *reinterpret_cast<const float4*>(strip + 4 * k4);

@@ -449,9 +449,12 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
       f32x4 ac[2][AQ];
 #pragma unroll
       for (int q = 0; q < AQ; ++q) ac[0][q] = lds4[ao + q * 64];
-#ifdef FPC_DIAG
+#ifdef FPC_DIAG_STEPS
+      // (per-step stamps: their own switch of the diagnostic build, and BRANCH-FREE -- as `if (a.stamps) s_memtime` every
+      // stamp split the chunk loop's basic block, and every block join costs an `s_waitcnt vmcnt(0)`: round 5 found the
+      // diagnostic build's chunk 60 % slower than the product's, and its first two steps "taking 6 k cycles")
       unsigned long long tq[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define FPC_TQ(i) if (a.stamps) asm volatile("s_memtime %0" : "=s"(tq[i]));
+#define FPC_TQ(i) asm volatile("s_memtime %0" : "=s"(tq[i]));
 #else
 #define FPC_TQ(i)
 #endif
@@ -531,7 +534,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB * (RING - 1)) : "memory");
       FPC_LDS_BARRIER();
       FPC_TQ(10)
-#ifdef FPC_DIAG
+#ifdef FPC_DIAG_STEPS
       if (a.stamps && wg == wg_stamp && c == 2 && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         unsigned long long* q = a.stamps + 1024 * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;

@@ -53,7 +53,7 @@ def test_product_library_was_built_without_experiment_switches():
         if name.endswith((".h", ".hip")):
             text = open(os.path.join(csrc, name)).read()
             for m in re.finditer(r"#\s*if(?:n?def)?\s+(?:!?\s*defined\s*\(?\s*)?(\w+)", text):
-                assert m.group(1) in ("FPC_DIAG", "defined", "STEMB_SKIP_LOAD"), (name, m.group(0))
+                assert m.group(1) in ("FPC_DIAG", "FPC_DIAG_STEPS", "defined", "STEMB_SKIP_LOAD"), (name, m.group(0))
 
 
 def test_library_contains_gfx950_code_object():

@@ -41,6 +41,10 @@ SPILLS = {
     # wblock36_dust_kernel<TYT, TXT> (the detector's 64 + 1 channels: NB = 1 and the dustbin channel on the VALU)
     (1, 4, 4, "dust"): (176, 0, 0),
     (1, 2, 8, "dust"): (176, 0, 0),
+    # wblock36p_kernel<TYT, TXT, RING> (round 5: the 64-channel instance at two waves per SIMD; accumulators in VGPRs, no AGPR
+    # named anywhere -- with one, the compiler splits the wave's 256 registers 128 / 128 and spills 137)
+    ("p", 4, 4): (48, 0, 0),
+    ("p", 2, 8): (48, 0, 0),
 }
 
 
@@ -48,6 +52,8 @@ SPILLS = {
 def code_object(tmp_path_factory):
     if not os.path.exists(LIB):
         pytest.skip("libfpc.so not built")
+    if not all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objdump", "llvm-readelf")):
+        pytest.skip("no LLVM tools under %s (a box without ROCm): the code object cannot be disassembled" % LLVM)
     d = tmp_path_factory.mktemp("isa")
     lib = os.path.join(d, "libfpc.so")
     shutil.copy(LIB, lib)
@@ -73,6 +79,7 @@ def code_object(tmp_path_factory):
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
         meta[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
                       for k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+        meta[name]["agpr_count"] = int(blk.split()[0])
     return funcs, meta
 
 
@@ -85,6 +92,9 @@ def _instances(funcs):
         m = re.match(r"_ZN3fpc20wblock36_dust_kernelILi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
         if m:
             out[(1,) + tuple(int(v) for v in m.groups()) + ("dust",)] = name
+        m = re.match(r"_ZN3fpc16wblock36p_kernelILi(\d+)ELi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
+        if m:
+            out[("p",) + tuple(int(v) for v in m.groups()[:2])] = name
     return out
 
 
@@ -235,8 +245,11 @@ def test_spills_are_what_design_md_says_and_outside_the_chunk_loop(code_object):
         loop = _chunk_loop(body)
         assert loop is not None, key
         head, tail, n_mfma = loop
-        # two chunks per trip: 2 x 36 positions x 4 k-steps x NB channel blocks
-        assert n_mfma == 2 * 36 * 4 * key[0], (key, n_mfma)
+        # two chunks per trip: 2 x 36 positions x 4 k-steps x NB channel blocks (the paired kernel: a wave's 18 positions,
+        # one such loop per role)
+        assert n_mfma == (2 * 18 * 4 if key[0] == "p" else 2 * 36 * 4 * key[0]), (key, n_mfma)
+        if key[0] == "p":
+            assert m["agpr_count"] == 0 and m["vgpr_count"] <= 256, (key, m)
         inside = [i for _, i in body[head:tail] if i.startswith(("v_readlane", "v_writelane", "scratch_"))]
         if "dust" in key:
             # the dust instance reloads the LDS-DMA's M0 values (the halo request's VALU burst, once per chunk) from spilled
