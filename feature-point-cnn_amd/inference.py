@@ -140,9 +140,10 @@ def truncated_normal(n, mean=0.0, stddev=1.0, rng=None):
 
 
 def sample_homography(shape, config=None, rng=None, reference_aliasing=True):
-    """sample_homography (python/src/homographies.py:78-192) step by step: a centred patch is perturbed
-    (perspective, scale, translation, rotation), each step keeping the corners inside the unit square unless
-    allow_artifacts, and the 8 coefficients mapping output points to input points are solved for.
+    """Restatement of `homographies.py:78-192` (python/src), quirks included -- a numpy transliteration in the reference's
+    own step order, not an independent design: a centred patch is perturbed (perspective, scale, translation,
+    rotation), each step keeping the corners inside the unit square unless allow_artifacts, and the 8 coefficients
+    mapping output points to input points are solved for.
 
     REPRODUCED QUIRK (round 4; the review measured it on the reference's own function): `pts2 = pts1` (:117) is an
     ALIAS, and the perspective step (:127) and the translation step (:155) perturb it IN PLACE, while the scaling
