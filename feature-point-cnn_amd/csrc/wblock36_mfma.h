@@ -90,10 +90,12 @@ struct W36Cfg {
   static constexpr int HPX = 128;                                   // pixels of one half
   static constexpr int T_FLOATS = HPX * (RH > RX ? RH : RX);
   static constexpr int BASE_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
-  // DUST: W2COL | WPCOL (336), UIN (2304), V of input channel 64 [36][16], M of output channel 64 [36][16], the halo of input
-  // channel 64 (one 16-byte slot per pixel by LDS-DMA: HIT64 requests per thread)
+  // DUST: the dust block's first 448 floats as they are (W2ROW | W2COL | WPCOL | B1, B2 | UIN64: every constant the tile's
+  // tail reads -- round 5: as scalar / vector GLOBAL loads in the tail each one was an L2 round trip in a serial chain),
+  // UIN (2304), V of input channel 64 [36][16], M of output channel 64 [36][16], the halo of input channel 64 (one 16-byte
+  // slot per pixel by LDS-DMA: HIT64 requests per thread)
   static constexpr int HIT64 = (NHALO + NT - 1) / NT;
-  static constexpr int D_COL = BASE_FLOATS, D_UIN = D_COL + 336, D_V64 = D_UIN + 2304, D_M64 = D_V64 + 576, D_H64 = D_M64 + 576;
+  static constexpr int D_HEAD = BASE_FLOATS, D_COL = D_HEAD + 64, D_UIN = D_HEAD + 448, D_V64 = D_UIN + 2304, D_M64 = D_V64 + 576, D_H64 = D_M64 + 576;
   static constexpr int LDS_FLOATS = DUST ? D_H64 + HIT64 * NT * 4 : BASE_FLOATS;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -371,7 +373,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
     d_va = wave * 64 + lane;                                                    // float4 index of (position w, this lane) in a V buffer
     d_ua = wave * 64 + 16 * ((lane & 3) ^ (2 * (lane >> 5)));                   // byte offset of its filter quad in a chunk's [36][16]
     // once per workgroup: W2COL | WPCOL and UIN into LDS (read back as broadcasts / MFMA operands at every tile's end)
-    for (int i = tid; i < 336 / 4; i += NT) lds4[C::D_COL / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::W2COL)[i];
+    for (int i = tid; i < 448 / 4; i += NT) lds4[C::D_HEAD / 4 + i] = reinterpret_cast<const f32x4*>(a.dust)[i];
     for (int i = tid; i < 2304 / 4; i += NT) lds4[C::D_UIN / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::UIN)[i];
   }
 
@@ -584,13 +586,20 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
         // ... and every wave adds its 16 output channels' share: ONE MFMA per position, K = 4 of which k = 0 is real (the
         // A operand of lanes 16..63 is zero, so their B operand only has to be finite)
         {
+          // (all 72 operands first -- the fragment ring's registers are free here --, then the 36 MFMAs back to back: as
+          // read, wait, multiply per position the loop was 36 LDS round trips in a row)
           const int va = C::D_V64 + (lane_d & 15), ub = C::D_UIN + wave * 576 + (lane_d & 15);
+          float av[36], bv[36];
 #pragma unroll
           for (int p = 0; p < 36; ++p) {
-            float av = lds[va + p * 16];
-            const float bv = lds[ub + p * 16];
-            av = lane_d < 16 ? av : 0.f;
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[p][0], 0, 0, 0);
+            av[p] = lds[va + p * 16];
+            bv[p] = lds[ub + p * 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 36; ++p) {
+            const float x = lane_d < 16 ? av[p] : 0.f;
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, bv[p], acc[p][0], 0, 0, 0);
           }
         }
       }
@@ -604,7 +613,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
           v += __shfl_xor(v, 1);
           v += __shfl_xor(v, 2);
           const int pos = wave + 4 * i;
-          if (a.dust_in) v = __builtin_fmaf(lds[C::D_V64 + pos * 16 + m_d], a.dust[W36Dust::UIN64 + pos], v);
+          if (a.dust_in) v = __builtin_fmaf(lds[C::D_V64 + pos * 16 + m_d], lds[C::D_HEAD + W36Dust::UIN64 + pos], v);
           if ((lane_d & 3) == 0) lds[C::D_M64 + pos * 16 + m_d] = v;
         }
       }
@@ -615,7 +624,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
         float mm[36];
 #pragma unroll
         for (int p = 0; p < 36; ++p) mm[p] = lds[C::D_M64 + p * 16 + tid_d];
-        const float bias1 = a.dust[W36Dust::B1];
+        const float bias1 = lds[C::D_HEAD + W36Dust::B1];
         float tt[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -804,7 +813,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
           for (int e = 0; e < 4; ++e) v = __builtin_fmaf(hq[e], wq[e], v);
           dpart[it] = v;
         }
-        dw2r = a.dust[W36Dust::W2ROW + 16 * wave + (lane_t & 15)];
+        dw2r = lds[C::D_HEAD + W36Dust::W2ROW + 16 * wave + (lane_t & 15)];
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
@@ -1001,7 +1010,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
         float tot = (b1 ? r2[1] : r2[0]) + __shfl_xor(b1 ? r2[0] : r2[1], 2);
         tot += __shfl_xor(tot, 1);
         const int dpx = 32 * wave + 4 * (dq >> 1) + dpxl, dhf = dq & 1, drow = dpx / TW, dcol = dpx % TW;
-        tot += dx64 + a.dust[W36Dust::B2];
+        tot += dx64 + lds[C::D_HEAD + W36Dust::B2];
         tot = tot > 0.f ? tot : 0.f;
         const bool ok = (drow < rows_valid) & (x0 + dcol < a.W);
         const int doff = ok ? ((drow * a.W + dcol) * a.cso + 64 + 4 * dhf) * 4 : W36_MARKER;
