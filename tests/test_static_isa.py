@@ -39,8 +39,8 @@ SPILLS = {
     (2, 4, 4): (96, 4, 16),
     (2, 2, 8): (96, 4, 16),
     # wblock36_dust_kernel<TYT, TXT> (the detector's 64 + 1 channels: NB = 1 and the dustbin channel on the VALU)
-    (1, 4, 4, "dust"): (176, 0, 0),
-    (1, 2, 8, "dust"): (176, 0, 0),
+    (1, 4, 4, "dust"): (184, 0, 0),
+    (1, 2, 8, "dust"): (184, 0, 0),
     # wblock36p_kernel<TYT, TXT, RING> (round 5: the 64-channel instance at two waves per SIMD; accumulators in VGPRs, no AGPR
     # named anywhere -- with one, the compiler splits the wave's 256 registers 128 / 128 and spills 137)
     ("p", 4, 4): (48, 0, 0),
