@@ -262,7 +262,7 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
     FPC_W36D_KINDS(X)
 #undef X
 #define X(name, TYT, TXT)                                                                                 \
-  {#name, "wblock36p_kernel<" #TYT ", " #TXT ">", 3, 16, 2, 64,                                            \
+  {#name, "wblock36p_kernel<" #TYT ", " #TXT ", 3>", 3, 16, 2, 64,                                            \
    W36PCfg<TYT, TXT>::LDS_BYTES, 4, 4 * TYT, 4 * TXT, 512, (const void*)wblock36p_kernel<TYT, TXT>, launchw_##name},
     FPC_W36P_KINDS(X)
 #undef X
