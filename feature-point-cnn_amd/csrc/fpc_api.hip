@@ -468,6 +468,7 @@ struct fpc_ctx {
 #endif
   bool winograd_in1 = true;          // descriptor.layer_in.1 (256 ch): conv-only Winograd x2 + 1x1 (FPC_WINOGRAD_IN1=0: fused direct block)
   bool winograd_det = true;          // ... also the detector's 65-channel blocks (FPC_WINOGRAD_DET=0: direct)
+  int w36_cus = 0;                   // FPC_W36_CUS: CUs a generation-3 launch may take (0 = all): A/B knob for contexts that share the GPU
   bool w36_paired = true;            // the 64-channel F(4x4,3x3) layers on wblock36p_kernel, two waves per SIMD (FPC_PLAN_W36_ONE_WAVE / FPC_W36_PAIRED=0: wblock36_kernel<1, ..>)
   bool winograd_det_gen3 = true;     // ... on wblock36_dust_kernel in batch calls (FPC_PLAN_DETECTOR_GEN1 / FPC_WINOGRAD_DET_GEN=1: round 1's kernel)
   bool winograd = true;              // stride-1 blocks with <= 128 channels: Winograd F(2x2,3x3) (FPC_WINOGRAD=0: direct)
@@ -2424,7 +2425,8 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             // leave the other CUs to the launches of the other sub-batch's stream -- 640 tiles: 216 workgroups x 3 rounds
             // instead of 256 of which 128 idle through the third; 320 tiles: 160 x 2.
             // (a launch of gridDim.y parts shares the CUs between them: each part's tile walk gets CUs / parts)
-            const int cus8 = std::max(1, c->num_cus / 8 / std::max(1, op.grid_y)), per_xcd = (a.total + 7) / 8;
+            const int cus_cap = c->w36_cus > 0 ? std::min(c->num_cus, c->w36_cus) : c->num_cus;
+            const int cus8 = std::max(1, cus_cap / 8 / std::max(1, op.grid_y)), per_xcd = (a.total + 7) / 8;
             const int rounds = (per_xcd + cus8 - 1) / cus8;
             const int grid3 = 8 * std::min(cus8, (per_xcd + rounds - 1) / rounds);
             g_wkinds[op.wkind].launch(a, dim3(std::min(a.total, grid3), op.grid_y), sb.st);
@@ -2868,6 +2870,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->winograd_det_gen3 = !(pf & FPC_PLAN_DETECTOR_GEN1);
     c->w36_paired = !(pf & FPC_PLAN_W36_ONE_WAVE);
     if (const char* e = getenv("FPC_W36_PAIRED")) c->w36_paired = atoi(e) != 0;
+    if (const char* e = getenv("FPC_W36_CUS")) c->w36_cus = std::max(0, atoi(e));
     if (const char* e = getenv("FPC_WINOGRAD_DET_GEN")) c->winograd_det_gen3 = atoi(e) >= 3;
     c->winograd = !(pf & FPC_PLAN_NO_WINOGRAD);
     c->winograd_det = !(pf & FPC_PLAN_NO_WINOGRAD_DETECTOR);
