@@ -215,3 +215,62 @@ def test_bench_parent_reports_a_failing_rank():
     assert "a rank exited with status" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert __import__("time").time() - t0 < 120
+
+
+def test_the_blob_collective_targets_the_librarys_buffer_and_falls_back_without_a_host_hop():
+    """dist.nccl_receive_target with a stand-in engine (no GPU here; the real one is tests/test_gpu_round5.py): the tensor
+    handed to the blob collective IS the engine's packed view when one can be made (then `finish` has the library verify
+    the tag), and a torch-owned buffer handed over with import_packed_device when not (or FPC_DIST_ZERO_COPY=0) -- in
+    neither case does a receiving rank go through export_packed / import_packed (host memory)."""
+    from fpc_amd import dist as fdist
+
+    class Fake:
+        def __init__(self, n, view_ok=True):
+            self.blob = torch.zeros(n, dtype=torch.uint8)
+            self.view_ok = view_ok
+            self.calls = []
+
+        def packed_view(self):
+            if not self.view_ok:
+                raise RuntimeError("no view")
+            return self.blob
+
+        def mark_weights_loaded(self):
+            self.calls.append("mark")
+
+        def import_packed_device(self, buf):
+            self.calls.append("import_device")
+            self.blob.copy_(buf)
+
+        def export_packed(self):
+            self.calls.append("export")
+            return self.blob.numpy()
+
+        def import_packed(self, b):
+            self.calls.append("import_host")
+
+    n = 4096
+    payload = torch.arange(n, dtype=torch.int64).to(torch.uint8)
+    e = Fake(n)
+    t, fin = fdist.nccl_receive_target(e, False, n, torch.device("cpu"))
+    assert t.data_ptr() == e.blob.data_ptr()
+    t.copy_(payload)
+    fin()
+    assert e.calls == ["mark"] and torch.equal(e.blob, payload)
+    for env, view_ok in (("0", True), ("1", False)):
+        os.environ["FPC_DIST_ZERO_COPY"] = env
+        try:
+            e = Fake(n, view_ok)
+            t, fin = fdist.nccl_receive_target(e, False, n, torch.device("cpu"))
+            assert t.data_ptr() != e.blob.data_ptr() and t.numel() == n
+            t.copy_(payload)
+            fin()
+            assert e.calls == ["import_device"] and torch.equal(e.blob, payload)
+            # the source rank's fallback: its blob into the torch buffer (the one place export_packed is allowed)
+            s = Fake(n, view_ok)
+            s.blob.copy_(payload)
+            t, fin = fdist.nccl_receive_target(s, True, n, torch.device("cpu"))
+            fin()
+            assert torch.equal(t, payload) and "import_host" not in s.calls and "import_device" not in s.calls
+        finally:
+            del os.environ["FPC_DIST_ZERO_COPY"]
