@@ -2848,6 +2848,12 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
   c->cap = cfg->max_keypoints > 0 ? cfg->max_keypoints : worst;
   c->sort_cap = 1;
   while (c->sort_cap < worst) c->sort_cap <<= 1;
+  // Kernel attributes first: the process's first call loads the code object here (~150 ms), so that the stream placement
+  // below -- whose first probe launch would otherwise trigger that load -- reports its own cost (fpc_stream_report).
+  {
+    const int prc = prepare_kernels(c.get(), cfg);
+    if (prc != FPC_OK) return prc;      // (nothing to give back yet: no stream, no event, no allocation)
+  }
   // Streams: placed on hardware queues of their own (queue_map.h).  The registry's lock is held while this context's
   // streams are chosen and registered, and RELEASED before anything that can fail and call fpc_destroy (round 4 held it
   // to the end of the function: a failing build_plan then deadlocked on fpc_destroy's own lock).
@@ -2950,7 +2956,7 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - create_t0).count();
     queue_lock.unlock();
   }
-  int rc = prepare_kernels(c.get(), cfg);
+  int rc = FPC_OK;
   // (test hook: the failure path below -- streams, events, registry entries and whatever build_plan had allocated given
   // back, the error code returned -- cannot be reached on this pool's 288 GB otherwise)
   if (rc == FPC_OK && getenv("FPC_TEST_FAIL_CREATE")) {
