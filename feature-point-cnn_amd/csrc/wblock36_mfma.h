@@ -133,22 +133,40 @@ struct W36Cfg {
 //    really puts a reader there (every other MFMA of the block was issued at least 32 cycles -- one MFMA -- earlier and
 //    has all but written its result when the last one issues: 40 cycles from issue to result, 32 to the next issue
 //    plus the builtin's own issue slots -- and two s_nop cycles at the end of the asm for margin).
-template <bool AG0, bool AG1>
+// LAST_IN_ASM (round 5): the block's last MFMA inside the asm as well, no builtin.  For the 128-channel instance this is
+// 3 % in the stand-alone harness (layer2.1-like 0.2317 -> 0.2253 ms, layer_out.0-like 0.469 -> 0.452) and 1.3 % in the
+// library: with the builtin the compiler gives some results a different register than their source accumulator and
+// carries them home across the unrolled chunk pair -- 26 v_accvgpr moves and 36 s_nop per chunk, VALU slots in the MFMA
+// stream.  Safe ONLY where nothing can read an accumulator right behind a block: tests/test_static_isa.py scans the
+// shipped code object for exactly that (every instance, straight line and back edges) and is the gate for this switch.
+// NOT for wblock36p_kernel (accumulators in VGPRs: the compiler moves them around between blocks -- two of the harness's
+// seven cases computed stale values with it) nor worth it for the 64-channel one-wave instances (all 144 accumulators in
+// AGPRs, no moves to save: same time).
+template <bool AG0, bool AG1, bool LAST_IN_ASM = false>
 __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
-#define FPC_MFMA8                                                                                                      \
+#define FPC_MFMA7                                                                                                      \
   "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %14, %1\n\t"                                \
   "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"                                \
   "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"                                \
-  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\ts_nop 1"
+  "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"
+#define FPC_MFMA8 FPC_MFMA7 "v_mfma_f32_16x16x4_f32 %1, %9, %17, %1"
 #define FPC_MFMA8_IN                                                                                                   \
   "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b0[0]), "v"(b0[1]), \
       "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3])
-  if constexpr (AG0 && AG1) asm volatile(FPC_MFMA8 : "+a"(c0), "+a"(c1) : FPC_MFMA8_IN);
-  else if constexpr (AG0) asm volatile(FPC_MFMA8 : "+a"(c0), "+v"(c1) : FPC_MFMA8_IN);
-  else if constexpr (AG1) asm volatile(FPC_MFMA8 : "+v"(c0), "+a"(c1) : FPC_MFMA8_IN);
-  else asm volatile(FPC_MFMA8 : "+v"(c0), "+v"(c1) : FPC_MFMA8_IN);
-  // the LAST MFMA of the block is the compiler's own (see the header comment: it then knows the wait states)
-  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], c1, 0, 0, 0);
+  if constexpr (LAST_IN_ASM) {
+    if constexpr (AG0 && AG1) asm volatile(FPC_MFMA8 : "+a"(c0), "+a"(c1) : FPC_MFMA8_IN);
+    else if constexpr (AG0) asm volatile(FPC_MFMA8 : "+a"(c0), "+v"(c1) : FPC_MFMA8_IN);
+    else if constexpr (AG1) asm volatile(FPC_MFMA8 : "+v"(c0), "+a"(c1) : FPC_MFMA8_IN);
+    else asm volatile(FPC_MFMA8 : "+v"(c0), "+v"(c1) : FPC_MFMA8_IN);
+  } else {
+    if constexpr (AG0 && AG1) asm volatile(FPC_MFMA7 "s_nop 1" : "+a"(c0), "+a"(c1) : FPC_MFMA8_IN);
+    else if constexpr (AG0) asm volatile(FPC_MFMA7 "s_nop 1" : "+a"(c0), "+v"(c1) : FPC_MFMA8_IN);
+    else if constexpr (AG1) asm volatile(FPC_MFMA7 "s_nop 1" : "+v"(c0), "+a"(c1) : FPC_MFMA8_IN);
+    else asm volatile(FPC_MFMA7 "s_nop 1" : "+v"(c0), "+v"(c1) : FPC_MFMA8_IN);
+    // the LAST MFMA of the block is the compiler's own builtin (see the header comment: it then knows the wait states)
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], c1, 0, 0, 0);
+  }
+#undef FPC_MFMA7
 #undef FPC_MFMA8
 #undef FPC_MFMA8_IN
 }
@@ -160,7 +178,7 @@ __device__ __forceinline__ void fpc_mfma_step(f32x4& c0, f32x4& c1, const f32x4&
 #define W36_MARKER 0x7fffff00
 
 // Sixteen MFMAs as one statement -- two positions x two channel blocks, four accumulators in turn -- for the 128-channel
-// instance: half as many gaps and half as many trailing wait states per MFMA as blocks of eight.
+// instance: half as many gaps per MFMA as blocks of eight.  All sixteen in the asm (LAST_IN_ASM above: round 5).
 template <bool AG>
 __device__ __forceinline__ void fpc_mfma_step16(f32x4& c00, f32x4& c01, f32x4& c10, f32x4& c11, const f32x4& a0, const f32x4& a1,
                                                 const f32x4& b00, const f32x4& b01, const f32x4& b10, const f32x4& b11) {
@@ -173,14 +191,13 @@ __device__ __forceinline__ void fpc_mfma_step16(f32x4& c00, f32x4& c01, f32x4& c
   "v_mfma_f32_16x16x4_f32 %0, %6, %14, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %18, %1\n\t"                               \
   "v_mfma_f32_16x16x4_f32 %2, %10, %22, %2\n\tv_mfma_f32_16x16x4_f32 %3, %10, %26, %3\n\t"                             \
   "v_mfma_f32_16x16x4_f32 %0, %7, %15, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %19, %1\n\t"                               \
-  "v_mfma_f32_16x16x4_f32 %2, %11, %23, %2\n\ts_nop 1"
+  "v_mfma_f32_16x16x4_f32 %2, %11, %23, %2\n\tv_mfma_f32_16x16x4_f32 %3, %11, %27, %3"
 #define FPC_MFMA16_IN                                                                                                   \
   "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(b00[0]), "v"(b00[1]), \
       "v"(b00[2]), "v"(b00[3]), "v"(b01[0]), "v"(b01[1]), "v"(b01[2]), "v"(b01[3]), "v"(b10[0]), "v"(b10[1]), "v"(b10[2]),  \
       "v"(b10[3]), "v"(b11[0]), "v"(b11[1]), "v"(b11[2]), "v"(b11[3])
   if constexpr (AG) asm volatile(FPC_MFMA16 : "+a"(c00), "+a"(c01), "+a"(c10), "+a"(c11) : FPC_MFMA16_IN);
   else asm volatile(FPC_MFMA16 : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11) : FPC_MFMA16_IN);
-  c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b11[3], c11, 0, 0, 0);     // (the block's last MFMA: the compiler's own)
 #undef FPC_MFMA16
 #undef FPC_MFMA16_IN
 }
@@ -885,7 +902,7 @@ __device__ __forceinline__ void wblock36_body(const WBlockArgs& a) {
                 for (int q = 0; q < APB; ++q) af[(blk + 1) & 1][q] = lds4[ar + (g + u + 1) * 4 + q * 16 * row_pitch4];   // (next step; past the last one: read and dropped)
               }
               __builtin_amdgcn_sched_barrier(0);
-              if constexpr (NB == 2) fpc_mfma_step<true, true>(acc2[blk][0], acc2[blk][1], af[blk & 1][0], af[blk & 1][0], cb[u][0], cb[u][NB - 1]);
+              if constexpr (NB == 2) fpc_mfma_step<true, true, true>(acc2[blk][0], acc2[blk][1], af[blk & 1][0], af[blk & 1][0], cb[u][0], cb[u][NB - 1]);
               else fpc_mfma_step<true, true>(acc2[2 * blk][0], acc2[2 * blk + 1][0], af[blk & 1][0], af[blk & 1][APB - 1], cb[u][0], cb[u][0]);
               __builtin_amdgcn_sched_barrier(0);
             });

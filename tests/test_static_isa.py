@@ -1,7 +1,8 @@
 """Static checks on the SHIPPED gfx950 code object (CPU suite: llvm-objdump, no GPU).
 
 wblock36_mfma.h hides 7 / 15 MFMAs of every block inside one `asm volatile`; the compiler's hazard recogniser sees only
-the block's last MFMA (its own builtin).  Whether an accumulator written by an MFMA *inside* the asm is old enough when
+the block's last MFMA (its own builtin) -- and since round 5 NONE of the 16 of the 128-channel instance's blocks
+(LAST_IN_ASM: this test is the gate for that switch).  Whether an accumulator written by an MFMA *inside* the asm is old enough when
 the first non-MFMA instruction touches it rests on a timing argument (wblock36_mfma.h, fpc_mfma_step): this test turns
 that argument into a build-time fact.  It disassembles every `wblock36_kernel` instance of feature-point-cnn_amd/lib/
 libfpc.so (and of `wblock36_dust_kernel`, the same body with the detector's 65th channel) and checks
