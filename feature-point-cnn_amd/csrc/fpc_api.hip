@@ -3235,8 +3235,10 @@ int fpc_broadcast_weights(fpc_ctx* c, void* nccl_comm, int root) {
 
 int fpc_set_stream(fpc_ctx* c, void* s) {
   if (!c) return FPC_E_INVALID;
-  // the stream the ctx already runs on: nothing to do (a caller may hand its stream over before every call)
-  if ((hipStream_t)s == c->stream && !c->own_stream) return FPC_OK;
+  // the stream the ctx already runs on -- the caller's from an earlier call, or the ctx's OWN one handed back (fpc_get_stream):
+  // nothing to do, and ownership stays as it is (round 5's first form destroyed the ctx's own stream in the second case and
+  // went on with the dangling handle)
+  if ((hipStream_t)s == c->stream) return FPC_OK;
   HIPCHECK(hipSetDevice(c->cfg.device));
   std::lock_guard<std::mutex> queue_lock(qmap::state().mu);
   if (c->own_stream && c->stream) {

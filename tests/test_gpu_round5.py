@@ -142,6 +142,26 @@ def test_set_stream_is_cheap_idempotent_and_keyed_by_context():
     e0.close()
 
 
+def test_handing_the_contexts_own_stream_back_keeps_it():
+    """fpc_set_stream(ctx, fpc_get_stream(ctx)): a caller that wraps the ctx's own stream (Engine.torch_stream()) and hands it
+    back must not make the ctx destroy the stream it goes on using."""
+    import torch
+    e = engine(64, 96, 1)
+    e.load_state_dict(synth.make_state_dict(3, dustbin_bias=4.0))
+    frames = synth.make_batch(5, 1, 64, 96)
+    want = e.detect(frames)
+    own = e.torch_stream()
+    with torch.cuda.stream(own):
+        e.use_torch_stream()
+        e.use_torch_stream()
+    assert e.torch_stream().cuda_stream == own.cuda_stream
+    got = e.detect(frames)
+    np.testing.assert_array_equal(want[0][0], got[0][0])
+    np.testing.assert_array_equal(want[0][1], got[0][1])
+    assert e.stream_report()["streams"]["main"] >= 0       # still the placed, owned stream
+    e.close()
+
+
 def test_a_busy_or_capturing_caller_stream_is_left_alone():
     """fpc_set_stream never launches on a caller stream that has work in flight (no verdict: queue -3)."""
     import torch
