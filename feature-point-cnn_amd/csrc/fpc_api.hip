@@ -3550,6 +3550,10 @@ int fpc_get_points(fpc_ctx* c, const float* prob, const float* desc_nchw, int n)
   HIPCHECK(hipSetDevice(c->cfg.device));
   const int HW = c->H * c->W;
   HIPCHECK(hipMemsetAsync(c->ncand, 0, sizeof(int32_t) * c->B, c->stream));
+  // (the per-frame range words belong to the last CALL: a caller-provided map has no input frames to flag, and an earlier
+  // fpc_detect's FPC_E_NONFINITE must not come back from this call's fpc_get_counts)
+  HIPCHECK(hipMemsetAsync(c->range, 0, sizeof(uint32_t) * FPC_RANGE_WORDS * c->B, c->stream));
+  HIPCHECK(hipMemsetAsync(c->rowmax, 0, sizeof(float) * c->Hc * c->B, c->stream));
   const int per = (HW + 255) / 256;
   hipLaunchKernelGGL(threshold_kernel, dim3(per * n), dim3(256), 0, c->stream, prob, n, HW, c->cfg.conf_thresh,
                      c->nmsmap, c->cand, c->ncand);

@@ -320,6 +320,12 @@ def test_a_non_finite_pixel_is_reported_and_stays_in_its_frame():
         np.testing.assert_array_equal(clean[b][1], got[b][1])
         np.testing.assert_array_equal(clean[b][2], got[b][2])
     assert e.check_guards() == 0
+    # get_points on a caller-provided map right behind the flagged call: its counts are its own, not the flag of the call before
+    prob = e.forward(frames)[0]
+    e.detect_async(dev, n)
+    e.sync()
+    pts = e.get_points(prob)
+    assert len(pts) == n and not e.output_range(n)[2].any()
     again = e.detect(frames)
     assert not e.output_range(n)[2].any()
     for b in range(n):
