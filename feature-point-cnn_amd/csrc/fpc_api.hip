@@ -174,6 +174,11 @@ static const BKindInfo g_bkinds[BK_COUNT] = {
   X(W36P_C64_4x4, 4, 4)   \
   X(W36P_C64_2x8, 2, 8)
 
+// W36PDKIND(name, TYT, TXT): wblock36p_dust_kernel -- the paired instance + the detector's 65th channel (same dust block)
+#define FPC_W36PD_KINDS(X) \
+  X(W36PD_C65_4x4, 4, 4)   \
+  X(W36PD_C65_2x8, 2, 8)
+
 // W36DKIND(name, TYT, TXT): wblock36_dust_kernel -- the 64-channel instance + the detector's 65th channel on the VALU
 #define FPC_W36D_KINDS(X) \
   X(W36_C65_4x4, 4, 4)    \
@@ -186,6 +191,7 @@ enum WKind {
   FPC_W36_KINDS(X)
   FPC_W36D_KINDS(X)
   FPC_W36P_KINDS(X)
+  FPC_W36PD_KINDS(X)
 #undef X
       WK_COUNT
 };
@@ -239,6 +245,13 @@ FPC_W36D_KINDS(X)
   }
 FPC_W36P_KINDS(X)
 #undef X
+#define X(name, TYT, TXT)                                                                                  \
+  static void launchw_##name(const WBlockArgs& a, dim3 grid, hipStream_t st) {                            \
+    constexpr int lds = W36PCfg<TYT, TXT, true>::LDS_BYTES;                                               \
+    hipLaunchKernelGGL((wblock36p_dust_kernel<TYT, TXT>), grid, dim3(512), lds, st, a);                   \
+  }
+FPC_W36PD_KINDS(X)
+#undef X
 
 static const WKindInfo g_wkinds[WK_COUNT] = {
 #define X(name, KC, NBT, CMID)                                                                            \
@@ -265,6 +278,11 @@ static const WKindInfo g_wkinds[WK_COUNT] = {
   {#name, "wblock36p_kernel<" #TYT ", " #TXT ", 3>", 3, 16, 2, 64,                                            \
    W36PCfg<TYT, TXT>::LDS_BYTES, 4, 4 * TYT, 4 * TXT, 512, (const void*)wblock36p_kernel<TYT, TXT>, launchw_##name},
     FPC_W36P_KINDS(X)
+#undef X
+#define X(name, TYT, TXT)                                                                                 \
+  {#name, "wblock36p_dust_kernel<" #TYT ", " #TXT ", 3>", 3, 16, 2, 64,                                    \
+   W36PCfg<TYT, TXT, true>::LDS_BYTES, 4, 4 * TYT, 4 * TXT, 512, (const void*)wblock36p_dust_kernel<TYT, TXT>, launchw_##name, true},
+    FPC_W36PD_KINDS(X)
 #undef X
 };
 
@@ -304,6 +322,7 @@ static int w36_conv_part(int cout, int tiles, int cus) {
 // projection must then be a multiple of 64 channels wide, which every 64-channel layer of both networks is)
 static WKind w36_kind(int cout, int H, int W, bool paired = false) {
   const int t44 = ((H + 15) / 16) * ((W + 15) / 16), t28 = ((H + 7) / 8) * ((W + 31) / 32);
+  if (cout == 65 && paired) return t28 < t44 ? WK_W36PD_C65_2x8 : WK_W36PD_C65_4x4;
   if (cout == 65) return t28 < t44 ? WK_W36_C65_2x8 : WK_W36_C65_4x4;
   if (cout == 64 && paired) return t28 < t44 ? WK_W36P_C64_2x8 : WK_W36P_C64_4x4;
   if (cout == 64) return t28 < t44 ? WK_W36_C64_2x8 : WK_W36_C64_4x4;
@@ -1513,7 +1532,7 @@ static int build_plan(fpc_ctx* c) {
         else if (cinp % 32 == 0 && cout == 128) wk = gen == 3 ? w36_kind(128, Hx, Wx) : gen == 2 ? WK_W16_C128 : WK_W816_K32_C128;
         else if (c->winograd_det && cout == 65 && c->winograd_det_gen3 && c->winograd_gen == 3 && w36_fits(c->B, Hx, Wx, csx, csy) &&
                  (cin == 65 ? !proj : (cin == cinp && cinp % 64 == 0 && cinp <= 256)))
-          wk = w36_kind(65, Hx, Wx);
+          wk = w36_kind(65, Hx, Wx, c->w36_paired);
         else if (c->winograd_det && cinp % 32 == 0 && coutp == 72) wk = WK_W816_K32_C72;
         else if (c->winograd_det && cinp == 72 && coutp == 72) wk = WK_W816_K24_C72;
       }
@@ -1564,7 +1583,7 @@ static int build_plan(fpc_ctx* c) {
   if (c->fuse_blocks) {
     const BlockSpec bs{"detector.layer.0", BK_B620_s1_K64_C72, feat, 256, 128, 128, Hc, Wc, c->d0, 72, 65, 72, true, false};
     if (c->winograd && c->winograd_det)
-      add_wblock(c, bs, c->winograd_det_gen3 && c->winograd_gen == 3 && w36_fits(c->B, Hc, Wc, 256, 72) ? w36_kind(65, Hc, Wc) : WK_W816_K32_C72, &bo);
+      add_wblock(c, bs, c->winograd_det_gen3 && c->winograd_gen == 3 && w36_fits(c->B, Hc, Wc, 256, 72) ? w36_kind(65, Hc, Wc, c->w36_paired) : WK_W816_K32_C72, &bo);
     else add_block(c, bs, &bo);
   } else {  // detector.layer.0: the projection shortcut has K = 128 while conv2 has K = 72 (65 padded):
      // run the shortcut as its own 1x1 and add it as the residual of conv2

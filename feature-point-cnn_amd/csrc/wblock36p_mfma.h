@@ -28,9 +28,10 @@
 
 namespace fpc {
 
-template <int TYT_, int TXT_>
+template <int TYT_, int TXT_, bool DUST_ = false>
 struct W36PCfg {
   static constexpr int TYT = TYT_, TXT = TXT_;
+  static constexpr bool DUST = DUST_;
   static_assert(TYT * TXT == 16 && (TYT == 4 || TYT == 2), "16 Winograd tiles per workgroup tile: 4 x 4 or 2 x 8");
   static constexpr int NT = 512, NTH = 256, NPOS = 36, KC = 16, N = 64;
   static constexpr int TH = 4 * TYT, TW = 4 * TXT, HH = TH + 2, HW = TW + 2, NHALO = HH * HW;
@@ -42,7 +43,12 @@ struct W36PCfg {
   static constexpr int RH = N + 8;                                  // h / x staging / output row (floats)
   static constexpr int PX = TH * TW;                                // 256 pixels: the whole tile
   static constexpr int T_FLOATS = PX * RH;
-  static constexpr int LDS_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
+  static constexpr int BASE_FLOATS = (OFF_V1 + V_FLOATS) > (OFF_H0 + T_FLOATS) ? (OFF_V1 + V_FLOATS) : (OFF_H0 + T_FLOATS);
+  // DUST (the detector's 65th channel, as W36Cfg<1, .., true>): the dust block's first 448 floats as they are, UIN (2304), V of
+  // input channel 64 [36][16], M of output channel 64 [36][16], the halo of input channel 64 (one 16-byte slot per pixel)
+  static constexpr int HIT64 = (NHALO + NTH - 1) / NTH;
+  static constexpr int D_HEAD = BASE_FLOATS, D_COL = D_HEAD + 64, D_UIN = D_HEAD + 448, D_V64 = D_UIN + 2304, D_M64 = D_V64 + 576, D_H64 = D_M64 + 576;
+  static constexpr int LDS_FLOATS = DUST ? D_H64 + HIT64 * NTH * 4 : BASE_FLOATS;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static constexpr int STEPS = 9;                                   // per wave: 18 positions, two per step
@@ -53,9 +59,9 @@ struct W36PCfg {
 // RING: depth of the fragment ring in steps (3 or 9: slot indices must line up across chunks); a wave's fragments are
 // requested RING - 1 steps ahead.  Measured: 9 (a whole chunk ahead, 72 registers, 16 of them spilled) is 5-7 % SLOWER
 // than 3 (24 registers; two steps = 1 k cycles of cover with the partner's MFMAs in between)
-template <int TYT, int TXT, int RING = 3>
-__global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
-  using C = W36PCfg<TYT, TXT>;
+template <int TYT, int TXT, int RING, bool DUST>
+__device__ __forceinline__ void wblock36p_body(const WBlockArgs& a) {
+  using C = W36PCfg<TYT, TXT, DUST>;
   constexpr int TH = C::TH, TW = C::TW, HW = C::HW, HH = C::HH, HROW = C::HROW, HIT = C::HIT, NTH = C::NTH;
   constexpr int N = C::N, RH = C::RH, STEPS = C::STEPS, PX = C::PX;
   static_assert(STEPS % RING == 0 && RING >= 2, "ring slots must line up across chunks");
@@ -99,33 +105,76 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
     return __builtin_amdgcn_readfirstlane(((q.b * a.H + q.ty * TH) * a.W + q.tx * TW) * a.csx * 4);
   };
   // G waves.  Slot q = t + 256 i of G thread t (t = tid & 255): halo pixel q / 5 = (hy, hx), channel quad q % 5 (4 = the skew
-  // slot).  What depends on the thread alone is computed ONCE per launch -- hoff[i], the slot's byte offset from the tile's
-  // first pixel, and hyx[i] = hy << 16 | hx (hy = 0x7fff for a skew / padding slot: it fails every bounds test) -- and a
-  // tile costs eight VALU instructions per slot (the one-wave kernel recomputes the divisions per tile: ~60 per slot,
-  // 1.0-1.3 k cycles of a 64-channel tile's 51 k, measured).
-  int okoff[HIT], hoff[HIT], hyx[HIT];
+  // slot).  What depends on the thread alone is computed ONCE per launch -- hyx[i] = hy << 16 | c4 << 8 | hx (hy = 0x7fff for a
+  // skew / padding slot: it fails every bounds test) -- and a tile costs a dozen VALU instructions per slot (the one-wave
+  // kernel recomputes the divisions per tile: ~60 per slot, 1.0-1.3 k cycles of a 64-channel tile's 51 k, measured).
+  // (the DUST instance is short of registers -- its per-launch values were spilled and reloaded one scratch round trip at a
+  // time inside halo_tile --: it derives them from the thread id per tile instead, six more VALU per slot)
+  constexpr bool KEEP_HYX = !DUST;
+  auto slot_hyx = [&](int tl, int i) {
+    const int e = tl + i * NTH;
+    const int pix = (e * 13108) >> 16, c4 = e - pix * 5;                    // e / 5 (e < 1792)
+    const int hy = HW == 18 ? (pix * 3641) >> 16 : (pix * 1928) >> 16;     // pix / 18 (pix < 469), pix / 34 (pix < 441)
+    const int hx = pix - hy * HW;
+    const bool slot_ok = (hy < HH) & (c4 < 4);
+    return slot_ok ? (hy << 16) | (c4 << 8) | hx : 0x7fff0000;
+  };
+  int okoff[HIT];
+  [[maybe_unused]] int hyx[KEEP_HYX ? HIT : 1];
   if (hs == 1) {
     const int tl = tid & (NTH - 1);
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
-      const int e = tl + i * NTH;
-      const int pix = (e * 13108) >> 16, c4 = e - pix * 5;                    // e / 5 (e < 1792)
-      const int hy = HW == 18 ? (pix * 3641) >> 16 : (pix * 1928) >> 16;     // pix / 18 (pix < 469), pix / 34 (pix < 441)
-      const int hx = pix - hy * HW;
-      const bool slot_ok = (hy < HH) & (c4 < 4);
-      hoff[i] = (((hy - 1) * a.W + (hx - 1)) * a.csx + c4 * 4) * 4;
-      hyx[i] = slot_ok ? (hy << 16) | hx : 0x7fff0000;
+      if constexpr (KEEP_HYX) hyx[i] = slot_hyx(tl, i);
       okoff[i] = W36_MARKER;
+    }
+  }
+  // DUST: the same for input channel 64 (detector.layer.1), one 16-byte slot per halo pixel: channels 64..67
+  [[maybe_unused]] int okoff64[C::HIT64];
+  auto slot_hyx64 = [&](int tl, int i) {
+    const int pix = tl + i * NTH;
+    const int hy = HW == 18 ? (pix * 3641) >> 16 : (pix * 1928) >> 16;
+    const int hx = pix - hy * HW;
+    return (hy < HH && a.dust_in) ? (hy << 16) | hx : 0x7fff0000;
+  };
+  if constexpr (DUST) {
+    if (hs == 1) {
+#pragma unroll
+      for (int i = 0; i < C::HIT64; ++i) okoff64[i] = W36_MARKER;
     }
   }
   auto halo_tile = [&](const TilePos& q) {               // okoff[] for that tile (G waves)
     const int iy0 = q.ty * TH - 1, ix0 = q.tx * TW - 1;
     const int hlim = q.live ? a.H : 0;
+    int tlq = tid & (NTH - 1);
+    asm volatile("" : "+v"(tlq));       // (opaque per tile: computed from loop invariants, everything below is hoisted out of the tile loop -- and spilled)
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
-      const int hy = hyx[i] >> 16, hx = hyx[i] & 0xffff;
+      int hv = KEEP_HYX ? hyx[KEEP_HYX ? i : 0] : slot_hyx(tlq, i);
+      asm volatile("" : "+v"(hv));
+      const int hy = hv >> 16, hx = hv & 0xff, c4 = (hv >> 8) & 0xff;
       const bool ok = ((unsigned)(iy0 + hy) < (unsigned)hlim) & ((unsigned)(ix0 + hx) < (unsigned)a.W);
-      okoff[i] = ok ? hoff[i] : W36_MARKER;
+      okoff[i] = ok ? (((hy - 1) * a.W + (hx - 1)) * a.csx + c4 * 4) * 4 : W36_MARKER;
+    }
+    if constexpr (DUST) {
+#pragma unroll
+      for (int i = 0; i < C::HIT64; ++i) {
+        int hv = slot_hyx64(tlq, i);
+        asm volatile("" : "+v"(hv));
+        const int hy = hv >> 16, hx = hv & 0xffff;
+        const bool ok = ((unsigned)(iy0 + hy) < (unsigned)hlim) & ((unsigned)(ix0 + hx) < (unsigned)a.W);
+        okoff64[i] = ok ? (((hy - 1) * a.W + (hx - 1)) * a.csx + 64) * 4 : W36_MARKER;
+      }
+    }
+  };
+  auto load_halo64 = [&](int base) {                     // DUST, G waves: channels 64..67 of the tile's halo pixels -> D_H64 [pixel][4]
+    if constexpr (DUST) {
+#pragma unroll
+      for (int i = 0; i < C::HIT64; ++i) {
+        int voff;
+        asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(okoff64[i]), "s"(base));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(lds + C::D_H64 + (i * NTH + grp * 64) * 4), 16, voff, 0, 0, 0);
+      }
     }
   };
   auto load_halo = [&](int base, int hoff_f) {            // G waves: base = halo_base of the tile + 64 bytes per chunk; hoff_f: the halo buffer (floats)
@@ -188,11 +237,28 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
     return r;
   };
 
+  // ---------------------------------------------------------------- DUST: the 65th output (and input) channel beside the 64 on the MFMAs
+  // As in wblock36_dust_kernel: output channel 64 of the 3x3 is a dot product per (position, Winograd tile) and chunk in
+  // the Winograd domain, on the VALU.  Here the G waves do it (the T waves have the transform): G wave g takes positions
+  // g, g + 4, ..., g + 32; its lane l reads float4 l of a position's V block and keeps one partial sum per position.
+  [[maybe_unused]] int d_va = 0, d_ua = 0;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t drsrc =
+      DUST ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dust + W36Dust::UOUT), 0, nchunk * 36 * 16 * 4, 0x00020000) : xrsrc;
+  [[maybe_unused]] f32x4 du[6];      // two batches of three filter quads (a third of a chunk's nine at a time)
+  [[maybe_unused]] float dacc[9];
+  if constexpr (DUST) {
+    d_va = grp * 64 + lane;
+    d_ua = grp * 64 + 16 * ((lane & 3) ^ (2 * (lane >> 5)));
+    for (int i = tid; i < 448 / 4; i += C::NT) lds4[C::D_HEAD / 4 + i] = reinterpret_cast<const f32x4*>(a.dust)[i];
+    for (int i = tid; i < 2304 / 4; i += C::NT) lds4[C::D_UIN / 4 + i] = reinterpret_cast<const f32x4*>(a.dust + W36Dust::UIN)[i];
+  }
+
   // ---------------------------------------------------------------- pipeline fill for the first tile
   TilePos pos_cur = tile_pos(wg_first);
   int base_cur = halo_base(pos_cur);
   if (hs == 1) {
     halo_tile(pos_cur);
+    load_halo64(base_cur);
     load_halo(base_cur, C::OFF_H0);
     load_halo(base_cur + 64, C::OFF_H1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HIT) : "memory");      // chunk 0 has landed (this wave's part of it)
@@ -233,6 +299,12 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
 #pragma unroll
       for (int p = 0; p < 18; ++p) acc[p] = f32x4{zf, zf, zf, zf};
     }
+    if constexpr (DUST) {
+      float zf = 0.f;
+      asm volatile("" : "+v"(zf));
+#pragma unroll
+      for (int i = 0; i < 9; ++i) dacc[i] = zf;
+    }
     // (ring filled per tile; kept alive ACROSS tiles -- the last chunk requesting the next tile's first fragments -- it
     // measured the same time at 16 more registers: the fill's L2 round trip hides under the partner wave)
     BF bq[RING];
@@ -252,6 +324,9 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
       const int l_base = (nxt ? base_next : base_cur) + (nxt ? c3 - nchunk : c3) * 64;
       int ao = aoff4 + VB_OFF / 4, trd_c = trd + HN_OFF, twr_c = twr + VN_OFF;
       asm volatile("" : "+v"(ao), "+v"(trd_c), "+v"(twr_c));
+      [[maybe_unused]] int dva = d_va + VB_OFF / 4;      // DUST: this lane's float4 of position g, this chunk's buffer
+      [[maybe_unused]] f32x4 dv[3];
+      if constexpr (DUST) asm volatile("" : "+v"(dva));
       f32x4 ac[2][2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) ac[0][q] = lds4[ao + q * 64];
@@ -275,6 +350,32 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
             if (slot == 1) {
               if (c3 == nchunk) halo_tile(pos_next);      // (uniform; no memory operation inside)
               load_halo(l_base, HS_OFF);
+            }
+            if constexpr (DUST) {
+              // output channel 64: the chunk's nine filter quads requested early, the V quads read three positions at a time
+              // and multiplied two slots later
+              auto dread = [&](int i0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dv[k] = lds4[dva + (i0 + k) * 256];
+              };
+              auto dfma = [&](int i0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) dacc[i0 + k] = __builtin_fmaf(dv[k][e], du[(i0 / 3 % 2) * 3 + k][e], dacc[i0 + k]);
+              };
+              auto dload = [&](int i0) {      // three filter quads, ten slots (2.5 steps) ahead of their use
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  du[(i0 / 3 % 2) * 3 + k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_ua + (i0 + k) * 256, c * (36 * 16 * 4), 0));
+              };
+              if (slot == 3) dload(0);
+              else if (slot == 11) dread(0);
+              else if (slot == 13) { dfma(0); dload(3); }
+              else if (slot == 21) dread(3);
+              else if (slot == 23) { dfma(3); dload(6); }
+              else if (slot == 31) dread(6);
+              else if (slot == 33) dfma(6);
             }
           } else {
             if (slot >= 2 && slot < 14) {
@@ -318,11 +419,65 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
     if (wg == wg_stamp) { FPC_STAMP(1) }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMA results read by the VALU below)
 
-    // ---------------------------------------------------------------- output transform: each wave its three rows of M, joined in place in h
     int tid_t = tid;
     asm volatile("" : "+v"(tid_t));
     const int lane_t = tid_t & 63, n16 = lane_t & 15, kq = lane_t >> 4;
     const bool proj = a.k8_x > 0;
+    if constexpr (DUST) {
+      if (a.dust_in) {
+        // INPUT channel 64 (detector.layer.1): its halo arrived at the tile's start (D_H64, 16 bytes per pixel); threads
+        // 0..15 transform the 6x6 patch of one Winograd tile each into V64 [position][row m] ...
+        if (tid_t < 16) {
+          const int rd = C::D_H64 + ((4 * (tid_t / TXT)) * HW + 4 * (tid_t % TXT)) * 4;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) tp[i][j >> 1][j & 1] = lds[rd + (i * HW + j) * 4];
+          t_burst();
+          const int mrow = ((tid_t & 7) >> 1) * 4 + (tid_t >> 3) * 2 + (tid_t & 1);
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) lds[C::D_V64 + (i * 6 + j) * 16 + mrow] = tp[2 * (i >> 1) + (j & 1)][j >> 1][i & 1];
+        }
+        FPC_LDS_BARRIER();
+        // ... and every wave adds its channel group's share at its 18 positions: ONE MFMA per position, K = 4 of which
+        // k = 0 is real (the A operand of lanes 16..63 is zero); all 36 operands first, then the MFMAs back to back
+        {
+          const int va = C::D_V64 + hs * 18 * 16 + (lane_t & 15), ub = C::D_UIN + grp * 576 + hs * 18 * 16 + (lane_t & 15);
+          float av[18], bv[18];
+#pragma unroll
+          for (int p = 0; p < 18; ++p) {
+            av[p] = lds[va + p * 16];
+            bv[p] = lds[ub + p * 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 18; ++p) {
+            const float x = lane_t < 16 ? av[p] : 0.f;
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, bv[p], acc[p], 0, 0, 0);
+          }
+        }
+      }
+      if (hs == 1) {
+        // (G waves) the four lanes of a V row add their partial sums up; lane 0 of the row adds input channel 64's share
+        // (in 64 -> out 64) and writes M64[position][m]
+        const int m_d = lane_t >> 2;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          float v = dacc[i];
+          v += __shfl_xor(v, 1);
+          v += __shfl_xor(v, 2);
+          const int pos = grp + 4 * i;
+          if (a.dust_in) v = __builtin_fmaf(lds[C::D_V64 + pos * 16 + m_d], lds[C::D_HEAD + W36Dust::UIN64 + pos], v);
+          if ((lane_t & 3) == 0) lds[C::D_M64 + pos * 16 + m_d] = v;
+        }
+      }
+      FPC_LDS_BARRIER();
+      if (hs == 1) load_halo64(base_next);      // D_H64 has been read: the next tile's input channel 64 (okoff64 is the next tile's by now)
+    }
+
+    // ---------------------------------------------------------------- output transform: each wave its three rows of M, joined in place in h
     // h position of (row r of this lane's accumulators -> Winograd tile T = 8 (r >> 1) + 2 kq + (r & 1), pixel (0, 0), this lane's channel)
     int hw_base[4];
 #pragma unroll
@@ -405,6 +560,40 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) lds[hw_base[2 * role + e] + (i * TW + jj) * RH] = hv[e][i * 4 + jj];
+        if constexpr (DUST && role == 0) {
+          if (tid_t < 16) {
+            // Y = A^T M A + bias, ReLU for output channel 64 of Winograd tile T(m), m = tid -> h[..][64] (here, with the
+            // other channels' h: the hand-over buffer this region held has been read)
+            float mm[36];
+#pragma unroll
+            for (int p = 0; p < 36; ++p) mm[p] = lds[C::D_M64 + p * 16 + tid_t];
+            const float bias64 = lds[C::D_HEAD + W36Dust::B1];
+            float tt[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              const float m0 = mm[0 * 6 + j], m1 = mm[1 * 6 + j], m2 = mm[2 * 6 + j], m3 = mm[3 * 6 + j], m4 = mm[4 * 6 + j], m5 = mm[5 * 6 + j];
+              const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+              tt[0][j] = m0 + s12 + s34;
+              tt[1][j] = __builtin_fmaf(2.f, d34, d12);
+              tt[2][j] = __builtin_fmaf(4.f, s34, s12);
+              tt[3][j] = __builtin_fmaf(8.f, d34, d12) + m5;
+            }
+            const int T = 8 * ((tid_t >> 1) & 1) + 2 * (tid_t >> 2) + (tid_t & 1);
+            const int hb = C::OFF_H0 + ((4 * (T / TXT)) * TW + 4 * (T % TXT)) * RH + 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float m0 = tt[i][0], m1 = tt[i][1], m2 = tt[i][2], m3 = tt[i][3], m4 = tt[i][4], m5 = tt[i][5];
+              const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+              float yv64[4];
+              yv64[0] = m0 + s12 + s34 + bias64;
+              yv64[1] = __builtin_fmaf(2.f, d34, d12) + bias64;
+              yv64[2] = __builtin_fmaf(4.f, s34, s12) + bias64;
+              yv64[3] = __builtin_fmaf(8.f, d34, d12) + m5 + bias64;
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) lds[hb + (i * TW + jj) * RH] = yv64[jj] > 0.f ? yv64[jj] : 0.f;
+            }
+          }
+        }
       }
       FPC_LDS_BARRIER();
     };
@@ -450,6 +639,38 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
       // ------------------------------------------------ phase 2: 1x1 over h (+ projection over x): eight pixel blocks of this wave's channel group
       f32x4 acc2[8];
       const int pb = hs;                          // pixel blocks 8 pb .. 8 pb + 7 (pixels 128 pb .. + 127)
+      // DUST: output channel 64 of the tile's 256 pixels.  Lane (pxl = l >> 4, q = l & 15) of wave w takes float4 q of the rows
+      // of pixels 32 w + 4 it + pxl, it = 0..7: a partial dot product per pixel over h here and over the projection's x in
+      // its passes below, added up across the 16 lanes in the epilogue.  And h[64]'s share of outputs 0..63 is the INITIAL
+      // VALUE of their accumulators.
+      [[maybe_unused]] float dpart[8];
+      [[maybe_unused]] float dw2r = 0.f;
+      [[maybe_unused]] float dhv[8][4];
+      [[maybe_unused]] const int dq = lane_t & 15, dpxl = lane_t >> 4;
+      [[maybe_unused]] float dx64 = 0.f;      // identity shortcut: x[px][64] of the pixel this lane stores
+      if constexpr (DUST) {
+        if (!proj) {
+          const int px = 32 * wave + 4 * (dq >> 1) + dpxl;
+          dx64 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (((px / TW) * a.W + px % TW) * a.csx + 64) * 4, xbase, 0));
+        }
+        const f32x4 wq = lds4[C::D_COL / 4 + dq];
+        const float w64 = dq == 0 ? lds[C::D_COL + 64] : 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int px = 32 * wave + 4 * it + dpxl;
+          const f32x4 hq = lds4[TL4 + px * (RH / 4) + dq];
+          const float h64 = lds[C::OFF_H0 + px * RH + 64];
+          float v = h64 * w64;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v = __builtin_fmaf(hq[e], wq[e], v);
+          dpart[it] = v;
+        }
+        dw2r = lds[C::D_HEAD + W36Dust::W2ROW + 16 * grp + n16];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhv[mb][r] = lds[C::OFF_H0 + (128 * pb + 16 * mb + 4 * kq + r) * RH + 64];
+      }
       auto ldb2 = [&](int s) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, (int)w2lane, s * 1024, 0));
       };
@@ -504,6 +725,12 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
           asm volatile("" : "+v"(zf));
 #pragma unroll
           for (int mb = 0; mb < 8; ++mb) acc2[mb] = f32x4{zf, zf, zf, zf};
+          if constexpr (DUST) {
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc2[mb][r] = dhv[mb][r] * dw2r;
+          }
         }
         gemm_over(KH, 0);
         if (wg == wg_stamp) { FPC_STAMP(3) }
@@ -518,6 +745,18 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
           }
           FPC_LDS_BARRIER();
           if (pass + 1 < npass) load_x(pass + 1);
+          if constexpr (DUST) {      // this pass's 64 channels of x against the projection's column for output 64
+            const f32x4 wa = lds4[C::D_COL / 4 + 20 + pass * 16 + dq];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const int px = 32 * wave + 4 * it + dpxl;
+              const f32x4 xa = lds4[TL4 + px * (RH / 4) + dq];
+              float v = dpart[it];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v = __builtin_fmaf(xa[e], wa[e], v);
+              dpart[it] = v;
+            }
+          }
           const int steps = min(4, a.k8_x / 2 - pass * 4);   // 16-channel steps of this pass: 4 (Cin is a multiple of 64 here)
           gemm_over(steps, KH + pass * 4);
         }
@@ -534,6 +773,12 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
             const int so = xbase + ((mbg / BPR) * a.W + (mbg % BPR) * 16 + r) * a.csx * 4;
             acc2[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xl, so, 0));
           }
+        if constexpr (DUST) {
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[mb][r] = __builtin_fmaf(dhv[mb][r], dw2r, acc2[mb][r]);
+        }
         gemm_over(KH, 0);
         if (wg == wg_stamp) { FPC_STAMP(3) }
       }
@@ -553,12 +798,46 @@ __global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
       }
       FPC_LDS_BARRIER();
       store_out();
+      if constexpr (DUST) {
+        // channels 64..71 of the pixel: (out[64], 0, 0, 0) from the pair's first thread, zeros from the second (pad channels
+        // are exact zeros: the next layer's 16-byte slot of input channel 64 relies on it).  The 16 lanes of a pixel add up
+        // in a halving butterfly (4 + 2 + 1 + 1 exchanges) that ends with the total of pixel it = q >> 1 in both lanes q & 1.
+        const bool b3 = (dq & 8) != 0, b2 = (dq & 4) != 0, b1 = (dq & 2) != 0;
+        float r1[4], r2[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r1[k] = (b3 ? dpart[4 + k] : dpart[k]) + __shfl_xor(b3 ? dpart[k] : dpart[4 + k], 8);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) r2[k] = (b2 ? r1[2 + k] : r1[k]) + __shfl_xor(b2 ? r1[k] : r1[2 + k], 4);
+        float tot = (b1 ? r2[1] : r2[0]) + __shfl_xor(b1 ? r2[0] : r2[1], 2);
+        tot += __shfl_xor(tot, 1);
+        const int dpx = 32 * wave + 4 * (dq >> 1) + dpxl, dhf = dq & 1, drow = dpx / TW, dcol = dpx % TW;
+        tot += dx64 + lds[C::D_HEAD + W36Dust::B2];
+        tot = tot > 0.f ? tot : 0.f;
+        const bool ok = (drow < rows_valid) & (x0 + dcol < a.W);
+        const int doff = ok ? ((drow * a.W + dcol) * a.cso + 64 + 4 * dhf) * 4 : W36_MARKER;
+        int voff;
+        asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(doff), "s"(obase));
+        const f32x4 v = {dhf ? 0.f : tot, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), orsrc, voff, 0, 0);
+      }
       if (wg == wg_stamp) { FPC_STAMP(5) FPC_RSTAMP(7) }
       FPC_LDS_BARRIER();   // the region is reused by the next tile's pipeline
     }
     pos_cur = pos_next;
     base_cur = base_next;
   }  // persistent tile loop
+}
+
+template <int TYT, int TXT, int RING = 3>
+__global__ __launch_bounds__(512, 1) void wblock36p_kernel(const WBlockArgs a) {
+  wblock36p_body<TYT, TXT, RING, false>(a);
+}
+
+// The detector's blocks at two waves per SIMD: 64 channels as wblock36p_kernel + the 65th ("dustbin") channel beside them
+// (W36Dust, wblock36_mfma.h), as wblock36_dust_kernel does for the one-wave instance.
+template <int TYT, int TXT, int RING = 3>
+__global__ __launch_bounds__(512, 1) void wblock36p_dust_kernel(const WBlockArgs a) {
+  wblock36p_body<TYT, TXT, RING, true>(a);
 }
 
 }  // namespace fpc

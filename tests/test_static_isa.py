@@ -46,6 +46,11 @@ SPILLS = {
     # named anywhere -- with one, the compiler splits the wave's 256 registers 128 / 128 and spills 137)
     ("p", 4, 4): (48, 0, 0),
     ("p", 2, 8): (48, 0, 0),
+    # wblock36p_dust_kernel<TYT, TXT, RING> (round 5: the paired instance + the detector's 65th channel): the only instance
+    # with anything in scratch -- 7 / 9 registers saved around a role's chunk loop, once per TILE (checked below: nothing of
+    # it inside a chunk loop)
+    ("p", 4, 4, "dust"): (144, 12, 48),
+    ("p", 2, 8, "dust"): (144, 12, 48),
 }
 
 
@@ -96,6 +101,9 @@ def _instances(funcs):
         m = re.match(r"_ZN3fpc16wblock36p_kernelILi(\d+)ELi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
         if m:
             out[("p",) + tuple(int(v) for v in m.groups()[:2])] = name
+        m = re.match(r"_ZN3fpc21wblock36p_dust_kernelILi(\d+)ELi(\d+)ELi(\d+)EEEvNS_10WBlockArgsE$", name)
+        if m:
+            out[("p",) + tuple(int(v) for v in m.groups()[:2]) + ("dust",)] = name
     return out
 
 
@@ -242,7 +250,7 @@ def test_spills_are_what_design_md_says_and_outside_the_chunk_loop(code_object):
         assert m["private_segment_fixed_size"] <= p_max, (key, m)
         body = funcs[name]
         n_scratch = sum(1 for _, i in body if i.startswith("scratch_"))
-        assert n_scratch <= (0 if v_max == 0 else 12), (key, n_scratch)
+        assert n_scratch <= (0 if v_max == 0 else 12 if key[0] != "p" else 40), (key, n_scratch)
         loop = _chunk_loop(body)
         assert loop is not None, key
         head, tail, n_mfma = loop
@@ -252,7 +260,19 @@ def test_spills_are_what_design_md_says_and_outside_the_chunk_loop(code_object):
         if key[0] == "p":
             assert m["agpr_count"] == 0 and m["vgpr_count"] <= 256, (key, m)
         inside = [i for _, i in body[head:tail] if i.startswith(("v_readlane", "v_writelane", "scratch_"))]
-        if "dust" in key:
+        if key[0] == "p":
+            # BOTH role loops (the transforming waves' and the requesting waves'): every innermost loop of 144 MFMAs
+            edges = _back_edges(body)
+            loops = [(h, k) for h, k in edges
+                     if sum(1 for _, i in body[h:k] if i.startswith("v_mfma")) == 144
+                     and not any(h2 >= h and k2 <= k and (h2, k2) != (h, k) and
+                                 sum(1 for _, i in body[h2:k2] if i.startswith("v_mfma")) for h2, k2 in edges)]
+            assert len(loops) == 2, (key, loops)
+            for h, k in loops:
+                assert not [i for _, i in body[h:k] if i.startswith("scratch_")], (key, h, k)
+        if "dust" in key and key[0] == "p":
+            assert not [i for i in inside if i.startswith("scratch_")], (key, inside[:5])
+        elif "dust" in key:
             # the dust instance reloads the LDS-DMA's M0 values (the halo request's VALU burst, once per chunk) from spilled
             # SGPRs: a dozen v_readlane in 288 MFMAs' worth of loop, no v_writelane, nothing in scratch
             assert len(inside) <= 12 and all(i.startswith("v_readlane") for i in inside), (key, inside[:5])
