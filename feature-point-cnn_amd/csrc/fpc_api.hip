@@ -22,6 +22,7 @@
 #include "../../include/fpc.h"
 #include "block_mfma.h"
 #include "block_bf16.h"
+#include "convt_bf16.h"
 #include "block_x3.h"
 #include "stem_bf16.h"
 #include "wblock_mfma.h"
@@ -341,6 +342,7 @@ static WKind w36_kind(int cout, int H, int W, bool paired = false) {
   X(F320_s2_K128_C256, block_bf16_one_kernel, BlockBfCfg, 1, 3, 20, 2, 3, 128, 1, 4, 2, 2, 256) \
   X(F416_s1_K128_C256, block_bf16_two_kernel, BlockBfCfg, 1, 4, 16, 1, 3, 128, 1, 4, 2, 2, 256) \
   X(F816_ct_K64_C128, block_bf16_kernel, BlockBfCfg, 1, 8, 16, 1, 2, 64, 1, 4, 4, 1, 128)   \
+  X(F816_ctf_K64_C128, convt_bf16_kernel, ConvTBfCfg, 1, 8, 16, 1, 2, 64, 2, 2, 2, 1, 128)  \
   X(S816_s1_K64_C64, block_x3_kernel, BlockX3Cfg, 3, 8, 16, 1, 3, 64, 2, 2, 2, 1, 64)       \
   X(S620_s2_K16_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 2, 3, 16, 2, 2, 2, 2, 128)     \
   X(S620_s1_K64_C128, block_x3_kernel, BlockX3Cfg, 3, 6, 20, 1, 3, 64, 2, 2, 2, 2, 128)     \
@@ -476,6 +478,7 @@ struct fpc_ctx {
   bool xcd_order = true;             // FPC_XCD_ORDER=0: plain tile order in the persistent Winograd kernel
   int nms_passes = 2;
   bool fuse_softmax = true;        // !FPC_PLAN_NO_FUSED_SOFTMAX (FPC_BF16's detector.layer.1, block_bf16.h)
+  bool convt_fused = true;         // !FPC_PLAN_CONVT_PHASES (FPC_BF16's ConvTranspose as ONE launch, convt_bf16.h)
   bool logits_valid = false;       // the last call wrote the logits ("det.1" of fpc_read_activation): false after a fused-softmax fpc_detect
   bool nms_one_workgroup = false;  // FPC_PLAN_NMS_ONE_WORKGROUP: round 1's sort (one workgroup per frame) for every frame
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
@@ -1047,6 +1050,53 @@ static void add_fconvT(fpc_ctx* c, FKind kind, const void* x, int csx, int cin, 
   if (kind >= FK_COUNT) { c->plan_error = true; return; }
   const FKindInfo& k = g_fkinds[kind];
   const int nbt = k.WN * k.NB, K16 = k.KC / 16;
+  if (strstr(k.symbol, "convt_bf16_kernel")) {
+    // round 5: ONE launch (convt_bf16.h) -- a workgroup stages a tile's halo chunk once and issues all nine taps on it, the
+    // four parities' accumulators side by side; gridDim.y = the output-channel parts
+    if (cin % k.KC != 0 || cout != k.CMIDP) { c->plan_error = true; return; }
+    Op op;
+    op.type = OP_BF16;
+    op.name = "descriptor.up_sample+bn+relu [bf16, four parities in one launch]";
+    op.prefix = "descriptor.up_sample";
+    op.fkind = kind;
+    op.phase = 4;   // all four
+    op.cin = cin;
+    op.cout = cout;
+    op.descriptor_branch = true;
+    op.grid_y = k.CMIDP / (k.WN * 32);
+    BlockBfArgs& a = op.fargs;
+    a.x = x;
+    a.csx = csx;
+    a.in_f32 = 0;
+    a.x_bytes = (unsigned)std::min<size_t>((size_t)c->B * H * W * csx * 2, 0xffffff00u);
+    a.nchunk = cin / k.KC;
+    a.H = H;
+    a.W = W;
+    a.pad = 0;
+    a.ntaps = 9;
+    a.conv_only = 1;
+    a.out = out;
+    a.cso = cso;
+    a.out_f32 = 0;
+    a.Ho = H;
+    a.Wo = W;
+    a.OH = 2 * H;
+    a.OW = 2 * W;
+    a.oys = a.oxs = 2;
+    a.tiles_x = (W + k.TW - 1) / k.TW;
+    a.tiles_y = (H + k.TH - 1) / k.TH;
+    fpc_ctx::ConvW cw;
+    cw.w_off[0] = *blob_off;
+    *blob_off += ((size_t)(cin / 16) * 9 + 2) * (k.CMIDP / 32) * 64 * 4;   // pack_conv_bf16 with KC = 16: [step of 16 channels][tap][32-channel block][lane]
+    cw.b_off = *blob_off;
+    *blob_off += (size_t)k.CMIDP;
+    op.flops_per_frame = 2.0 * 9 * H * W * cin * cout;
+    op.mfma_flops_per_frame = 2.0 * 9 * a.tiles_x * a.tiles_y * (k.TH * k.TW) * (double)cin * k.CMIDP;
+    op.bytes_per_frame = 2.0 * ((double)cin * H * W + 4.0 * cout * H * W);
+    c->ops.push_back(op);
+    c->convw.push_back(cw);
+    return;
+  }
   const int HWp = k.planes == 1 ? bf_halo_pitch(k.TH, k.TW, k.S, k.EXT) : (k.TW - 1) * k.S + k.EXT, ROW16 = k.KC / 8 + 1;
   for (int ph = 0; ph < 4; ++ph) {
     const int py = ph >> 1, px = ph & 1;
@@ -1131,7 +1181,7 @@ static void build_bf16_ops(fpc_ctx* c, size_t* bo) {
   if (de) {
     add_fblock(c, {"descriptor.layer_in.0", FK_F320_s2_K128_C256, feat, 256, 0, 128, 128, Hc, Wc, c->y16a, 256, 0, 256, true, true}, bo);
     add_fblock(c, {"descriptor.layer_in.1", FK_F416_s1_K128_C256, c->y16a, 256, 0, 256, 256, H16, W16, c->y16b, 256, 0, 256, false, true}, bo);
-    add_fconvT(c, FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
+    add_fconvT(c, c->convt_fused ? FK_F816_ctf_K64_C128 : FK_F816_ct_K64_C128, c->y16b, 256, 256, H16, W16, c->cat, 256, 128, bo);
     add_fblock(c, {"descriptor.layer_out.0", FK_F816_s1_K64_C128, c->cat, 256, 0, 256, 256, Hc, Wc, c->lo0, 128, 0, 128, true, true}, bo);
     // (the descriptor map is bf16 as well -- round 3: descriptor16_kernel<8, true> reads it, fpc_forward / the tap convert it)
     add_fblock(c, {"descriptor.layer_out.1", FK_F816_s1_K128_C128, c->lo0, 128, 0, 128, 128, Hc, Wc, c->desc_map, 128, 0, 128, false, true}, bo);
@@ -2099,6 +2149,15 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
         const float* bct = need("descriptor.up_sample.bias", {128});
         Fold f;
         if (!w || !bct || !fold_bn(m, "descriptor.bn", 128, &f, missing)) return FPC_E_MISSING_KEY;
+        if (op.phase == 4) {   // convt_bf16_kernel: all nine taps per step of 16 channels, in ConvTTaps' order
+          PackSource s{ci, ci, 9,
+                       [&](int n, int cc, int t) { return (double)w[((cc * 128 + n) * 3 + ConvTTaps::ky(t)) * 3 + ConvTTaps::kx(t)]; },
+                       &f.s};
+          std::vector<float> frag = pack_conv_bf16({s}, co, k.CMIDP / 32, 16, 1, &range_bad);
+          memcpy(blob.data() + cw.w_off[0], frag.data(), frag.size() * sizeof(float));
+          for (int n = 0; n < co; ++n) blob[cw.b_off + n] = (float)((double)bct[n] * f.s[n] + f.t[n]);
+          continue;
+        }
         const int py = op.phase >> 1, px = op.phase & 1;
         std::vector<std::pair<int, int>> taps;  // (ky, kx) in the order add_fconvT laid the taps out
         for (int iy = 0; iy < (py ? 2 : 1); ++iy)
@@ -2498,8 +2557,9 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
             a.cand = c->cand + f0 * HW;
             a.ncand = c->ncand + f0;
           }
-          const int g = std::min((a.total_tiles + 7) / 8 * 8, std::max(8, c->fkind_blocks_per_cu[op.fkind] * c->num_cus / 8 * 8));
-          g_fkinds[op.fkind].launch(a, dim3(g), sb.st);
+          // (op.grid_y parts -- convt_bf16_kernel's output-channel halves -- share the CUs)
+          const int g = std::min((a.total_tiles + 7) / 8 * 8, std::max(8, c->fkind_blocks_per_cu[op.fkind] * c->num_cus / op.grid_y / 8 * 8));
+          g_fkinds[op.fkind].launch(a, dim3(g, op.grid_y), sb.st);
         } else {
           g_fkinds[op.fkind].launch(a, dim3(a.tiles_x * a.tiles_y * n), sb.st);
         }
@@ -2913,6 +2973,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->latency_tiles = !(pf & FPC_PLAN_NO_LATENCY_TILES);
     if (const char* e = getenv("FPC_LATENCY_TILES")) c->latency_tiles = atoi(e) != 0;
     c->fuse_softmax = !(pf & FPC_PLAN_NO_FUSED_SOFTMAX);
+    c->convt_fused = !(pf & FPC_PLAN_CONVT_PHASES);
+    if (const char* e = getenv("FPC_CONVT_FUSED")) c->convt_fused = atoi(e) != 0;
     if (const char* e = getenv("FPC_FUSE_SOFTMAX")) c->fuse_softmax = atoi(e) != 0;
     c->nms_one_workgroup = (pf & FPC_PLAN_NMS_ONE_WORKGROUP) != 0;
     if (const char* e = getenv("FPC_NMS_CHUNKED")) c->nms_one_workgroup = atoi(e) == 0;

@@ -134,6 +134,7 @@ enum {
   FPC_PLAN_HEADS_IN_LINE = 1 << 17,        /* ... and its opt-out: the two heads of a sub-batch back to back on its stream  (FPC_SPLIT_HEADS=0) */
   FPC_PLAN_DETECTOR_GEN1 = 1 << 16,        /* the detector's 65-channel blocks on round 1's kernel in batch calls too       (FPC_WINOGRAD_DET_GEN=1) */
   FPC_PLAN_W36_ONE_WAVE = 1 << 18,         /* the 64-channel F(4x4,3x3) layers on round 3's one-wave-per-SIMD kernel instead of round 5's two  (FPC_W36_PAIRED=0) */
+  FPC_PLAN_CONVT_PHASES = 1 << 19,         /* FPC_BF16: the ConvTranspose as four output-parity launches (rounds 2-4) instead of round 5's one  (FPC_CONVT_FUSED=0) */
   FPC_PLAN_GUARD_ZONES = 1 << 15           /* TEST FACILITY: 64 KiB of a canary pattern behind every buffer of the workspace and
                                               2 GiB behind the last one (the workspace grows by that much); fpc_check_guards
                                               counts the words a kernel has overwritten.  Not for production contexts.          */
