@@ -483,6 +483,8 @@ struct fpc_ctx {
   bool nms_one_workgroup = false;  // FPC_PLAN_NMS_ONE_WORKGROUP: round 1's sort (one workgroup per frame) for every frame
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
+  bool stem_lean = true;             // ... on stem_pool2_kernel where the conv map is whole 16 x 16 tiles (FPC_PLAN_STEM_ROUND3 / FPC_STEM_LEAN=0: stem_pool_kernel)
+  bool stem2 = false;                // decided in fpc_create: stem_lean, fp32 MFMA mode, fused stem + pool, whole tiles -- the fragments then carry the bias (stem_pair2)
   bool layer1_t816 = false;          // direct (non-Winograd) layer1 blocks on 8x16 tiles instead of 16x16
 #ifdef FPC_DIAG
   unsigned long long* diag_stamps = nullptr;
@@ -1795,6 +1797,9 @@ postproc:
   c->stem.H = H; c->stem.W = W; c->stem.Ho = H2; c->stem.Wo = W2;
   c->stem.tiles_x = (W2 + STEM_T - 1) / STEM_T;
   c->stem.tiles_y = (H2 + STEM_T - 1) / STEM_T;
+  // round 5: the fp32 stem + pool on stem_pool2_kernel where the conv map is whole tiles (VGA, HD; QVGA's 120 rows are
+  // not): its fragments carry the bias as a K step, so the choice is part of the packed layout (plan_hash)
+  c->stem2 = c->stem_lean && !c->bf16 && !c->split && !c->vgg && (c->fuse_stem_pool || c->cin == 1) && H2 % STEM_T == 0 && W2 % STEM_T == 0;
   return FPC_OK;
 }
 
@@ -1812,7 +1817,7 @@ static uint64_t plan_hash(const fpc_ctx* c) {
   };
   mix(FPC_ABI_VERSION); mix(FPC_PACK_LAYOUT_REVISION); mix((uint64_t)c->cfg.dtype); mix((uint64_t)c->cfg.arch); mix((uint64_t)c->cin);
   mix((uint64_t)(c->cfg.descriptor_enabled != 0)); mix(c->blob_floats); mix(c->stem_w_off); mix(c->stem_b_off);
-  mix(c->vconv0_off);
+  mix(c->vconv0_off); mix((uint64_t)c->stem2);
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
     mix((uint64_t)op.type); mix((uint64_t)op.kind); mix((uint64_t)op.bkind); mix((uint64_t)op.wkind); mix((uint64_t)op.fkind);
@@ -2021,8 +2026,12 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
       for (int nb = 0; nb < 2; ++nb)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 4; ++j) {
-            const StemPair sp = stem_pair(c->cin, g * 4 + j);      // the kernels' K order (kernels_misc.h)
+            const StemPair sp = c->stem2 ? stem_pair2(c->cin, g * 4 + j) : stem_pair(c->cin, g * 4 + j);      // the kernels' K order (kernels_misc.h)
             const int k = (lane >> 5) ? sp.wb : sp.wa, n = nb * 32 + (lane & 31);
+            if (k == STEM_BIAS_TAP) {   // stem_pool2_kernel: the folded-BN bias as a K step (A operand 1.0)
+              dst[(((size_t)g * 2 + nb) * 64 + lane) * 4 + j] = (float)f.t[n];
+              continue;
+            }
             double v = 0.0;
             if (k >= 0 && k < kreal) {
               if (c->cin == 3) v = (double)w[n * 147 + k];
@@ -2439,6 +2448,9 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
               if (c->cin == 1) hipLaunchKernelGGL((stem_pool_x3_kernel<1, 3>), grid, dim3(256), 0, sb.st, x);
               else hipLaunchKernelGGL((stem_pool_x3_kernel<3, 3>), grid, dim3(256), 0, sb.st, x);
             }
+          } else if (c->stem2) {
+            if (c->cin == 1) hipLaunchKernelGGL(stem_pool2_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
+            else hipLaunchKernelGGL(stem_pool2_kernel<3>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
           } else if (c->cin == 1)
             hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(a.tiles_x * a.tiles_y * n), dim3(256), 0, sb.st, a);
           else
@@ -2962,6 +2974,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->winograd_in1 = !(pf & FPC_PLAN_NO_WINOGRAD_LAYER_IN1);
     c->xcd_order = !(pf & FPC_PLAN_NO_XCD_ORDER);
     c->fuse_stem_pool = !(pf & FPC_PLAN_NO_FUSED_STEM_POOL);
+    c->stem_lean = !(pf & FPC_PLAN_STEM_ROUND3);
+    if (const char* e = getenv("FPC_STEM_LEAN")) c->stem_lean = atoi(e) != 0;
     // Round 4, with the streams on hardware queues of their own: one context, two sub-batches, Python network, fp32 MFMA:
     // 10 740 -> 10 845 frames/s (steady 10 790 -> 10 930; two runs each); the C++ network loses 2 %, bf16 HD and the QVGA
     // detector do not move, one-sub-batch contexts (the bench's two in turn) +0.1 %: the default where it was measured to pay.
@@ -3807,7 +3821,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
     if (kernels) {
       const char* k = "?";
       if (op) switch (op->type) {
-          case OP_STEM: k = c->bf16 ? "stem_bf16_kernel" : c->split ? "stem_pool_x3_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
+          case OP_STEM: k = c->bf16 ? "stem_bf16_kernel" : c->split ? "stem_pool_x3_kernel" : c->stem2 ? "stem_pool2_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
           case OP_CONV: k = g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;

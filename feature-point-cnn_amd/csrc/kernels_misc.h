@@ -358,6 +358,200 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Round 5: stem_pool_kernel on a VALU diet, for maps of whole tiles (Ho, Wo multiples of 16: VGA, HD; others keep
+// stem_pool_kernel).  On gfx950 the fp32 MFMA and the VALU exclude each other on a SIMD (wblock36_mfma.h), and the
+// shipped stem_pool_kernel<3> issues ~900 VALU instructions per wave and tile around its 304 MFMAs (static count of the
+// code object: 251 in the prologue, 52 in the K loop, 669 in the epilogue, 408 of them v_max_f32) -- a fifth of its
+// matrix time.  Here:
+//   * the folded-BN bias is a K step of the GEMM (the step the K order leaves empty behind the last channel: A = 1.0,
+//     B = bias in lanes 0-31, stem_pair2 below) and the accumulators start at the MFMA's inline constant 0: no 64 moves per
+//     tile, no addition in the epilogue;
+//   * at most 128 registers (__launch_bounds__(256, 4): the kernel names no AGPR, so the accumulators are architectural
+//     VGPRs): the tile write is 32 ds_write_b32 per half straight from them, where the AGPR form went through 94
+//     v_accvgpr moves per tile;
+//   * the window is staged through a buffer descriptor of the frame: 32-bit offsets, out-of-frame float4s get an offset
+//     outside its range and come back as zeros (no 64-bit address arithmetic, no select on the data);
+//   * pooling: a pooled row is v_max3_f32 over its three conv rows (16 instructions; row -1 of the tile's first pooled
+//     row reads row 0 again -- a duplicate does not change a maximum) and v_max3_f32 over three columns + the ReLU per
+//     output, no masks (whole tiles), one branch per half (the tile's first pooled row goes out by atomics, the others by
+//     seven plain stores and two atomics).
+// Same K order, same fragments (+ the bias step), same cells completed by atomicMax as stem_pool_kernel.
+// ---------------------------------------------------------------------------------
+constexpr int STEM_BIAS_TAP = -2;   // StemPair::wa of the step that carries the bias
+__host__ __device__ constexpr StemPair stem_pair2(int cin, int t) {
+  if (t == cin * 25) return StemPair{0, STEM_BIAS_TAP, -1, 0};
+  return stem_pair(cin, t);
+}
+
+// (as asm, like stem_max3: behind an asm result the compiler's own fmaxf first canonicalises its operand -- v_max_f32 x, x)
+__device__ __forceinline__ float stem_relu(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float stem_max3(float x, float y, float z) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 4) void stem_pool2_kernel(const StemPoolArgs a) {
+  constexpr int KREAL = CIN * 49, KG = (KREAL + 7) / 8;
+  static_assert(CIN * 25 < KG * 4, "an empty step behind the last channel carries the bias");
+  __shared__ float lds[STEM_POOL_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bidx = fpc_xcd_tile_index();
+  const int b = bidx / tiles;
+  const int t = bidx - b * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const int iy0 = ty * STEM_T * 2 - 3, ix0 = tx * STEM_T * 2 - 3;
+
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wfrag), 0, (KG + 2) * 2 * 64 * 16, 0x00020000);
+  const int wlane = lane * 16;
+  auto wfrag = [&](int i) {   // fragment i = group * 2 + nb
+    const f32x4w r = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, i * 1024, 0));
+    return make_float4(r.x, r.y, r.z, r.w);
+  };
+  float4 q0[2], q1[2];
+  q0[0] = wfrag(0);
+  q0[1] = wfrag(1);
+  q1[0] = wfrag(2);
+  q1[1] = wfrag(3);
+
+  {  // input window -> LDS as aligned float4 row segments (stem_pool_kernel), through a descriptor of THIS frame
+    constexpr int NQ = STEM_LW / 4, NE = CIN * STEM_HALO * NQ, IT = (NE + 255) / 256;
+    const int plane = a.H * a.W;
+    const __amdgpu_buffer_rsrc_t irsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in) + (size_t)b * CIN * plane, 0, CIN * plane * 4, 0x00020000);
+    f32x4w v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / NQ, q = e - row * NQ;
+      const int c = row / STEM_HALO, hy = row - c * STEM_HALO;
+      const int iy = iy0 + hy, ix = ix0 - 1 + 4 * q;
+      bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+      if ((i + 1) * 256 > NE) ok = ok & (e < NE);
+      const int off = ((c * a.H + iy) * a.W + ix) * 4;
+      v[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(irsrc, ok ? off : (int)0x7ffffff0, 0, 0));
+    }
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * 256;
+      if ((i + 1) * 256 <= NE || e < NE) *reinterpret_cast<f32x4w*>(lds + e * 4) = v[i];
+      chk = fmaf((v[i].x + v[i].y) + (v[i].z + v[i].w), 0.f, chk);   // nonfinite_probe
+    }
+    if (chk != chk && a.range) a.range[b * FPC_RANGE_WORDS + RANGE_BAD_INPUT] = 1u;
+  }
+  __syncthreads();
+
+  // A operand bases PER CHANNEL, as registers of their own: a tap's offset inside its channel's window is at most 6 rows + 6
+  // columns = 246 dwords, inside ds_read2_b32's 8-bit offsets -- from one base per (column | row) form the compiler made new
+  // bases on the way (v_add_u32 in the K loop: 30 of them, and each VALU instruction between two fp32 MFMAs costs 15 cycles)
+  int acol[CIN][2], arow[CIN][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = (wave * 2 + mb) * 32 + l31;
+    const int ab = (2 * (m / STEM_T)) * STEM_LW + 2 * (m % STEM_T) + 1;
+#pragma unroll
+    for (int ch = 0; ch < CIN; ++ch) {
+      acol[ch][mb] = (ab + half + ch * (STEM_HALO * STEM_LW)) * 4;            // BYTE offsets (a dword index is shifted at every use)
+      arow[ch][mb] = (ab + half * STEM_LW + ch * (STEM_HALO * STEM_LW)) * 4;
+      asm volatile("" : "+v"(acol[ch][mb]), "+v"(arow[ch][mb]));
+    }
+  }
+  float one = 1.f;
+  asm volatile("" : "+v"(one));   // (a register the MFMA can take as its A operand)
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    float4 q2[2];
+    q2[0] = wfrag((g + 2) * 2 + 0);
+    q2[1] = wfrag((g + 2) * 2 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const StemPair P = stem_pair2(CIN, g * 4 + j);
+      if (P.wa == -1 && P.wb == -1) continue;   // an empty step: no MFMA
+      const int kk = P.addr_k < KREAL ? P.addr_k : KREAL - 1, ch = kk / 49;
+      const int off = ((kk % 49) / 7) * STEM_LW + (kk % 7);   // inside the channel's window
+      const float bf0 = j == 0 ? q0[0].x : j == 1 ? q0[0].y : j == 2 ? q0[0].z : q0[0].w;
+      const float bf1 = j == 0 ? q0[1].x : j == 1 ? q0[1].y : j == 2 ? q0[1].z : q0[1].w;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float af = P.wa == STEM_BIAS_TAP
+                             ? one
+                             : *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + (P.row ? arow[ch][mb] : acol[ch][mb]) + off * 4);
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf0, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf1, acc[mb][1], 0, 0, 0);
+      }
+    }
+    q0[0] = q1[0];
+    q0[1] = q1[1];
+    q1[0] = q2[0];
+    q1[1] = q2[1];
+  }
+
+  // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool
+  const int c = tid & 31, j = tid >> 5;
+  const int wbase = (wave * 64 + 4 * half) * STEM_TROW + l31;
+  const int r0 = j == 0 ? 0 : 2 * j - 1;
+  const int rd0 = r0 * STEM_T * STEM_TROW + c, rd1 = 2 * j * STEM_T * STEM_TROW + c;
+  const bool has_col8 = tx * 8 + 8 < a.Wp, has_row8 = ty * 8 + 8 < a.Hp;   // pooled column / row 8 of the tile exists (it is the next tile's 0)
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    FPC_LDS_BARRIER();   // (LDS hand-offs only: __syncthreads() would also wait for the first half's stores and atomics)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[wbase + (mb * 32 + (r & 3) + 8 * (r >> 2)) * STEM_TROW] = acc[mb][nb][r];
+    FPC_LDS_BARRIER();
+    float cm[STEM_T];
+#pragma unroll
+    for (int cc = 0; cc < STEM_T; ++cc)
+      cm[cc] = stem_max3(lds[rd0 + cc * STEM_TROW], lds[rd1 + cc * STEM_TROW], lds[rd1 + (STEM_T + cc) * STEM_TROW]);
+    float mx[9];
+    mx[0] = stem_max3(cm[0], cm[1], 0.f);
+#pragma unroll
+    for (int px = 1; px < 8; ++px) mx[px] = stem_relu(stem_max3(cm[2 * px - 1], cm[2 * px], cm[2 * px + 1]));
+    mx[8] = stem_relu(cm[15]);
+    float* row = a.out + ((size_t)(b * a.Hp + ty * 8 + j) * a.Wp + tx * 8) * 64 + nb * 32 + c;
+    if (j == 0) {
+#pragma unroll
+      for (int px = 0; px < 8; ++px) atomicMax(reinterpret_cast<unsigned int*>(row + px * 64), __float_as_uint(mx[px]));
+    } else {
+      atomicMax(reinterpret_cast<unsigned int*>(row), __float_as_uint(mx[0]));
+#pragma unroll
+      for (int px = 1; px < 8; ++px) row[px * 64] = mx[px];
+    }
+    if (has_col8) atomicMax(reinterpret_cast<unsigned int*>(row + 8 * 64), __float_as_uint(mx[8]));
+    if (has_row8 && j == 0) {   // pooled row 8: conv row 15 only, the rest of its windows belongs to the tile below
+      float* row8 = row + (size_t)8 * a.Wp * 64;
+      const int rd = 15 * STEM_T * STEM_TROW + c;
+#pragma unroll
+      for (int cc = 0; cc < STEM_T; ++cc) cm[cc] = lds[rd + cc * STEM_TROW];
+      atomicMax(reinterpret_cast<unsigned int*>(row8), __float_as_uint(stem_max3(cm[0], cm[1], 0.f)));
+#pragma unroll
+      for (int px = 1; px < 8; ++px)
+        atomicMax(reinterpret_cast<unsigned int*>(row8 + px * 64), __float_as_uint(stem_relu(stem_max3(cm[2 * px - 1], cm[2 * px], cm[2 * px + 1]))));
+      if (has_col8) atomicMax(reinterpret_cast<unsigned int*>(row8 + 8 * 64), __float_as_uint(stem_relu(cm[15])));
+    }
+  }
+}
+
 // MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC, C = 64 (superpoint.py:15,23).
 __global__ __launch_bounds__(256) void maxpool_kernel(const float4* in, float4* out, int B, int H, int W,
                                                       int Ho, int Wo) {

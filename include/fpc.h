@@ -35,8 +35,10 @@ extern "C" {
  * of values inside a layer's fragments -- offsets and sizes, which the plan hash covers anyway, do not change then, and
  * a blob of the older build would otherwise be accepted and multiplied with the wrong weights.
  *   1: rounds 1-2.   2: round 3 (fp32 stem fragments in the column / row tap-pair K order, stem_pair).
- *   3: round 4.  (ABI 4, round 5: fpc_stream_report added, fpc_set_stream's contract narrowed; layouts unchanged.) */
-#define FPC_PACK_LAYOUT_REVISION 3
+ *   3: round 4.  (ABI 4, round 5: fpc_stream_report added, fpc_set_stream's contract narrowed.)
+ *   4: round 5 (fp32 stem fragments carry the folded-BN bias as a K step where stem_pool2_kernel runs; FPC_BF16's
+ *      ConvTranspose fragments in convt_bf16_kernel's nine-taps-per-step order). */
+#define FPC_PACK_LAYOUT_REVISION 4
 
 enum {
   FPC_OK = 0,
@@ -134,6 +136,7 @@ enum {
   FPC_PLAN_HEADS_IN_LINE = 1 << 17,        /* ... and its opt-out: the two heads of a sub-batch back to back on its stream  (FPC_SPLIT_HEADS=0) */
   FPC_PLAN_DETECTOR_GEN1 = 1 << 16,        /* the detector's 65-channel blocks on round 1's kernel in batch calls too       (FPC_WINOGRAD_DET_GEN=1) */
   FPC_PLAN_W36_ONE_WAVE = 1 << 18,         /* the 64-channel F(4x4,3x3) layers on round 3's one-wave-per-SIMD kernel instead of round 5's two  (FPC_W36_PAIRED=0) */
+  FPC_PLAN_STEM_ROUND3 = 1 << 20,          /* FPC_F32: round 3's stem_pool_kernel also where round 5's stem_pool2_kernel applies (conv map of whole 16x16 tiles) (FPC_STEM_LEAN=0) */
   FPC_PLAN_CONVT_PHASES = 1 << 19,         /* FPC_BF16: the ConvTranspose as four output-parity launches (rounds 2-4) instead of round 5's one  (FPC_CONVT_FUSED=0) */
   FPC_PLAN_GUARD_ZONES = 1 << 15           /* TEST FACILITY: 64 KiB of a canary pattern behind every buffer of the workspace and
                                               2 GiB behind the last one (the workspace grows by that much); fpc_check_guards
