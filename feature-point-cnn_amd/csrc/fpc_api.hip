@@ -484,7 +484,7 @@ struct fpc_ctx {
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
   bool stem_lean = true;             // ... on stem_pool2_kernel where the conv map is whole 16 x 16 tiles (FPC_PLAN_STEM_ROUND3 / FPC_STEM_LEAN=0: stem_pool_kernel)
-  bool stem2 = false;                // decided in fpc_create: stem_lean, fp32 MFMA mode, fused stem + pool, whole tiles -- the fragments then carry the bias (stem_pair2)
+  bool stem2 = false;                // decided in fpc_create: stem_lean, fp32 MFMA mode, fused stem + pool, whole tiles
   bool layer1_t816 = false;          // direct (non-Winograd) layer1 blocks on 8x16 tiles instead of 16x16
 #ifdef FPC_DIAG
   unsigned long long* diag_stamps = nullptr;
@@ -1798,7 +1798,8 @@ postproc:
   c->stem.tiles_x = (W2 + STEM_T - 1) / STEM_T;
   c->stem.tiles_y = (H2 + STEM_T - 1) / STEM_T;
   // round 5: the fp32 stem + pool on stem_pool2_kernel where the conv map is whole tiles (VGA, HD; QVGA's 120 rows are
-  // not): its fragments carry the bias as a K step, so the choice is part of the packed layout (plan_hash)
+  // not).  The fragments carry the bias as a K step in EVERY geometry (pack layout revision 4; stem_pool_kernel and
+  // stem_kernel skip that step), so the choice is a launch-time one and blobs stay exchangeable between geometries
   c->stem2 = c->stem_lean && !c->bf16 && !c->split && !c->vgg && (c->fuse_stem_pool || c->cin == 1) && H2 % STEM_T == 0 && W2 % STEM_T == 0;
   return FPC_OK;
 }
@@ -1817,7 +1818,7 @@ static uint64_t plan_hash(const fpc_ctx* c) {
   };
   mix(FPC_ABI_VERSION); mix(FPC_PACK_LAYOUT_REVISION); mix((uint64_t)c->cfg.dtype); mix((uint64_t)c->cfg.arch); mix((uint64_t)c->cin);
   mix((uint64_t)(c->cfg.descriptor_enabled != 0)); mix(c->blob_floats); mix(c->stem_w_off); mix(c->stem_b_off);
-  mix(c->vconv0_off); mix((uint64_t)c->stem2);
+  mix(c->vconv0_off);
   for (size_t i = 0; i < c->ops.size(); ++i) {
     const Op& op = c->ops[i];
     mix((uint64_t)op.type); mix((uint64_t)op.kind); mix((uint64_t)op.bkind); mix((uint64_t)op.wkind); mix((uint64_t)op.fkind);
@@ -2026,9 +2027,9 @@ static int pack_all_impl(fpc_ctx* c, const TensorMap& m, std::string* missing, b
       for (int nb = 0; nb < 2; ++nb)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 4; ++j) {
-            const StemPair sp = c->stem2 ? stem_pair2(c->cin, g * 4 + j) : stem_pair(c->cin, g * 4 + j);      // the kernels' K order (kernels_misc.h)
+            const StemPair sp = stem_pair2(c->cin, g * 4 + j);      // the kernels' K order (kernels_misc.h), bias step included
             const int k = (lane >> 5) ? sp.wb : sp.wa, n = nb * 32 + (lane & 31);
-            if (k == STEM_BIAS_TAP) {   // stem_pool2_kernel: the folded-BN bias as a K step (A operand 1.0)
+            if (k == STEM_BIAS_TAP) {   // the folded-BN bias as a K step (stem_pool2_kernel: A operand 1.0; the other stem kernels skip the step)
               dst[(((size_t)g * 2 + nb) * 64 + lane) * 4 + j] = (float)f.t[n];
               continue;
             }

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     for (int j = 0; j < 4; ++j) {
       constexpr int CIN3 = 3;
       const StemPair P = stem_pair(CIN3, g * 4 + j);
+      if (P.wa < 0 && P.wb < 0) continue;   // an empty step; the first one carries the bias for stem_pool2_kernel (pack layout revision 4)
       const int off = stem_koff(P.addr_k);
       const float bf0 = j == 0 ? bq0.x : j == 1 ? bq0.y : j == 2 ? bq0.z : bq0.w;
       const float bf1 = j == 0 ? bq1.x : j == 1 ? bq1.y : j == 2 ? bq1.z : bq1.w;
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const StemPair P = stem_pair(CIN, g * 4 + j);
+      if (P.wa < 0 && P.wb < 0) continue;   // an empty step; the first one carries the bias for stem_pool2_kernel (pack layout revision 4)
       const int off = stem_koff_c<KREAL>(P.addr_k);
       const float bf0 = j == 0 ? q0[0].x : j == 1 ? q0[0].y : j == 2 ? q0[0].z : q0[0].w;
       const float bf1 = j == 0 ? q0[1].x : j == 1 ? q0[1].y : j == 2 ? q0[1].z : q0[1].w;
@@ -376,7 +378,8 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 //     row reads row 0 again -- a duplicate does not change a maximum) and v_max3_f32 over three columns + the ReLU per
 //     output, no masks (whole tiles), one branch per half (the tile's first pooled row goes out by atomics, the others by
 //     seven plain stores and two atomics).
-// Same K order, same fragments (+ the bias step), same cells completed by atomicMax as stem_pool_kernel.
+// Same K order, same fragments (the bias step is in them for every kernel since pack layout revision 4; stem_pool_kernel
+// and stem_kernel skip it), same cells completed by atomicMax as stem_pool_kernel.
 // ---------------------------------------------------------------------------------
 constexpr int STEM_BIAS_TAP = -2;   // StemPair::wa of the step that carries the bias
 __host__ __device__ constexpr StemPair stem_pair2(int cin, int t) {
@@ -504,7 +507,8 @@ __global__ __launch_bounds__(256, 4) void stem_pool2_kernel(const StemPoolArgs a
     q1[0] = q2[0];
     q1[1] = q2[1];
   }
-
+  // (no fence here: with one, the epilogue's address arithmetic waits behind the last MFMA and the kernel measures 1.7 % slower
+  // than with those dozen instructions under the last steps' MFMAs, where the compiler puts them)
   // epilogue: per 32-channel half, tile -> LDS -> 3x3/2 max-pool
   const int c = tid & 31, j = tid >> 5;
   const int wbase = (wave * 64 + 4 * half) * STEM_TROW + l31;

@@ -418,6 +418,16 @@ class Engine:
                 for i in range(min(n, cap))]
 
 
+    def kernel_names(self, frames):
+        """Kernel symbols one fpc_forward over `frames` launches (through the timing facility: events on, one call, events off)."""
+        self.set_timing(True)
+        self.forward(frames)
+        self.sync()
+        out = [k for _, k, _, _, _, _ in self.timings()]
+        self.set_timing(False)
+        return out
+
+
 class _DevArray:
     """Minimal __cuda_array_interface__ holder so torch can alias library-owned memory."""
 

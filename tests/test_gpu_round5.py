@@ -72,7 +72,9 @@ def test_stream_placement_is_cheap_bounded_and_changes_no_result():
     # (create_placement_ms of a process's FIRST context also holds one-time runtime work -- the first pinned allocation,
     # the first stream -- 100 ms measured; it is bounded on the second context below)
     assert r1["process_probe_ms"] < 20.0, r1
-    assert r1["process_inconclusive_rounds"] == 0, r1
+    # (an inconclusive round -- the host was late with the flag, a probe kernel ran out of its 2 ms -- is repeated; three of them
+    # would switch probing off, which the `probing` field above would show)
+    assert r1["process_inconclusive_rounds"] <= 1 and r1["probing"], r1
     t0 = time.perf_counter()
     e2 = engine(h, w, n)
     create_s = time.perf_counter() - t0
@@ -339,3 +341,73 @@ def test_a_non_finite_pixel_is_reported_and_stays_in_its_frame():
     assert g.output_range(1)[2].tolist() == [True]
     g.close()
     e.close()
+
+
+def test_round5_stem_and_its_round3_form_agree(golden_dir):
+    """Round 5's stem_pool2_kernel (whole-tile maps: VGA here; bias as a K step, v_max3 pooling) against round 3's
+    stem_pool_kernel (FPC_PLAN_STEM_ROUND3) and against the reference's fixture: the pooled stem tensor within 2e-6 of
+    each other (the bias enters the fp32 sum at the other end), both within 1e-4 of the fixture's probes, identical
+    keypoints; the switch is not part of the packed layout (same plan hash, blobs exchangeable), and the gray instance
+    (in_channels = 1, K = 49 + the bias step) equals the replicated-plane RGB result."""
+    g = np.load(os.path.join(golden_dir, "f5_e2e_vga.npz"))
+    h, w = int(g["h"]), int(g["w"])
+    sd = synth.make_state_dict(int(g["seed_weights"]), float(g["dustbin_bias"]))
+    frames = np.repeat(synth.make_batch(int(g["seed_frame"]), 1, h, w), 3, axis=0)
+    e5 = engine(h, w, 3)
+    e3 = engine(h, w, 3, plan_flags=["stem_round3"])
+    assert e5.plan_hash() == e3.plan_hash()
+    e5.load_state_dict(sd)
+    e3.import_packed(e5.export_packed())
+    assert "stem_pool2_kernel" in " ".join(e5.kernel_names(frames)) and "stem_pool2_kernel" not in " ".join(e3.kernel_names(frames))
+    out5, out3 = e5.forward(frames), e3.forward(frames)
+    p5, p3 = e5.activation("pool", 0, 3).cpu().numpy(), e3.activation("pool", 0, 3).cpu().numpy()
+    assert float(np.abs(p5 - p3).max()) < 2e-6 * max(1.0, float(np.abs(p3).max()))
+    for out in (out5, out3):
+        np.testing.assert_allclose(out[2][2].cpu().numpy().ravel()[::7], g["logits_probe"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(out[1][1].cpu().numpy().ravel()[::11], g["desc_map_probe"], rtol=0, atol=ATOL)
+    r5, r3 = e5.detect(frames), e3.detect(frames)
+    for a, b in zip(r5, r3):      # the same keypoint SET (confidences differ in their last bits, so near-ties may swap places)
+        np.testing.assert_array_equal(np.sort(a[0][:, 1].astype(np.int64) * w + a[0][:, 0]), np.sort(b[0][:, 1].astype(np.int64) * w + b[0][:, 0]))
+    gx, gy = g["points_x"].astype(np.int64), g["points_y"].astype(np.int64)
+    np.testing.assert_array_equal(np.sort(r5[2][0][:, 1].astype(np.int64) * w + r5[2][0][:, 0]), np.sort(gy * w + gx))
+    e3.close()
+    # gray plane: stem_pool2_kernel<1>
+    rgb = np.stack([synth.make_frame(300 + i, h, w, gray=True).transpose(2, 0, 1) for i in range(2)])
+    e1 = engine(h, w, 3, in_channels=1)
+    e1.load_state_dict(sd)
+    l3 = e5.forward(rgb)[2]
+    l1 = e1.forward(np.ascontiguousarray(rgb[:, :1]))[2]
+    assert float((l3 - l1).abs().max()) < 2e-5
+    e1.close()
+    e5.close()
+
+
+def test_bf16_conv_transpose_in_one_launch_and_in_four_agree(golden_dir):
+    """FPC_BF16's ConvTranspose: round 5's convt_bf16_kernel (all four output parities from one staged input tile) against
+    the four phase launches of rounds 2-4 (FPC_PLAN_CONVT_PHASES) on the same input tensor: the same products in another
+    order of fp32 accumulation -- equal up to a bf16 rounding boundary (at most one ulp, on well under 0.5 % of the
+    elements) -- and the two plans have different packed layouts (plan hash; a blob of one is refused by the other).  Maps
+    narrower and lower than a tile, and a batch whose tile count is not a multiple of the grid."""
+    for (h, w, n) in ((480, 640, 2), (112, 208, 5), (64, 96, 1)):
+        sd = synth.make_state_dict(11, dustbin_bias=5.0)
+        frames = synth.make_batch(40, n, h, w)
+        ef = engine(h, w, n, dtype="bf16")
+        ep = engine(h, w, n, dtype="bf16", plan_flags=["convt_phases"])
+        assert ef.plan_hash() != ep.plan_hash()
+        ef.load_state_dict(sd)
+        ep.load_state_dict(sd)
+        if ef.packed_size() == ep.packed_size():
+            with pytest.raises(_lib.FpcError):
+                ep.import_packed(ef.export_packed())
+            ep.load_state_dict(sd)
+        assert any("convt_bf16_kernel" in k for k in ef.kernel_names(frames)) and not any("convt_bf16_kernel" in k for k in ep.kernel_names(frames))
+        ef.forward(frames)
+        ep.forward(frames)
+        xin_f, xin_p = ef.activation("desc_in.1", 0, n).cpu().numpy(), ep.activation("desc_in.1", 0, n).cpu().numpy()
+        np.testing.assert_array_equal(xin_f, xin_p)                  # the layers in front are the same kernels
+        up_f, up_p = ef.activation("up", 0, n).cpu().numpy().astype(np.float64), ep.activation("up", 0, n).cpu().numpy().astype(np.float64)
+        assert up_f.shape == up_p.shape and up_f.shape[1] == 128
+        rel = np.abs(up_f - up_p) / np.maximum(np.abs(up_p), 1.0)
+        assert float(rel.max()) <= 2.0 ** -7 and float((rel > 0).mean()) < 0.005, (h, w, float(rel.max()), float((rel > 0).mean()))
+        ef.close()
+        ep.close()

@@ -298,3 +298,46 @@ def test_one_chunk_bf16_block_instances_keep_their_registers(code_object):
         assert not any(i.startswith("scratch_") for _, i in funcs[name]), key
     layer1 = [k for k in inst if k[4] == 64 and k[2] == 1]          # (TH, TW, S, EXT, KC, WM, WN, MB, NB, CMIDP): KC = 64, stride 1
     assert layer1 and all(k[7] == 4 for k in layer1), layer1
+
+
+def test_round5_stem_has_no_valu_instruction_between_its_mfmas(code_object):
+    """DESIGN.md 3.2 (round 5): stem_pool2_kernel exists because a VALU instruction costs fp32 MFMA time on gfx950 -- the
+    shipped instances hold NO VALU instruction between their first and last-but-one MFMA group (per-channel LDS bases, the
+    bias as a K step), name no AGPR (accumulators straight into ds_write), fit 128 registers (four workgroups per CU)
+    with nothing in scratch, and issue less than a third of stem_pool_kernel's VALU instructions."""
+    funcs, meta = code_object
+    new = {n: b for n, b in funcs.items() if re.match(r"_ZN3fpc17stem_pool2_kernelILi[13]EEEvNS_12StemPoolArgsE$", n)}
+    old = {n: b for n, b in funcs.items() if re.match(r"_ZN3fpc16stem_pool_kernelILi[13]EEEvNS_12StemPoolArgsE$", n)}
+    assert len(new) == 2 and len(old) == 2, (sorted(new), sorted(old))
+    valu = lambda body: sum(1 for _, i in body if i.startswith("v_") and not i.startswith("v_mfma"))
+    for name, body in new.items():
+        m = meta[name]
+        assert m["agpr_count"] == 0 and m["vgpr_count"] <= 128, (name, m)
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
+        seq = [i for _, i in body]
+        mf = [k for k, i in enumerate(seq) if i.startswith("v_mfma")]
+        assert {seq[k].split()[0] for k in mf} == {"v_mfma_f32_32x32x2_f32"}
+        cin = 3 if "ILi3E" in name else 1
+        assert len(mf) == 4 * (cin * 25 + 1), (name, len(mf))            # 25 steps per channel + the bias step, 2 x 2 blocks
+        # (the compiler sinks the last step's MFMAs of the SECOND half under the first half's epilogue -- its address arithmetic
+        # and pooling: everything in front of the last four steps' sixteen MFMAs is the K loop proper)
+        inside = [i for i in seq[mf[0]:mf[-16]] if i.startswith("v_") and not i.startswith("v_mfma")]
+        assert not inside, (name, inside[:6])
+    for cin in (1, 3):
+        n_new = valu(next(b for n, b in new.items() if "ILi%dE" % cin in n))
+        n_old = valu(next(b for n, b in old.items() if "ILi%dE" % cin in n))
+        assert 3 * n_new < n_old, (cin, n_new, n_old)
+
+
+def test_round5_bf16_conv_transpose_kernel_keeps_its_registers(code_object):
+    """convt_bf16_kernel (csrc/convt_bf16.h): 128 accumulators (four output parities x two pixel blocks) + the nine-fragment ring
+    + the pixel ring fit the 256 registers of two waves per SIMD with nothing in scratch, and a chunk is 4 x 18 MFMAs."""
+    funcs, meta = code_object
+    inst = [n for n in funcs if n.startswith("_ZN3fpc17convt_bf16_kernelI")]
+    assert len(inst) == 1, inst
+    m = meta[inst[0]]
+    assert m["vgpr_count"] <= 256 and m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
+    body = funcs[inst[0]]
+    assert not any(i.startswith("scratch_") for _, i in body)
+    loop = _chunk_loop(body)
+    assert loop is not None and loop[2] == 72, loop
