@@ -321,7 +321,7 @@ def test_round5_stem_has_no_valu_instruction_between_its_mfmas(code_object):
         assert len(mf) == 4 * (cin * 25 + 1), (name, len(mf))            # 25 steps per channel + the bias step, 2 x 2 blocks
         # (the compiler sinks the last step's MFMAs of the SECOND half under the first half's epilogue -- its address arithmetic
         # and pooling: everything in front of the last four steps' sixteen MFMAs is the K loop proper)
-        inside = [i for i in seq[mf[0]:mf[-16]] if i.startswith("v_") and not i.startswith("v_mfma")]
+        inside = [i for i in seq[mf[0]:mf[-17]] if i.startswith("v_") and not i.startswith("v_mfma")]
         assert not inside, (name, inside[:6])
     for cin in (1, 3):
         n_new = valu(next(b for n, b in new.items() if "ILi%dE" % cin in n))
