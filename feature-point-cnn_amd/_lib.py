@@ -38,7 +38,7 @@ PLAN_FLAGS = {
     "no_fused_blocks": 1 << 0, "no_winograd": 1 << 1, "no_winograd_detector": 1 << 2, "no_winograd_layer_in1": 1 << 3,
     "no_xcd_order": 1 << 4, "no_fused_stem_pool": 1 << 5, "split_heads": 1 << 6, "nms_in_line": 1 << 7,
     "no_persistent_grid": 1 << 8, "layer1_tile_8x16": 1 << 9, "winograd_gen1": 1 << 10, "no_latency_tiles": 1 << 11,
-    "nms_one_workgroup": 1 << 12, "no_fused_softmax": 1 << 13, "winograd_gen2": 1 << 14, "guard_zones": 1 << 15, "detector_gen1": 1 << 16, "heads_in_line": 1 << 17, "w36_one_wave": 1 << 18, "convt_phases": 1 << 19, "stem_round3": 1 << 20,
+    "nms_one_workgroup": 1 << 12, "no_fused_softmax": 1 << 13, "winograd_gen2": 1 << 14, "guard_zones": 1 << 15, "detector_gen1": 1 << 16, "heads_in_line": 1 << 17, "w36_one_wave": 1 << 18, "convt_phases": 1 << 19, "stem_round3": 1 << 20, "conv_round1": 1 << 21,
 }
 
 

@@ -258,4 +258,213 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(const ConvArg
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Round 5: conv_mfma_kernel on a VALU diet (kernels_misc.h, stem_pool2_kernel, has the why: on gfx950 a VALU instruction
+// is an fp32 MFMA slot of its SIMD, and the shipped conv_mfma_kernel instances issue ~1 300 of them per wave and tile --
+// 64-bit addresses and two divisions per staged element and chunk, one four-byte store + one four-byte identity load with
+// a 64-bit address and a branch per accumulator register -- beside 256 MFMAs in the 1x1 of descriptor.layer_in.1).  For
+// launches with ONE K source whose workgroups store all their N channels (the host checks; the others keep
+// conv_mfma_kernel).  Same arithmetic in the same order: bit-identical results.
+//   * staging: a buffer descriptor of the FRAME, per-element byte offsets computed once per workgroup (out-of-frame,
+//     padding: a marker that stays out of range under the saturating addition of the chunk's offset) -- one VALU
+//     instruction per element and chunk;
+//   * a step's pixels are read from LDS while the previous step's MFMAs run (the old loop read them in front of their MFMAs);
+//   * epilogue: acc + bias -> LDS tile -> float4 elements: identity (requested before the tile is turned around), ReLU,
+//     16-byte stores through a descriptor of the output frame.
+// ---------------------------------------------------------------------------------
+#define CONV2_MARKER 0x7fffff00
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB>
+struct Conv2Cfg {
+  using C = ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>;
+  static constexpr int ROWO4 = C::N / 4 + 1;                          // float4 per pixel of the output tile (+1 skew)
+  static constexpr int OUT_BYTES = C::M * ROWO4 * 16;
+  static constexpr int LDS_BYTES = C::LDS_BYTES > OUT_BYTES ? C::LDS_BYTES : OUT_BYTES;
+};
+
+template <int TH, int TW, int S, int EXT, int KC, int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv2_mfma_kernel(const ConvArgs a) {
+  using C = ConvCfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>;
+  using C2 = Conv2Cfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>;
+  constexpr int NT = C::NT, HW = C::HW, HH = C::HH, ROW4 = C::ROW4, K8 = KC / 8, KC4 = KC / 4, N = C::N;
+  constexpr int NV = HH * HW * KC4, ITER = (NV + NT - 1) / NT, ROWO4 = C2::ROWO4;
+  extern __shared__ float4 lds4[];
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bidx = fpc_xcd_tile_index();
+  const int bl = bidx / tiles;
+  const int b = a.frame0 + bl;
+  const int t = bidx - bl * tiles;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const int subi = gridDim.z - 1 - blockIdx.z;
+  const ConvSub& sp = a.sub[subi];
+
+  int abase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int m = (wm * MB + mb) * 32 + l31;
+    m = m < TH * TW ? m : TH * TW - 1;
+    const int py = m / TW, px = m - py * TW;
+    abase[mb] = ((py * S) * HW + px * S) * ROW4 + half;
+  }
+  const int stepstride = a.nbt * 64;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float4*>(sp.wfrag), 0, (int)((unsigned)(a.nchunk0 * sp.ntaps * K8 + 2) * (unsigned)(stepstride * 16)), 0x00020000);
+  const int wlane = (((blockIdx.y * WN + wn) * NB) * 64 + lane) * 16;
+  int wstep = 0;
+  auto wfrag = [&](int nb) {
+    const f32x4w r = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + nb * 1024, wstep, 0));
+    return make_float4(r.x, r.y, r.z, r.w);
+  };
+
+  // ---- staging: per-element offsets inside the frame, once per workgroup
+  const int iy0 = ty * TH * S - a.pad, ix0 = tx * TW * S - a.pad;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in0) + (size_t)b * a.H * a.W * a.cs0, 0, a.H * a.W * a.cs0 * 4, 0x00020000);
+  int eoff[ITER], eslot[ITER];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int e = tid + i * NT;
+    int pix = e / KC4, c4 = e - pix * KC4;
+    const int hy = pix / HW, hx = pix - hy * HW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = (NV % NT == 0 || e < NV) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+    eoff[i] = ok ? ((iy * a.W + ix) * a.cs0 + c4 * 4) * 4 : CONV2_MARKER;
+    if (NV % NT != 0) {   // elements past the halo go to the skew slot of its last pixel (never read)
+      const bool in = e < NV;
+      pix = in ? pix : HH * HW - 1;
+      c4 = in ? c4 : KC4;
+    }
+    eslot[i] = pix * ROW4 + c4;
+  }
+  f32x4w stage[ITER];
+  auto load_chunk = [&](int chunk) {
+    const int cbase = chunk < a.nchunk0 ? chunk * (KC * 4) : CONV2_MARKER;   // nothing is in range past the last chunk
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      int voff;
+      asm("v_add_i32 %0, %1, %2 clamp" : "=v"(voff) : "v"(eoff[i]), "s"(cbase));
+      stage[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) *reinterpret_cast<f32x4w*>(&lds4[eslot[i]]) = stage[i];
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const int nchunks = a.nchunk0, ntaps = sp.ntaps;
+  load_chunk(0);
+  float4 b0[NB], b1[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b0[nb] = wfrag(nb);
+  wstep += stepstride * 16;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) b1[nb] = wfrag(nb);
+  wstep += stepstride * 16;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    FPC_LDS_BARRIER();
+    store_chunk();
+    FPC_LDS_BARRIER();
+    load_chunk(chunk + 1);
+    float4 av[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) av[mb] = lds4[abase[mb] + sp.tapoff4[0]];
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const int toff = sp.tapoff4[tap];
+      const int toffn = sp.tapoff4[tap + 1 < ntaps ? tap + 1 : tap];
+#pragma unroll
+      for (int k8 = 0; k8 < K8; ++k8) {
+        float4 b2[NB], an[MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = wfrag(nb);
+        wstep += stepstride * 16;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) an[mb] = lds4[abase[mb] + (k8 + 1 < K8 ? toff + (k8 + 1) * 2 : toffn)];   // (last step of a chunk: unused)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const float af = j == 0 ? av[mb].x : j == 1 ? av[mb].y : j == 2 ? av[mb].z : av[mb].w;
+              const float bf = j == 0 ? b0[nb].x : j == 1 ? b0[nb].y : j == 2 ? b0[nb].z : b0[nb].w;
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mb][nb], 0, 0, 0);
+            }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          b0[nb] = b1[nb];
+          b1[nb] = b2[nb];
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = an[mb];
+      }
+    }
+  }
+
+  // ---- epilogue: + bias -> LDS tile -> (+ identity) -> ReLU -> 16-byte stores
+  constexpr int C4 = N / 4, NE = TH * TW * C4, EIT = (NE + NT - 1) / NT;
+  const int oyb = ty * TH, oxb = tx * TW;
+  const int nbase = blockIdx.y * N;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.OH * a.OW * a.cso, 0, a.OH * a.OW * a.cso * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res : a.out) + (size_t)b * a.OH * a.OW * (a.res ? a.csr : a.cso), 0, a.res ? a.OH * a.OW * a.csr * 4 : 0, 0x00020000);
+  int ooff[EIT], olds[EIT];
+  f32x4w idv[EIT];
+#pragma unroll
+  for (int i = 0; i < EIT; ++i) {
+    const int e = tid + i * NT;
+    const int m = e / C4, c4 = e - m * C4;
+    const int py = m / TW, px = m - py * TW;
+    const int y = oyb + py, x = oxb + px;
+    const bool ok = (NE % NT == 0 || e < NE) & (y < a.Ho) & (x < a.Wo);
+    const int opix = (y * a.oys + sp.oy0) * a.OW + x * a.oxs + sp.ox0;
+    ooff[i] = ok ? (opix * a.cso + nbase + c4 * 4) * 4 : CONV2_MARKER;
+    olds[i] = (NE % NT == 0 || e < NE) ? m * ROWO4 + c4 : 0;
+    // (the identity: zeros from the bounds check where there is none -- the descriptor's range is 0 then)
+    idv[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? (opix * a.csr + nbase + c4 * 4) * 4 : CONV2_MARKER, 0, 0));
+  }
+  FPC_LDS_BARRIER();   // every wave is done reading the last chunk
+  {
+    float* ol = reinterpret_cast<float*>(lds4);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int nl = (wn * NB + nb) * 32 + l31;
+      const float bias = a.bias[nbase + nl];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          ol[m * (ROWO4 * 4) + nl] = acc[mb][nb][r] + bias;
+        }
+    }
+  }
+  FPC_LDS_BARRIER();
+  const float floor_ = a.relu ? 0.f : -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < EIT; ++i) {
+    f32x4w v = *reinterpret_cast<const f32x4w*>(&lds4[olds[i]]);
+    v += idv[i];
+    v.x = fmaxf(v.x, floor_);
+    v.y = fmaxf(v.y, floor_);
+    v.z = fmaxf(v.z, floor_);
+    v.w = fmaxf(v.w, floor_);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), orsrc, ooff[i], 0, 0);
+  }
+}
+
 }  // namespace fpc

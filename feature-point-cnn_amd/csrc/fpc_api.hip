@@ -102,6 +102,42 @@ static const KindInfo g_kinds[K_COUNT] = {
 #undef X
 };
 
+// Round 5: conv2_mfma_kernel (conv_mfma.h: the same convolution with a quarter of the VALU instructions) for the two
+// instances of the default fp32 plan -- the ConvTranspose phases and descriptor.layer_in.1's 1x1; launches it does not
+// cover (a second K source, workgroups that store only part of their N channels) and every other instance keep
+// conv_mfma_kernel.
+#define FPC_LEAN_KINDS(X)                          \
+  X(T320_2x2_K64_N128, 3, 20, 1, 2, 64, 1, 4, 2, 1) \
+  X(T320_1x1_K64_N128, 3, 20, 1, 1, 64, 1, 4, 2, 1)
+struct LeanKindInfo {
+  Kind kind;
+  const char* symbol;
+  int lds_bytes;
+  const void* fn;
+  void (*launch)(const ConvArgs&, dim3, hipStream_t);
+};
+#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB)                                                              \
+  static void launch_lean_##name(const ConvArgs& a, dim3 grid, hipStream_t st) {                                 \
+    using C2 = Conv2Cfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>;                                                    \
+    hipLaunchKernelGGL((conv2_mfma_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB>), grid, dim3(WM* WN * 64),         \
+                       C2::LDS_BYTES, st, a);                                                                    \
+  }
+FPC_LEAN_KINDS(X)
+#undef X
+static const LeanKindInfo g_lean_kinds[] = {
+#define X(name, TH, TW, S, EXT, KC, WM, WN, MB, NB)                                                                       \
+  {K_##name, "conv2_mfma_kernel<" #TH ", " #TW ", " #S ", " #EXT ", " #KC ", " #WM ", " #WN ", " #MB ", " #NB ">",          \
+   Conv2Cfg<TH, TW, S, EXT, KC, WM, WN, MB, NB>::LDS_BYTES, (const void*)conv2_mfma_kernel<TH, TW, S, EXT, KC, WM, WN, MB, NB>, \
+   launch_lean_##name},
+    FPC_LEAN_KINDS(X)
+#undef X
+};
+static const LeanKindInfo* lean_kind(Kind k) {
+  for (const LeanKindInfo& l : g_lean_kinds)
+    if (l.kind == k) return &l;
+  return nullptr;
+}
+
 // Fused ResNetBlock instances.  BKIND(name, TH,TW, S, KC, WM,WN, MB,NB, CMIDP)
 #define FPC_BLOCK_KINDS(X)                                   \
   X(B816_s1_K64_C64, 8, 16, 1, 64, 4, 1, 1, 2, 64)           \
@@ -420,6 +456,7 @@ struct Op {
   bool wconv = false;          // conv-only Winograd launch: 3x3 conv + (BN or bias) + ReLU, output channels n0 .. n0+127
   int n0 = 0;
   bool plain_conv = false;     // a Conv2d + bias (+ ReLU) of the C++ network: weights `prefix`.weight / .bias, no BN
+  bool lean = false;           // OP_CONV on conv2_mfma_kernel (round 5; add_conv decides)
   int ksize = 0;
   const float* pin = nullptr;  // OP_POOL2 / OP_L2NORM / OP_VCONV0 operands
   float* pout = nullptr;
@@ -483,6 +520,7 @@ struct fpc_ctx {
   bool nms_one_workgroup = false;  // FPC_PLAN_NMS_ONE_WORKGROUP: round 1's sort (one workgroup per frame) for every frame
   int nms_g = 0;                     // FPC_NMS_G: workgroups per frame of the NMS rounds kernel (0 = 512 / frames, at most 16)
   bool fuse_stem_pool = true;        // conv1+bn1+relu+max_pool in one launch (FPC_FUSE_STEM=0: two)
+  bool conv_lean = true;             // OP_CONV launches on conv2_mfma_kernel where it applies (FPC_PLAN_CONV_ROUND1 / FPC_CONV_LEAN=0: conv_mfma_kernel)
   bool stem_lean = true;             // ... on stem_pool2_kernel where the conv map is whole 16 x 16 tiles (FPC_PLAN_STEM_ROUND3 / FPC_STEM_LEAN=0: stem_pool_kernel)
   bool stem2 = false;                // decided in fpc_create: stem_lean, fp32 MFMA mode, fused stem + pool, whole tiles
   bool layer1_t816 = false;          // direct (non-Winograd) layer1 blocks on 8x16 tiles instead of 16x16
@@ -621,6 +659,14 @@ struct ConvSpec {
   bool desc_branch;
 };
 
+// conv2_mfma_kernel (round 5) takes a launch with one K source whose workgroups store all of their N channels as float4s
+static bool conv_is_lean(const fpc_ctx* c, const Op& op) {
+  const KindInfo& k = g_kinds[op.kind];
+  const ConvArgs& a = op.args;
+  return c->conv_lean && lean_kind(op.kind) && a.nchunk1 == 0 && a.nstore == op.grid_y * (k.WN * k.NB * 32) && a.cso % 4 == 0 &&
+         (!a.res || a.csr % 4 == 0);
+}
+
 static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
   const KindInfo& k = g_kinds[s.kind];
   Op op;
@@ -696,6 +742,8 @@ static void add_conv(fpc_ctx* c, const ConvSpec& s, size_t* blob_off) {
   }
   cw.b_off = *blob_off;
   *blob_off += (size_t)nbt * 32;
+  // conv2_mfma_kernel: one K source, every workgroup stores all of its N channels as float4s
+  op.lean = conv_is_lean(c, op);
   a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
   op.bytes_per_frame = 4.0 * ((double)s.cin0 * s.H0 * s.W0 + (s.in1 ? (double)s.cin1 * s.H1 * s.W1 : 0.0) +
@@ -798,6 +846,7 @@ static void retile_last(fpc_ctx* c, Kind small) {
     }
   a.tiles_x = (a.Wo + k.TW - 1) / k.TW;
   a.tiles_y = (a.Ho + k.TH - 1) / k.TH;
+  o.lean = conv_is_lean(c, o);
 }
 
 static void add_wblock(fpc_ctx* c, const BlockSpec& s, WKind wk, size_t* blob_off, bool small_only = false) {
@@ -2607,7 +2656,8 @@ static void run_network(fpc_ctx* c, const float* frames, const Sub& sb0, int whi
         LaunchTimer t(c, (int)i, sb.st, n);
         ConvArgs a = op.args;
         a.frame0 = f0;
-        g_kinds[op.kind].launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), sb.st);
+        if (op.lean) lean_kind(op.kind)->launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), sb.st);
+        else g_kinds[op.kind].launch(a, dim3(a.tiles_x * a.tiles_y * n, op.grid_y, op.grid_z), sb.st);
         break;
       }
       default:
@@ -2847,6 +2897,7 @@ enum { SLOT_MAIN = 0, SLOT_AUX = 1, SLOT_SIDE = 100, SLOT_UPLOAD = 200 };
 static int prepare_kernels(fpc_ctx* c, const fpc_config* cfg) {
   for (int k = 0; k < K_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_kinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_kinds[k].lds_bytes));
+  for (const LeanKindInfo& l : g_lean_kinds) HIPCHECK(hipFuncSetAttribute(l.fn, hipFuncAttributeMaxDynamicSharedMemorySize, l.lds_bytes));
   for (int k = 0; k < WK_COUNT; ++k)
     HIPCHECK(hipFuncSetAttribute(g_wkinds[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_wkinds[k].lds_bytes));
   for (int k = 0; k < BK_COUNT; ++k)
@@ -2976,6 +3027,8 @@ int fpc_create(fpc_ctx** out, const fpc_config* cfg) {
     c->xcd_order = !(pf & FPC_PLAN_NO_XCD_ORDER);
     c->fuse_stem_pool = !(pf & FPC_PLAN_NO_FUSED_STEM_POOL);
     c->stem_lean = !(pf & FPC_PLAN_STEM_ROUND3);
+    c->conv_lean = !(pf & FPC_PLAN_CONV_ROUND1);
+    if (const char* e = getenv("FPC_CONV_LEAN")) c->conv_lean = atoi(e) != 0;
     if (const char* e = getenv("FPC_STEM_LEAN")) c->stem_lean = atoi(e) != 0;
     // Round 4, with the streams on hardware queues of their own: one context, two sub-batches, Python network, fp32 MFMA:
     // 10 740 -> 10 845 frames/s (steady 10 790 -> 10 930; two runs each); the C++ network loses 2 %, bf16 HD and the QVGA
@@ -3824,7 +3877,7 @@ int fpc_get_timings(fpc_ctx* c, int cap, const char** names, const char** kernel
       if (op) switch (op->type) {
           case OP_STEM: k = c->bf16 ? "stem_bf16_kernel" : c->split ? "stem_pool_x3_kernel" : c->stem2 ? "stem_pool2_kernel" : c->fuse_stem_pool ? "stem_pool_kernel" : "stem_kernel"; break;
           case OP_POOL: k = "maxpool_kernel"; break;
-          case OP_CONV: k = g_kinds[op->kind].symbol; break;
+          case OP_CONV: k = op->lean ? lean_kind(op->kind)->symbol : g_kinds[op->kind].symbol; break;
           case OP_BLOCK: k = g_bkinds[op->bkind].symbol; break;
           case OP_WBLOCK: k = g_wkinds[op->wkind].symbol; break;
           case OP_BF16: k = g_fkinds[op->fkind].symbol; break;

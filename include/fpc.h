@@ -137,6 +137,7 @@ enum {
   FPC_PLAN_DETECTOR_GEN1 = 1 << 16,        /* the detector's 65-channel blocks on round 1's kernel in batch calls too       (FPC_WINOGRAD_DET_GEN=1) */
   FPC_PLAN_W36_ONE_WAVE = 1 << 18,         /* the 64-channel F(4x4,3x3) layers on round 3's one-wave-per-SIMD kernel instead of round 5's two  (FPC_W36_PAIRED=0) */
   FPC_PLAN_STEM_ROUND3 = 1 << 20,          /* FPC_F32: round 3's stem_pool_kernel also where round 5's stem_pool2_kernel applies (conv map of whole 16x16 tiles) (FPC_STEM_LEAN=0) */
+  FPC_PLAN_CONV_ROUND1 = 1 << 21,          /* FPC_F32: round 1's conv_mfma_kernel also where round 5's conv2_mfma_kernel applies (ConvTranspose, layer_in.1's 1x1) (FPC_CONV_LEAN=0) */
   FPC_PLAN_CONVT_PHASES = 1 << 19,         /* FPC_BF16: the ConvTranspose as four output-parity launches (rounds 2-4) instead of round 5's one  (FPC_CONVT_FUSED=0) */
   FPC_PLAN_GUARD_ZONES = 1 << 15           /* TEST FACILITY: 64 KiB of a canary pattern behind every buffer of the workspace and
                                               2 GiB behind the last one (the workspace grows by that much); fpc_check_guards
