@@ -395,4 +395,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void block_mfma_kernel(const BlockA
   FPC_STAMP(5)
 }
 
+// (Round 5 measured this kernel on the diet that paid for the stem and for conv_mfma_kernel -- staging offsets once per
+// workgroup, descriptors instead of 64-bit pointers, phase 2's accumulators from the MFMA's inline 0, 32-bit epilogue addresses:
+// 1 039 -> 589 and 875 -> 472 static VALU instructions for the two default-plan instances -- and found nothing: layer2.0 0.263 ->
+// 0.268 ms, layer_in.0 0.244 -> 0.243; with conv2's fragments or the projection's pixels through descriptors + scalar step
+// offsets layer_in.0 was 6-12 % SLOWER.  The variant is not kept; HISTORY.md R5.10.)
+
 }  // namespace fpc

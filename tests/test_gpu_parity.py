@@ -499,6 +499,8 @@ def test_packed_weight_blob_round_trip(torch_gpu):
     {"FPC_LATENCY_TILES": "0", "FPC_WINOGRAD_GEN": "1"},     # round 1's
     {"FPC_LATENCY_TILES": "0", "FPC_WINOGRAD_DET_GEN": "1"},  # F(4x4,3x3) blocks, but the detector's 65 channels on round 1's kernel (FPC_PLAN_DETECTOR_GEN1)
     {"FPC_LATENCY_TILES": "0", "FPC_W36_PAIRED": "0"},       # the 64-channel layers on round 3's one-wave-per-SIMD kernel (FPC_PLAN_W36_ONE_WAVE)
+    {"FPC_CONV_LEAN": "0", "FPC_STEM_LEAN": "0"},            # round 1's conv_mfma_kernel / round 3's stem where round 5's leaner instances apply
+    {"FPC_LATENCY_TILES": "0", "FPC_CONV_LEAN": "0"},        # ... in the batch plan
 ])
 def test_alternative_plans_agree(torch_gpu, golden_dir, env):
     """Every launch plan the library can be switched to (environment knobs read at fpc_create) must

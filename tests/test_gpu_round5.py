@@ -411,3 +411,28 @@ def test_bf16_conv_transpose_in_one_launch_and_in_four_agree(golden_dir):
         assert float(rel.max()) <= 2.0 ** -7 and float((rel > 0).mean()) < 0.005, (h, w, float(rel.max()), float((rel > 0).mean()))
         ef.close()
         ep.close()
+
+
+def test_the_lean_convolution_kernel_gives_the_bits_of_the_one_it_replaces():
+    """conv2_mfma_kernel (round 5: the fp32 ConvTranspose phases and descriptor.layer_in.1's 1x1) does conv_mfma_kernel's
+    arithmetic in conv_mfma_kernel's order with a third of its VALU instructions: dense maps and keypoints of the two plans
+    are identical bit for bit, on a batch plan (VGA, maps of whole tiles) and on a map with partial tiles and an odd batch."""
+    sd = synth.make_state_dict(17, dustbin_bias=4.0)
+    for (h, w, n) in ((480, 640, 3), (144, 208, 5)):
+        frames = synth.make_batch(60, n, h, w)
+        e2 = engine(h, w, n)
+        e1 = engine(h, w, n, plan_flags=["conv_round1"])
+        assert e2.plan_hash() == e1.plan_hash()                      # the same fragments: not a layout choice
+        e2.load_state_dict(sd)
+        e1.load_state_dict(sd)
+        k2, k1 = e2.kernel_names(frames), e1.kernel_names(frames)
+        assert any("conv2_mfma_kernel" in k for k in k2) and not any("conv2_mfma_kernel" in k for k in k1), (k2, k1)
+        o2, o1 = e2.forward(frames), e1.forward(frames)
+        for a, b in zip(o2, o1):
+            np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+        for a, b in zip(e2.detect(frames), e1.detect(frames)):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(a[2], b[2])
+        e2.close()
+        e1.close()

@@ -341,3 +341,22 @@ def test_round5_bf16_conv_transpose_kernel_keeps_its_registers(code_object):
     assert not any(i.startswith("scratch_") for _, i in body)
     loop = _chunk_loop(body)
     assert loop is not None and loop[2] == 72, loop
+
+
+def test_round5_conv2_kernel_is_lean_and_spill_free(code_object):
+    """conv2_mfma_kernel (csrc/conv_mfma.h): the two default-plan instances hold nothing in scratch, no AGPR, and well under
+    half of the VALU instructions of the conv_mfma_kernel instances they replace (1 372 / 1 255 -> 473 / 436 when written)."""
+    funcs, meta = code_object
+    valu = lambda body: sum(1 for _, i in body if i.startswith("v_") and not i.startswith("v_mfma"))
+    pairs = 0
+    for name, body in funcs.items():
+        m = re.match(r"_ZN3fpc17conv2_mfma_kernelI(.+)EEvNS_8ConvArgsE$", name)
+        if not m:
+            continue
+        old = "_ZN3fpc16conv_mfma_kernelI%sEEvNS_8ConvArgsE" % m.group(1)
+        assert old in funcs, old
+        mm = meta[name]
+        assert mm["agpr_count"] == 0 and mm["vgpr_spill_count"] == 0 and mm["private_segment_fixed_size"] == 0, (name, mm)
+        assert 2 * valu(body) < valu(funcs[old]), (name, valu(body), valu(funcs[old]))
+        pairs += 1
+    assert pairs == 2, pairs
