@@ -4,6 +4,8 @@
 * Stream placement (csrc/queue_map.h): cheap, bounded, observable (fpc_stream_report), keyed by context, and without any
   influence on results (FPC_QUEUE_PROBE=0 gives the same bits).
 * Sampled timing covers every entry point.
+* The kernels round 5 added behind plan switches against the ones they replace: stem_pool2_kernel / stem_pool_kernel,
+  conv2_mfma_kernel / conv_mfma_kernel (bit-equal), convt_bf16_kernel / the four ConvTranspose phase launches.
 """
 import os
 import time
