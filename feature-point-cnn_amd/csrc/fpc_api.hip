@@ -1846,10 +1846,9 @@ postproc:
   c->stem.H = H; c->stem.W = W; c->stem.Ho = H2; c->stem.Wo = W2;
   c->stem.tiles_x = (W2 + STEM_T - 1) / STEM_T;
   c->stem.tiles_y = (H2 + STEM_T - 1) / STEM_T;
-  // round 5: the fp32 stem + pool on stem_pool2_kernel where the conv map is whole tiles (VGA, HD; QVGA's 120 rows are
-  // not).  The fragments carry the bias as a K step in EVERY geometry (pack layout revision 4; stem_pool_kernel and
+  // round 5: the fp32 stem + pool on stem_pool2_kernel where the conv map's width is whole tiles (VGA, HD, QVGA).  The fragments carry the bias as a K step in EVERY geometry (pack layout revision 4; stem_pool_kernel and
   // stem_kernel skip that step), so the choice is a launch-time one and blobs stay exchangeable between geometries
-  c->stem2 = c->stem_lean && !c->bf16 && !c->split && !c->vgg && (c->fuse_stem_pool || c->cin == 1) && H2 % STEM_T == 0 && W2 % STEM_T == 0;
+  c->stem2 = c->stem_lean && !c->bf16 && !c->split && !c->vgg && (c->fuse_stem_pool || c->cin == 1) && H2 % 2 == 0 && W2 % STEM_T == 0;
   return FPC_OK;
 }
 

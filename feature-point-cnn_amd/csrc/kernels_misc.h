@@ -361,8 +361,8 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// Round 5: stem_pool_kernel on a VALU diet, for maps of whole tiles (Ho, Wo multiples of 16: VGA, HD; others keep
-// stem_pool_kernel).  On gfx950 the fp32 MFMA and the VALU exclude each other on a SIMD (wblock36_mfma.h), and the
+// Round 5: stem_pool_kernel on a VALU diet, for maps whose WIDTH is whole tiles (Wo a multiple of 16: VGA, HD, QVGA; a
+// last tile row of fewer than 16 conv rows takes a masked tile write; other widths keep stem_pool_kernel).  On gfx950 the fp32 MFMA and the VALU exclude each other on a SIMD (wblock36_mfma.h), and the
 // shipped stem_pool_kernel<3> issues ~900 VALU instructions per wave and tile around its 304 MFMAs (static count of the
 // code object: 251 in the prologue, 52 in the K loop, 669 in the epilogue, 408 of them v_max_f32) -- a fifth of its
 // matrix time.  Here:
@@ -514,14 +514,25 @@ __global__ __launch_bounds__(256, 4) void stem_pool2_kernel(const StemPoolArgs a
   const int wbase = (wave * 64 + 4 * half) * STEM_TROW + l31;
   const int r0 = j == 0 ? 0 : 2 * j - 1;
   const int rd0 = r0 * STEM_T * STEM_TROW + c, rd1 = 2 * j * STEM_T * STEM_TROW + c;
-  const bool has_col8 = tx * 8 + 8 < a.Wp, has_row8 = ty * 8 + 8 < a.Hp;   // pooled column / row 8 of the tile exists (it is the next tile's 0)
+  const bool has_col8 = tx * 8 + 8 < a.Wp, has_row8 = ty * 8 + 8 < a.Hp;
+  const int rows_valid = min(STEM_T, a.Ho - ty * STEM_T);   // (uniform) conv rows of the tile inside the map
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     FPC_LDS_BARRIER();   // (LDS hand-offs only: __syncthreads() would also wait for the first half's stores and atomics)
+    if (rows_valid == STEM_T) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lds[wbase + (mb * 32 + (r & 3) + 8 * (r >> 2)) * STEM_TROW] = acc[mb][nb][r];
+        for (int r = 0; r < 16; ++r) lds[wbase + (mb * 32 + (r & 3) + 8 * (r >> 2)) * STEM_TROW] = acc[mb][nb][r];
+    } else {   // the map's last tile row (Ho not a multiple of 16): conv rows below the map leave every maximum alone
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wave * 2 + mb) * 2 + (r >> 3);   // (wave-uniform)
+          lds[wbase + (mb * 32 + (r & 3) + 8 * (r >> 2)) * STEM_TROW] = row < rows_valid ? acc[mb][nb][r] : -3.0e38f;
+        }
+    }
     FPC_LDS_BARRIER();
     float cm[STEM_T];
 #pragma unroll
@@ -533,7 +544,9 @@ __global__ __launch_bounds__(256, 4) void stem_pool2_kernel(const StemPoolArgs a
     for (int px = 1; px < 8; ++px) mx[px] = stem_relu(stem_max3(cm[2 * px - 1], cm[2 * px], cm[2 * px + 1]));
     mx[8] = stem_relu(cm[15]);
     float* row = a.out + ((size_t)(b * a.Hp + ty * 8 + j) * a.Wp + tx * 8) * 64 + nb * 32 + c;
-    if (j == 0) {
+    if (ty * 8 + j >= a.Hp) {
+      // (a pooled row below the map: only in the last tile row of a map whose height is not a multiple of 16)
+    } else if (j == 0) {
 #pragma unroll
       for (int px = 0; px < 8; ++px) atomicMax(reinterpret_cast<unsigned int*>(row + px * 64), __float_as_uint(mx[px]));
     } else {
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(256, 4) void stem_pool2_kernel(const StemPoolArgs a
 #pragma unroll
       for (int px = 1; px < 8; ++px) row[px * 64] = mx[px];
     }
-    if (has_col8) atomicMax(reinterpret_cast<unsigned int*>(row + 8 * 64), __float_as_uint(mx[8]));
+    if (has_col8 && ty * 8 + j < a.Hp) atomicMax(reinterpret_cast<unsigned int*>(row + 8 * 64), __float_as_uint(mx[8]));
     if (has_row8 && j == 0) {   // pooled row 8: conv row 15 only, the rest of its windows belongs to the tile below
       float* row8 = row + (size_t)8 * a.Wp * 64;
       const int rd = 15 * STEM_T * STEM_TROW + c;

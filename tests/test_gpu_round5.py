@@ -346,7 +346,7 @@ def test_a_non_finite_pixel_is_reported_and_stays_in_its_frame():
 
 
 def test_round5_stem_and_its_round3_form_agree(golden_dir):
-    """Round 5's stem_pool2_kernel (whole-tile maps: VGA here; bias as a K step, v_max3 pooling) against round 3's
+    """Round 5's stem_pool2_kernel (bias as a K step, v_max3 pooling; VGA: whole tiles, then maps with a partial last tile row) against round 3's
     stem_pool_kernel (FPC_PLAN_STEM_ROUND3) and against the reference's fixture: the pooled stem tensor within 2e-6 of
     each other (the bias enters the fp32 sum at the other end), both within 1e-4 of the fixture's probes, identical
     keypoints; the switch is not part of the packed layout (same plan hash, blobs exchangeable), and the gray instance
@@ -373,6 +373,19 @@ def test_round5_stem_and_its_round3_form_agree(golden_dir):
     gx, gy = g["points_x"].astype(np.int64), g["points_y"].astype(np.int64)
     np.testing.assert_array_equal(np.sort(r5[2][0][:, 1].astype(np.int64) * w + r5[2][0][:, 0]), np.sort(gy * w + gx))
     e3.close()
+    # maps whose last tile row is partial (conv map height not a multiple of 16: QVGA's 120 rows, 72 rows): the masked tile write
+    for (hh, ww, nn) in ((240, 320, 2), (144, 224, 3)):
+        fr = synth.make_batch(77, nn, hh, ww)
+        a5, a3 = engine(hh, ww, nn), engine(hh, ww, nn, plan_flags=["stem_round3"])
+        a5.load_state_dict(sd)
+        a3.load_state_dict(sd)
+        assert "stem_pool2_kernel" in " ".join(a5.kernel_names(fr)) and "stem_pool2_kernel" not in " ".join(a3.kernel_names(fr))
+        a5.forward(fr)
+        a3.forward(fr)
+        q5, q3 = a5.activation("pool", 0, nn).cpu().numpy(), a3.activation("pool", 0, nn).cpu().numpy()
+        assert q5.shape == q3.shape and float(np.abs(q5 - q3).max()) < 2e-6 * max(1.0, float(np.abs(q3).max())), (hh, ww)
+        a5.close()
+        a3.close()
     # gray plane: stem_pool2_kernel<1>
     rgb = np.stack([synth.make_frame(300 + i, h, w, gray=True).transpose(2, 0, 1) for i in range(2)])
     e1 = engine(h, w, 3, in_channels=1)
